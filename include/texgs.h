@@ -1,0 +1,148 @@
+/*
+ * texgs.h -- C ABI of libtexgs.so, the MI355X (gfx950) textured Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of slothfulxtx/Texture-GS: the operator the
+ * reference imports at render/uv_tex_render.py:4 (`from diff_gauss_uv_tex import
+ * GaussianRasterizationSettings, GaussianRasterizer`) and calls at render/uv_tex_render.py:56-66,
+ * plus its autograd backward (triggered at models/texture_gaussian3d.py:410).  In the reference that
+ * module is a pybind11 extension (`_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward`, not in
+ * the reference tree -- un-vendored pip dependency, requirements.txt:15); the entry points below are
+ * what a binding for this path binds instead.  Plain pointers and sizes only: no torch / C++ types.
+ *
+ * All pointers are DEVICE pointers unless a field says "host".  All buffers are caller-allocated
+ * (the Python host layer allocates them through torch's caching allocator so stream semantics hold);
+ * the library keeps no global or static scratch, so several forwards may be alive before a backward
+ * (models/texture_gaussian3d.py:318 and :378 both precede :410).  Kernels are enqueued on the
+ * `stream` argument (a hipStream_t passed as void*).  Every function returns 0 on success, non-zero
+ * on failure; texgs_last_error() then returns a thread-local message.
+ */
+#ifndef TEXGS_H
+#define TEXGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEXGS_ABI_VERSION 1
+#define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
+#define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
+#define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
+
+/* Per-call configuration = GaussianRasterizationSettings (render/uv_tex_render.py:25-38). */
+typedef struct TexGSFrame {
+    int32_t image_height;      /* :26 */
+    int32_t image_width;       /* :27 */
+    float   tanfovx;           /* :28 */
+    float   tanfovy;           /* :29 */
+    float   scale_modifier;    /* :31 */
+    int32_t sh_degree;         /* :35 active degree 0..3                                               */
+    int32_t sh_coeffs;         /* shs.shape[1] (15 for max degree 3); 0 when shs is NULL               */
+    int32_t tex_res;           /* R of texture[6,R,R,3] (models/texture_gaussian3d.py:51)              */
+    int32_t num_gaussians;     /* N                                                                    */
+    int32_t debug;             /* :37 -- sync + error check after every launch                         */
+    const float* bg;           /* :30 f32[3]                                                           */
+    const float* viewmatrix;   /* :32 f32[16], row-vector (transposed) form of utils/cameras.py:62     */
+    const float* projmatrix;   /* :33 f32[16], full world->clip, utils/cameras.py:64                   */
+    const float* campos;       /* :36 f32[3]                                                           */
+} TexGSFrame;
+
+/* Operator inputs = kwargs of render/uv_tex_render.py:56-66 (means2D is a zero grad-carrier, never read). */
+typedef struct TexGSInputs {
+    const float* means3D;      /* f32[N,3]                                                             */
+    const float* shs;          /* f32[N,K,3] view-dependent SH coefficients 1..K, or NULL              */
+    const float* opacities;    /* f32[N]   (sigmoid-activated, models/texture_gaussian3d.py:239)       */
+    const float* scales;       /* f32[N,3] (exp-activated, :197)                                       */
+    const float* rotations;    /* f32[N,4] (w,x,y,z), unit (:201)                                      */
+    const float* uvs;          /* f32[N,3] phi(mu) on the unit sphere (:229-236)                       */
+    const float* gradient_uvs; /* f32[N,9] [3*i+j] = d uv_i / d x_j (:216-227)                         */
+    const float* texture;      /* f32[6,R,R,3] SH-DC valued cubemap (:51, :16-21)                      */
+} TexGSInputs;
+
+/* Per-Gaussian state written by texgs_preprocess_forward. */
+typedef struct TexGSGeom {
+    float*    rec;             /* f32[N,32]: xy(2) conic(3) opacity g(2) | G(6) phi(3) viewdep(3) depth normal(3) | pad */
+    float*    depth;           /* f32[N] view-space z (sort key)                                       */
+    int32_t*  radii;           /* i32[N] screen radius in px; 0 = culled (operator output `radii`)     */
+    uint32_t* rect;            /* u32[N,2]: (minx | miny<<16), (maxx | maxy<<16) tile rectangle        */
+    uint32_t* tiles_touched;   /* u32[N]                                                               */
+    uint32_t* offsets;         /* u32[N] inclusive prefix sum of tiles_touched                         */
+    void*     scan_temp;       /* >= texgs_scan_temp_bytes(N)                                          */
+    size_t    scan_temp_bytes;
+} TexGSGeom;
+
+/* Tile binning buffers, sized from num_rendered (D). */
+typedef struct TexGSBinning {
+    uint32_t  num_rendered;    /* D = offsets[N-1] (host value)                                        */
+    uint64_t* keys_unsorted;   /* u64[D]  (tile_id << 32) | float_bits(depth)                          */
+    uint64_t* keys_sorted;     /* u64[D]                                                               */
+    uint32_t* vals_unsorted;   /* u32[D]  Gaussian index                                               */
+    uint32_t* point_list;      /* u32[D]  Gaussian index, sorted by (tile, depth), stable              */
+    uint32_t* ranges;          /* u32[T,2] [first,last) into point_list per tile; caller zero-fills    */
+    void*     sort_temp;       /* >= texgs_sort_temp_bytes(D, T)                                       */
+    size_t    sort_temp_bytes;
+} TexGSBinning;
+
+/* Operator outputs (render/uv_tex_render.py:56) + the per-pixel state the backward replays. */
+typedef struct TexGSImage {
+    float*    out_color;       /* f32[3,H,W]                                                           */
+    float*    out_depth;       /* f32[1,H,W]                                                           */
+    float*    out_norm;        /* f32[3,H,W]                                                           */
+    float*    out_alpha;       /* f32[1,H,W]                                                           */
+    float*    final_T;         /* f32[H,W]                                                             */
+    uint32_t* n_contrib;       /* u32[H,W] 1-based position of the last contributor in the tile list   */
+} TexGSImage;
+
+/* Backward: upstream grads in, input grads out.  NULL dL_dout pointers mean "zero". */
+typedef struct TexGSGrads {
+    const float* dL_dcolor;    /* f32[3,H,W] or NULL */
+    const float* dL_ddepth;    /* f32[1,H,W] or NULL */
+    const float* dL_dnorm;     /* f32[3,H,W] or NULL */
+    const float* dL_dalpha;    /* f32[1,H,W] or NULL */
+    float* acc;                /* f32[N,24] caller zero-filled; scratch between the two backward kernels */
+    float* dL_dmeans3D;        /* f32[N,3]                                                             */
+    float* dL_dmeans2D;        /* f32[N,3] dL/d(ndc xy), z = 0 (lineage convention)                    */
+    float* dL_dshs;            /* f32[N,K,3] or NULL                                                   */
+    float* dL_dopacities;      /* f32[N]                                                               */
+    float* dL_dscales;         /* f32[N,3]                                                             */
+    float* dL_drotations;      /* f32[N,4]                                                             */
+    float* dL_duvs;            /* f32[N,3]                                                             */
+    float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
+} TexGSGrads;
+
+int         texgs_abi_version(void);
+const char* texgs_last_error(void);
+
+size_t texgs_scan_temp_bytes(int32_t num_gaussians);
+size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
+
+/* K1 (frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold) + K2
+ * (inclusive scan of tiles_touched).  Replaces the first half of _C.rasterize_gaussians. */
+int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, void* stream);
+
+/* The one device->host sync of the forward: D = offsets[N-1].  (Same sync exists in the lineage.) */
+int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream);
+
+/* K3 duplicate-with-keys, K4 radix sort of 32+ceil(log2 T) key bits, K5 tile ranges, K6 16x16-tile
+ * alpha-blend with cubemap fetch.  Second half of _C.rasterize_gaussians. */
+int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                                  TexGSBinning* bin, TexGSImage* img, void* stream);
+
+/* K6 alone on existing binning (re-render with a different texture / sh_degree-independent state). */
+int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                         const TexGSBinning* bin, TexGSImage* img, void* stream);
+
+/* K7 (back-to-front replay, per-Gaussian partials + texture-grad scatter) + K8 (chain to the operator's
+ * inputs).  Replaces _C.rasterize_gaussians_backward. */
+int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                   const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream);
+
+/* Frustum test only (upstream API `markVisible`; unused by the reference). visible: u8[N]. */
+int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXGS_H */

@@ -1,0 +1,81 @@
+"""Shared helpers for the parity tests: build identical inputs for the HIP operator and the oracle."""
+import math
+
+import torch
+
+from texgs import synth
+from oracle import texgs_torch as O
+
+
+def settings_for(cam, sh_degree, bg, device=None, cls=None, scale_modifier=1.0, debug=False):
+    cls = cls or O.Settings
+    mv = (lambda t: t.to(device)) if device is not None else (lambda t: t)
+    return cls(image_height=cam.image_height, image_width=cam.image_width,
+               tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+               bg=mv(bg), scale_modifier=scale_modifier, viewmatrix=mv(cam.world_view_transform),
+               projmatrix=mv(cam.full_proj_transform), sh_degree=sh_degree, campos=mv(cam.camera_center),
+               prefiltered=False, debug=debug)
+
+
+def oracle_run(scene, cam, sh_degree, bg, with_grad=False, target=None, nhat=None, dtype=torch.float64,
+               depth_weight=0.0, scale_modifier=1.0):
+    st = settings_for(cam, sh_degree, bg, scale_modifier=scale_modifier)
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
+    leaves = {n: getattr(scene, n).clone().to(dtype).requires_grad_(with_grad) for n in names}
+    m2 = torch.zeros_like(leaves["means3D"], requires_grad=with_grad)
+    res, dbg = O.rasterize(leaves["means3D"], m2, leaves["shs"], leaves["opacities"], leaves["scales"],
+                           leaves["rotations"], leaves["uvs"], scene.gradient_uvs.to(dtype), leaves["texture"],
+                           st, dtype=dtype, debug=True)
+    grads = None
+    if with_grad:
+        img, depth, norm, alpha = res[0], res[1], res[2], res[3]
+        L = synth.synthetic_loss(img, alpha, norm, target.to(dtype), nhat.to(dtype))
+        if depth_weight:
+            L = L + depth_weight * depth.mean()
+        L.backward()
+        grads = {n: leaves[n].grad for n in names}
+        grads["means2D"] = m2.grad
+    return res, dbg, grads
+
+
+def hip_run(scene, cam, sh_degree, bg, with_grad=False, target=None, nhat=None, depth_weight=0.0,
+            scale_modifier=1.0, debug=False):
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, forward_raw
+    dev = torch.device("cuda:0")
+    st = settings_for(cam, sh_degree, bg, device=dev, cls=GaussianRasterizationSettings,
+                      scale_modifier=scale_modifier, debug=debug)
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
+    leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(with_grad) for n in names}
+    m2 = torch.zeros_like(leaves["means3D"], requires_grad=with_grad)
+    rast = GaussianRasterizer(raster_settings=st)
+    out = rast(means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"], opacities=leaves["opacities"],
+               scales=leaves["scales"], rotations=leaves["rotations"], uvs=leaves["uvs"],
+               gradient_uvs=scene.gradient_uvs.to(dev), texture=leaves["texture"], extra_attrs=None)
+    grads = None
+    if with_grad:
+        img, depth, norm, alpha = out[0], out[1], out[2], out[3]
+        L = synth.synthetic_loss(img, alpha, norm, target.to(dev), nhat.to(dev))
+        if depth_weight:
+            L = L + depth_weight * depth.mean()
+        L.backward()
+        grads = {n: leaves[n].grad.detach().cpu() for n in names}
+        grads["means2D"] = m2.grad.detach().cpu()
+    return out, grads
+
+
+def hip_debug_state(scene, cam, sh_degree, bg):
+    """Forward through forward_raw to expose the integer intermediates."""
+    from texgs.rasterizer import GaussianRasterizationSettings, forward_raw
+    dev = torch.device("cuda:0")
+    st = settings_for(cam, sh_degree, bg, device=dev, cls=GaussianRasterizationSettings)
+    t = lambda x: x.to(dev)
+    outs, s = forward_raw(st, t(scene.means3D), t(scene.shs), t(scene.opacities), t(scene.scales),
+                          t(scene.rotations), t(scene.uvs), t(scene.gradient_uvs), t(scene.texture))
+    torch.cuda.synchronize()
+    return outs, s
+
+
+def rel_err(a, b):
+    a = a.double().reshape(-1)
+    b = b.double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -1,0 +1,57 @@
+"""Build libtexgs.so (hipcc, gfx950 only) in-tree.  Usage: python texture-gs_amd/build.py [--force] [--verbose]
+
+Objects are rebuilt only when their sources are newer.  preprocess.hip is built with -ffp-contract=off (its
+fp32 operation order is part of the bit-exact key/rect/radius contract); the render kernels allow contraction
+and use hardware fp32 atomics (-munsafe-fp-atomics).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libtexgs.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+UNITS = {
+    "preprocess.hip": ["-ffp-contract=off"],
+    "binning.hip": [],
+    "render.hip": ["-munsafe-fp-atomics", "-ffp-contract=fast"],
+    "abi.hip": [],
+}
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "texgs.h")]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    for src, flags in UNITS.items():
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _newer([sp] + HEADERS + [os.path.abspath(__file__)], op):
+            cmd = [HIPCC] + COMMON + flags + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _newer(objs, LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

@@ -1,0 +1,136 @@
+// C-ABI entry points of libtexgs.so (declared in include/texgs.h).  No C++ types or exceptions cross this
+// boundary: int return codes + a thread-local error string.
+#include "common.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* where, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e ? (int)e : -1;
+}
+
+int fail_msg(const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return -1;
+}
+
+// After every launch: cheap async check; with debug=1 also a stream sync (lineage `debug` semantics,
+// render/uv_tex_render.py:37).
+int check(const TexGSFrame* f, hipStream_t s, const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(where, e);
+    if (f->debug) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(where, e);
+    }
+    return 0;
+}
+
+int validate_frame(const TexGSFrame* f) {
+    if (!f) return fail_msg("frame is NULL");
+    if (f->image_height <= 0 || f->image_width <= 0) return fail_msg("image size must be positive");
+    if (f->image_width > 65535 * TEXGS_TILE || f->image_height > 65535 * TEXGS_TILE) return fail_msg("image too large");
+    if (f->sh_degree < 0 || f->sh_degree > 3) return fail_msg("sh_degree must be in [0,3]");
+    if (f->num_gaussians < 0) return fail_msg("num_gaussians < 0");
+    if (f->tex_res <= 0) return fail_msg("tex_res must be positive");
+    if (!f->bg || !f->viewmatrix || !f->projmatrix || !f->campos) return fail_msg("frame device pointers must be non-NULL");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int texgs_abi_version(void) { return TEXGS_ABI_VERSION; }
+
+const char* texgs_last_error(void) { return g_err; }
+
+size_t texgs_scan_temp_bytes(int32_t num_gaussians) { return scan_temp_bytes(num_gaussians); }
+
+size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles) { return sort_temp_bytes(num_rendered, num_tiles); }
+
+int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, void* stream) {
+    if (int r = validate_frame(frame)) return r;
+    if (!in || !geom) return fail_msg("NULL argument");
+    if (frame->num_gaussians == 0) return 0;
+    if (!in->means3D || !in->opacities || !in->scales || !in->rotations || !in->uvs || !in->gradient_uvs)
+        return fail_msg("per-Gaussian input pointer is NULL");
+    if (geom->scan_temp_bytes < scan_temp_bytes(frame->num_gaussians)) return fail_msg("scan_temp too small");
+    hipStream_t s = (hipStream_t)stream;
+    const CamConst c = make_cam(frame);
+    launch_preprocess_fwd(c, frame, in, geom, s);
+    if (int r = check(frame, s, "preprocess_fwd")) return r;
+    if (int r = launch_scan(geom, frame->num_gaussians, s)) return fail("inclusive_scan", (hipError_t)r);
+    return check(frame, s, "inclusive_scan");
+}
+
+int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream) {
+    if (!geom || !host_out) return fail_msg("NULL argument");
+    *host_out = 0;
+    if (num_gaussians <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(host_out, geom->offsets + (num_gaussians - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return fail("num_rendered readback", e);
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail("num_rendered sync", e);
+    return 0;
+}
+
+int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                         const TexGSBinning* bin, TexGSImage* img, void* stream) {
+    if (int r = validate_frame(frame)) return r;
+    if (!in || !geom || !bin || !img) return fail_msg("NULL argument");
+    if (!in->texture) return fail_msg("texture is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const CamConst c = make_cam(frame);
+    launch_render_fwd(c, frame, in, geom, bin, img, s);
+    return check(frame, s, "render_fwd");
+}
+
+int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                                  TexGSBinning* bin, TexGSImage* img, void* stream) {
+    if (int r = validate_frame(frame)) return r;
+    if (!in || !geom || !bin || !img) return fail_msg("NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    const CamConst c = make_cam(frame);
+    if (bin->num_rendered > 0) {
+        if (bin->sort_temp_bytes < sort_temp_bytes(bin->num_rendered, (uint32_t)(c.tiles_x * c.tiles_y)))
+            return fail_msg("sort_temp too small");
+        launch_duplicate(c, geom, bin, s);
+        if (int r = check(frame, s, "duplicate_with_keys")) return r;
+        if (int r = launch_sort(c, bin, s)) return fail("radix_sort_pairs", (hipError_t)r);
+        if (int r = check(frame, s, "radix_sort_pairs")) return r;
+        launch_ranges(c, bin, s);
+        if (int r = check(frame, s, "tile_ranges")) return r;
+    }
+    return texgs_render_forward(frame, in, geom, bin, img, stream);
+}
+
+int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                   const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
+    if (int r = validate_frame(frame)) return r;
+    if (!in || !geom || !bin || !img || !grads) return fail_msg("NULL argument");
+    if (!grads->acc || !grads->dL_dtexture) return fail_msg("acc / dL_dtexture must be allocated (zero-filled)");
+    hipStream_t s = (hipStream_t)stream;
+    const CamConst c = make_cam(frame);
+    if (bin->num_rendered > 0) {
+        launch_render_bwd(c, frame, in, geom, bin, img, grads, s);
+        if (int r = check(frame, s, "render_bwd")) return r;
+    }
+    launch_preprocess_bwd(c, frame, in, geom, grads, s);
+    return check(frame, s, "preprocess_bwd");
+}
+
+int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream) {
+    if (int r = validate_frame(frame)) return r;
+    if (!means3D || !visible) return fail_msg("NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    launch_mark_visible(frame, means3D, visible, s);
+    return check(frame, s, "mark_visible");
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Shared declarations for the gfx950 kernels of libtexgs.so.  CDNA4 only: wave64, 160 KiB LDS/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "texgs.h"
+
+// ---- operator constants (restated in oracle/texgs_torch.py) ----
+#define TG_NEAR_Z        0.2f
+#define TG_LOWPASS       0.3f
+#define TG_FRUSTUM_CLAMP 1.3f
+#define TG_ALPHA_MAX     0.99f
+#define TG_ALPHA_MIN     (1.0f / 255.0f)
+#define TG_T_EPS         1e-4f
+#define TG_PLANE_EPS     1e-4f
+#define TG_DEN_MIN       0.05f
+#define TG_MA_MIN        1e-20f
+#define TG_SH_C0         0.28209479177387814f
+
+// record / accumulator slots (float index)
+enum {
+    R_XY = 0, R_CONIC = 2, R_OP = 5, R_G2 = 6, R_GM = 8, R_PHI = 14, R_VD = 17, R_DEPTH = 20, R_N = 21
+};
+
+#define TG_BLOCK 256
+
+struct CamConst {       // small per-frame constants passed by value in kernel args (SGPRs)
+    int W, H, tiles_x, tiles_y;
+    float fx, fy, tanfovx, tanfovy;
+    float scale_modifier;
+    int sh_degree, sh_coeffs, R, N;
+};
+
+static inline CamConst make_cam(const TexGSFrame* f) {
+    CamConst c;
+    c.W = f->image_width; c.H = f->image_height;
+    c.tiles_x = (c.W + TEXGS_TILE - 1) / TEXGS_TILE;
+    c.tiles_y = (c.H + TEXGS_TILE - 1) / TEXGS_TILE;
+    c.tanfovx = f->tanfovx; c.tanfovy = f->tanfovy;
+    c.fx = (float)c.W / (2.0f * f->tanfovx);
+    c.fy = (float)c.H / (2.0f * f->tanfovy);
+    c.scale_modifier = f->scale_modifier;
+    c.sh_degree = f->sh_degree; c.sh_coeffs = f->sh_coeffs; c.R = f->tex_res; c.N = f->num_gaussians;
+    return c;
+}
+
+// launchers implemented in the .hip files (host side, called from abi.hip)
+void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, TexGSGeom* g, hipStream_t s);
+void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
+                           TexGSGrads* gr, hipStream_t s);
+void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s);
+int  launch_scan(const TexGSGeom* g, int N, hipStream_t s);
+size_t scan_temp_bytes(int N);
+size_t sort_temp_bytes(uint32_t D, uint32_t T);
+void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStream_t s);
+int  launch_sort(const CamConst& c, TexGSBinning* b, hipStream_t s);
+void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s);
+void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
+                       const TexGSBinning* b, TexGSImage* img, hipStream_t s);
+void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
+                       const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s);

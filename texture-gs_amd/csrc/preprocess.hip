@@ -1,0 +1,490 @@
+// K1 preprocess forward, K8 preprocess backward, K9 mark_visible -- gfx950.
+//
+// Built with -ffp-contract=off: every quantity that feeds an integer stage (depth bits of the sort key,
+// pixel centre -> tile rectangle, radius) is an explicitly ordered sequence of IEEE fp32 operations with
+// correctly rounded '/' and sqrt, so the C oracle (oracle/texgs_ref.c, same operation order, also built
+// without contraction) reproduces keys / rects / radii bit for bit.
+//
+// One thread per Gaussian, 256 threads (4 wave64) per workgroup.  HBM-bound: reads 92+12K B, writes one
+// 128-B record (= one cache line) + 24 B of SoA state per Gaussian.
+#include "common.h"
+
+namespace {
+
+struct Frame {          // per-frame matrices, read through wave-uniform (scalar) loads
+    float V[16];        // row-vector view matrix: t = [m,1] @ V
+    float P[16];        // row-vector full projection
+    float cam[3];
+};
+
+__device__ __forceinline__ Frame load_frame(const float* vm, const float* pm, const float* cp) {
+    Frame f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { f.V[i] = vm[i]; f.P[i] = pm[i]; }
+    f.cam[0] = cp[0]; f.cam[1] = cp[1]; f.cam[2] = cp[2];
+    return f;
+}
+
+// Forward intermediates of one Gaussian, shared by K1 and K8 (K8 recomputes instead of saving ~200 B).
+struct Geo {
+    bool  valid;
+    float m[3], t[3];
+    float hx, hy, hw, pw, xy[2];
+    float q[4], s[3], R[9], M[9], S[6];           // S: xx,xy,xz,yy,yz,zz
+    float txc, tyc; bool clx, cly;
+    float J00, J02, J11, J12, T0[3], T1[3];
+    float a, b, c, det, inv, conic[3];
+    int   radius;
+    int   kmin; float sign; float n[3];
+    float nv[3], sdot; bool degen; float gx, gy, G[6], K[9];
+    float dir[3], dlen;
+};
+
+// Wr[r][c] (world->view rotation, column-vector form) = V[c*4 + r]
+#define WR(F, r, c) ((F).V[(c) * 4 + (r)])
+
+__device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamConst& C, int i,
+                                            const float* __restrict__ means, const float* __restrict__ scales,
+                                            const float* __restrict__ rots, const float* __restrict__ juv) {
+    g.m[0] = means[3 * i + 0]; g.m[1] = means[3 * i + 1]; g.m[2] = means[3 * i + 2];
+    const float mx = g.m[0], my = g.m[1], mz = g.m[2];
+    g.t[0] = F.V[0] * mx + F.V[4] * my + F.V[8] * mz + F.V[12];
+    g.t[1] = F.V[1] * mx + F.V[5] * my + F.V[9] * mz + F.V[13];
+    g.t[2] = F.V[2] * mx + F.V[6] * my + F.V[10] * mz + F.V[14];
+    g.valid = g.t[2] > TG_NEAR_Z;
+    g.radius = 0;
+    if (!g.valid) return;
+    const float tx = g.t[0], ty = g.t[1], tz = g.t[2];
+
+    g.hx = F.P[0] * mx + F.P[4] * my + F.P[8] * mz + F.P[12];
+    g.hy = F.P[1] * mx + F.P[5] * my + F.P[9] * mz + F.P[13];
+    g.hw = F.P[3] * mx + F.P[7] * my + F.P[11] * mz + F.P[15];
+    g.pw = 1.0f / (g.hw + 1e-7f);
+    const float ndcx = g.hx * g.pw, ndcy = g.hy * g.pw;
+    g.xy[0] = ((ndcx + 1.0f) * (float)C.W - 1.0f) * 0.5f;
+    g.xy[1] = ((ndcy + 1.0f) * (float)C.H - 1.0f) * 0.5f;
+
+    // cov3D = (R diag(s)) (R diag(s))^T      (models/gaussian3d.py:17-21, utils/general.py:87-119)
+    g.q[0] = rots[4 * i + 0]; g.q[1] = rots[4 * i + 1]; g.q[2] = rots[4 * i + 2]; g.q[3] = rots[4 * i + 3];
+    const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
+    g.R[0] = 1.0f - 2.0f * (y * y + z * z); g.R[1] = 2.0f * (x * y - r * z); g.R[2] = 2.0f * (x * z + r * y);
+    g.R[3] = 2.0f * (x * y + r * z); g.R[4] = 1.0f - 2.0f * (x * x + z * z); g.R[5] = 2.0f * (y * z - r * x);
+    g.R[6] = 2.0f * (x * z - r * y); g.R[7] = 2.0f * (y * z + r * x); g.R[8] = 1.0f - 2.0f * (x * x + y * y);
+    const float s0 = scales[3 * i + 0], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    g.s[0] = C.scale_modifier * s0; g.s[1] = C.scale_modifier * s1; g.s[2] = C.scale_modifier * s2;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) g.M[rr * 3 + cc] = g.R[rr * 3 + cc] * g.s[cc];
+    const float* M = g.M;
+    g.S[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    g.S[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    g.S[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    g.S[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    g.S[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    g.S[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+
+    // EWA cov2D = (J Wr) S (J Wr)^T + 0.3 I
+    const float limx = TG_FRUSTUM_CLAMP * C.tanfovx, limy = TG_FRUSTUM_CLAMP * C.tanfovy;
+    const float txtz = tx / tz, tytz = ty / tz;
+    g.clx = (txtz < -limx) || (txtz > limx);
+    g.cly = (tytz < -limy) || (tytz > limy);
+    g.txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    g.tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    if (!g.clx) g.txc = tx;
+    if (!g.cly) g.tyc = ty;
+    const float tz2 = tz * tz;
+    g.J00 = C.fx / tz; g.J02 = -(C.fx * g.txc) / tz2;
+    g.J11 = C.fy / tz; g.J12 = -(C.fy * g.tyc) / tz2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.T0[k] = g.J00 * WR(F, 0, k) + g.J02 * WR(F, 2, k);
+        g.T1[k] = g.J11 * WR(F, 1, k) + g.J12 * WR(F, 2, k);
+    }
+    const float* S = g.S;
+    const float v00 = S[0] * g.T0[0] + S[1] * g.T0[1] + S[2] * g.T0[2];
+    const float v01 = S[1] * g.T0[0] + S[3] * g.T0[1] + S[4] * g.T0[2];
+    const float v02 = S[2] * g.T0[0] + S[4] * g.T0[1] + S[5] * g.T0[2];
+    const float v10 = S[0] * g.T1[0] + S[1] * g.T1[1] + S[2] * g.T1[2];
+    const float v11 = S[1] * g.T1[0] + S[3] * g.T1[1] + S[4] * g.T1[2];
+    const float v12 = S[2] * g.T1[0] + S[4] * g.T1[1] + S[5] * g.T1[2];
+    g.a = (g.T0[0] * v00 + g.T0[1] * v01 + g.T0[2] * v02) + TG_LOWPASS;
+    g.b = g.T1[0] * v00 + g.T1[1] * v01 + g.T1[2] * v02;
+    g.c = (g.T1[0] * v10 + g.T1[1] * v11 + g.T1[2] * v12) + TG_LOWPASS;
+    g.det = g.a * g.c - g.b * g.b;
+    if (g.det == 0.0f) { g.valid = false; return; }
+    g.inv = 1.0f / g.det;
+    g.conic[0] = g.c * g.inv; g.conic[1] = -g.b * g.inv; g.conic[2] = g.a * g.inv;
+    const float mid = 0.5f * (g.a + g.c);
+    const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - g.det));
+    g.radius = (int)ceilf(3.0f * sqrtf(lam));
+
+    // normal: shortest axis (first minimum), flipped to face the camera, world space
+    g.kmin = 0; float smin = s0;
+    if (s1 < smin) { smin = s1; g.kmin = 1; }
+    if (s2 < smin) { smin = s2; g.kmin = 2; }
+    g.dir[0] = mx - F.cam[0]; g.dir[1] = my - F.cam[1]; g.dir[2] = mz - F.cam[2];
+    float n0 = g.R[0 + g.kmin], n1 = g.R[3 + g.kmin], n2 = g.R[6 + g.kmin];
+    g.sign = ((n0 * g.dir[0] + n1 * g.dir[1] + n2 * g.dir[2]) > 0.0f) ? -1.0f : 1.0f;
+    g.n[0] = g.sign * n0; g.n[1] = g.sign * n1; g.n[2] = g.sign * n2;
+    g.dlen = sqrtf(g.dir[0] * g.dir[0] + g.dir[1] * g.dir[1] + g.dir[2] * g.dir[2]);
+    g.dir[0] /= g.dlen; g.dir[1] /= g.dlen; g.dir[2] /= g.dlen;
+
+    // UV Taylor pre-fold: uv(p) = phi + G dp / (1 + g.dp), dp = pix - xy   
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        g.nv[k] = WR(F, k, 0) * g.n[0] + WR(F, k, 1) * g.n[1] + WR(F, k, 2) * g.n[2];
+    g.sdot = g.nv[0] * tx + g.nv[1] * ty + g.nv[2] * tz;
+    const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
+    g.degen = fabsf(g.sdot) <= TG_PLANE_EPS * tn;
+    // K = Jphi * R_c2w ; R_c2w[k][c] = Wr[c][k]
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            g.K[rr * 3 + cc] = juv[9 * i + rr * 3 + 0] * WR(F, cc, 0) + juv[9 * i + rr * 3 + 1] * WR(F, cc, 1)
+                             + juv[9 * i + rr * 3 + 2] * WR(F, cc, 2);
+    if (g.degen) {
+        g.gx = 0.0f; g.gy = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g.G[k] = 0.0f;
+    } else {
+        const float ax = tz * g.nv[0] / g.sdot, ay = tz * g.nv[1] / g.sdot;
+        g.gx = ax / C.fx; g.gy = ay / C.fy;
+        const float B00 = tz / C.fx - tx * g.gx, B01 = -tx * g.gy;
+        const float B10 = -ty * g.gx,            B11 = tz / C.fy - ty * g.gy;
+        const float B20 = -tz * g.gx,            B21 = -tz * g.gy;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            g.G[rr * 2 + 0] = g.K[rr * 3 + 0] * B00 + g.K[rr * 3 + 1] * B10 + g.K[rr * 3 + 2] * B20;
+            g.G[rr * 2 + 1] = g.K[rr * 3 + 0] * B01 + g.K[rr * 3 + 1] * B11 + g.K[rr * 3 + 2] * B21;
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_rect(const Geo& g, const CamConst& C, int& x0, int& y0, int& x1, int& y1) {
+    const float rf = (float)g.radius;
+    x0 = min(C.tiles_x, max(0, (int)((g.xy[0] - rf) / (float)TEXGS_TILE)));
+    y0 = min(C.tiles_y, max(0, (int)((g.xy[1] - rf) / (float)TEXGS_TILE)));
+    x1 = min(C.tiles_x, max(0, (int)((g.xy[0] + rf + (float)(TEXGS_TILE - 1)) / (float)TEXGS_TILE)));
+    y1 = min(C.tiles_y, max(0, (int)((g.xy[1] + rf + (float)(TEXGS_TILE - 1)) / (float)TEXGS_TILE)));
+}
+
+// SH basis (bands 1..3) of utils/sh.py:74-100 for coefficient k = 1..15 -> b[k-1]
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b) {
+    const float C1 = 0.4886025119029199f;
+    b[0] = -C1 * y; b[1] = C1 * z; b[2] = -C1 * x;
+    if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[3] = 1.0925484305920792f * xy;
+        b[4] = -1.0925484305920792f * yz;
+        b[5] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+        b[6] = -1.0925484305920792f * xz;
+        b[7] = 0.5462742152960396f * (xx - yy);
+        if (deg > 2) {
+            b[8]  = -0.5900435899266435f * y * (3.0f * xx - yy);
+            b[9]  = 2.890611442640554f * xy * z;
+            b[10] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+            b[11] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            b[12] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+            b[13] = 1.445305721320277f * z * (xx - yy);
+            b[14] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+        }
+    }
+}
+
+// d basis_k / d (x,y,z)
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* bx, float* by, float* bz) {
+    const float C1 = 0.4886025119029199f;
+    bx[0] = 0.f; by[0] = -C1; bz[0] = 0.f;
+    bx[1] = 0.f; by[1] = 0.f; bz[1] = C1;
+    bx[2] = -C1; by[2] = 0.f; bz[2] = 0.f;
+    if (deg > 1) {
+        const float c20 = 1.0925484305920792f, c22 = 0.31539156525252005f, c24 = 0.5462742152960396f;
+        bx[3] = c20 * y;   by[3] = c20 * x;   bz[3] = 0.f;
+        bx[4] = 0.f;       by[4] = -c20 * z;  bz[4] = -c20 * y;
+        bx[5] = c22 * (-2.0f * x); by[5] = c22 * (-2.0f * y); bz[5] = c22 * 4.0f * z;
+        bx[6] = -c20 * z;  by[6] = 0.f;       bz[6] = -c20 * x;
+        bx[7] = c24 * 2.0f * x; by[7] = -c24 * 2.0f * y; bz[7] = 0.f;
+        if (deg > 2) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f,
+                        c33 = 0.3731763325901154f, c35 = 1.445305721320277f;
+            bx[8]  = c30 * 6.0f * x * y;            by[8]  = c30 * (3.0f * xx - 3.0f * yy);        bz[8]  = 0.f;
+            bx[9]  = c31 * y * z;                   by[9]  = c31 * x * z;                          bz[9]  = c31 * x * y;
+            bx[10] = c32 * (-2.0f * x * y);         by[10] = c32 * (4.0f * zz - xx - 3.0f * yy);   bz[10] = c32 * 8.0f * y * z;
+            bx[11] = c33 * (-6.0f * x * z);         by[11] = c33 * (-6.0f * y * z);                bz[11] = c33 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+            bx[12] = c32 * (4.0f * zz - 3.0f * xx - yy); by[12] = c32 * (-2.0f * x * y);           bz[12] = c32 * 8.0f * x * z;
+            bx[13] = c35 * 2.0f * x * z;            by[13] = -c35 * 2.0f * y * z;                  bz[13] = c35 * (xx - yy);
+            bx[14] = c30 * (3.0f * xx - 3.0f * yy); by[14] = c30 * (-6.0f * x * y);                bz[14] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ int sh_active(int deg, int K) {
+    const int want = (deg + 1) * (deg + 1) - 1;
+    return want < K ? want : K;
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+__global__ void __launch_bounds__(TG_BLOCK)
+k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
+                 const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
+                 const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ uvs,
+                 const float* __restrict__ juv,
+                 float4* __restrict__ rec, float* __restrict__ depth, int32_t* __restrict__ radii,
+                 uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched) {
+    const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
+    if (i >= C.N) return;
+    const Frame F = load_frame(vm, pm, cp);
+    Geo g;
+    geo_forward(g, F, C, i, means, scales, rots, juv);
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (g.valid) {
+        tile_rect(g, C, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) == 0) g.valid = false;
+    }
+    if (!g.valid) {
+        radii[i] = 0; tiles_touched[i] = 0; depth[i] = 0.0f; rect[i] = make_uint2(0u, 0u);
+        return;                                   // record left unwritten: never gathered (no instances)
+    }
+    // view-dependent colour: SH bands 1..deg at the (unit) view direction
+    float vd[3] = {0.f, 0.f, 0.f};
+    const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, C.sh_coeffs) : 0;
+    if (na > 0) {
+        float b[15];
+        sh_basis(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
+        const float* sp = shs + (size_t)i * C.sh_coeffs * 3;
+        for (int k = 0; k < na; ++k) {
+            vd[0] += b[k] * sp[3 * k + 0]; vd[1] += b[k] * sp[3 * k + 1]; vd[2] += b[k] * sp[3 * k + 2];
+        }
+    }
+    radii[i] = g.radius;
+    tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+    depth[i] = g.t[2];
+    rect[i] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+    float4* r = rec + (size_t)i * (TEXGS_REC_FLOATS / 4);
+    r[0] = make_float4(g.xy[0], g.xy[1], g.conic[0], g.conic[1]);
+    r[1] = make_float4(g.conic[2], opac[i], g.gx, g.gy);
+    r[2] = make_float4(g.G[0], g.G[1], g.G[2], g.G[3]);
+    r[3] = make_float4(g.G[4], g.G[5], uvs[3 * i + 0], uvs[3 * i + 1]);
+    r[4] = make_float4(uvs[3 * i + 2], vd[0], vd[1], vd[2]);
+    r[5] = make_float4(g.t[2], g.n[0], g.n[1], g.n[2]);
+}
+
+// ------------------------------------------------------------------------------------------------ K8
+__global__ void __launch_bounds__(TG_BLOCK)
+k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
+                 const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ scales,
+                 const float* __restrict__ rots, const float* __restrict__ juv, const int32_t* __restrict__ radii,
+                 const float* __restrict__ acc,
+                 float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
+                 float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
+                 float* __restrict__ d_uvs) {
+    const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
+    if (i >= C.N) return;
+    const int K = C.sh_coeffs;
+    if (radii[i] <= 0) {
+        d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
+        d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
+        d_op[i] = 0.f;
+        d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
+        d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
+        d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
+        if (d_shs) for (int k = 0; k < 3 * K; ++k) d_shs[(size_t)i * 3 * K + k] = 0.f;
+        return;
+    }
+    const Frame F = load_frame(vm, pm, cp);
+    Geo g;
+    geo_forward(g, F, C, i, means, scales, rots, juv);
+    float A[TEXGS_ACC_FLOATS];
+    {
+        const float4* ap = reinterpret_cast<const float4*>(acc + (size_t)i * TEXGS_ACC_FLOATS);
+#pragma unroll
+        for (int k = 0; k < TEXGS_ACC_FLOATS / 4; ++k) {
+            const float4 v = ap[k];
+            A[4 * k] = v.x; A[4 * k + 1] = v.y; A[4 * k + 2] = v.z; A[4 * k + 3] = v.w;
+        }
+    }
+    const float tx = g.t[0], ty = g.t[1], tz = g.t[2];
+    float dt[3] = {0.f, 0.f, 0.f};      // dL/d t (view-space mean)
+    float dm[3] = {0.f, 0.f, 0.f};      // dL/d mean (world)
+    float dR[9];                        // dL/d R
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dR[k] = 0.f;
+
+    // (1,2) pass-through
+    d_op[i] = A[R_OP];
+    d_uvs[3 * i + 0] = A[R_PHI]; d_uvs[3 * i + 1] = A[R_PHI + 1]; d_uvs[3 * i + 2] = A[R_PHI + 2];
+
+    // (3) conic -> cov2D (a,b,c)
+    const float dA = A[R_CONIC], dB = A[R_CONIC + 1], dC = A[R_CONIC + 2];
+    const float inv = g.inv, inv2 = inv * inv;
+    const float da = dA * (-g.c * g.c * inv2) + dB * (g.b * g.c * inv2) + dC * (inv - g.a * g.c * inv2);
+    const float db = dA * (2.0f * g.b * g.c * inv2) + dB * (-inv - 2.0f * g.b * g.b * inv2) + dC * (2.0f * g.a * g.b * inv2);
+    const float dc = dA * (inv - g.a * g.c * inv2) + dB * (g.a * g.b * inv2) + dC * (-g.a * g.a * inv2);
+    // (4) cov2D = T S T^T
+    const float hb = 0.5f * db;
+    const float* S = g.S;
+    float TS0[3], TS1[3];
+    TS0[0] = g.T0[0] * S[0] + g.T0[1] * S[1] + g.T0[2] * S[2];
+    TS0[1] = g.T0[0] * S[1] + g.T0[1] * S[3] + g.T0[2] * S[4];
+    TS0[2] = g.T0[0] * S[2] + g.T0[1] * S[4] + g.T0[2] * S[5];
+    TS1[0] = g.T1[0] * S[0] + g.T1[1] * S[1] + g.T1[2] * S[2];
+    TS1[1] = g.T1[0] * S[1] + g.T1[1] * S[3] + g.T1[2] * S[4];
+    TS1[2] = g.T1[0] * S[2] + g.T1[1] * S[4] + g.T1[2] * S[5];
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dT0[k] = 2.0f * (da * TS0[k] + hb * TS1[k]);
+        dT1[k] = 2.0f * (hb * TS0[k] + dc * TS1[k]);
+    }
+    // dL/dS (symmetric 3x3, full matrix)
+    float dS[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            dS[k * 3 + l] = g.T0[k] * g.T0[l] * da + (g.T0[k] * g.T1[l] + g.T1[k] * g.T0[l]) * hb + g.T1[k] * g.T1[l] * dc;
+    // S = M M^T -> dM = 2 dS M
+    float dM[9];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            dM[rr * 3 + cc] = 2.0f * (dS[rr * 3 + 0] * g.M[0 * 3 + cc] + dS[rr * 3 + 1] * g.M[1 * 3 + cc] + dS[rr * 3 + 2] * g.M[2 * 3 + cc]);
+    float dscale[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        dscale[cc] = (dM[0 + cc] * g.R[0 + cc] + dM[3 + cc] * g.R[3 + cc] + dM[6 + cc] * g.R[6 + cc]) * C.scale_modifier;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) dR[rr * 3 + cc] += dM[rr * 3 + cc] * g.s[cc];
+    }
+    // T = J Wr -> dJ
+    const float dJ00 = dT0[0] * WR(F, 0, 0) + dT0[1] * WR(F, 0, 1) + dT0[2] * WR(F, 0, 2);
+    const float dJ02 = dT0[0] * WR(F, 2, 0) + dT0[1] * WR(F, 2, 1) + dT0[2] * WR(F, 2, 2);
+    const float dJ11 = dT1[0] * WR(F, 1, 0) + dT1[1] * WR(F, 1, 1) + dT1[2] * WR(F, 1, 2);
+    const float dJ12 = dT1[0] * WR(F, 2, 0) + dT1[1] * WR(F, 2, 1) + dT1[2] * WR(F, 2, 2);
+    const float tz2 = tz * tz, tz3 = tz2 * tz;
+    dt[2] += -dJ00 * C.fx / tz2 - dJ11 * C.fy / tz2 + 2.0f * dJ02 * C.fx * g.txc / tz3 + 2.0f * dJ12 * C.fy * g.tyc / tz3;
+    if (!g.clx) dt[0] += -dJ02 * C.fx / tz2;      // clamped: no gradient (lineage)
+    if (!g.cly) dt[1] += -dJ12 * C.fy / tz2;
+
+    // (6) mean2D: record slot is dL/d(pixel xy); operator returns dL/d(ndc xy)
+    const float dndx = A[R_XY] * 0.5f * (float)C.W, dndy = A[R_XY + 1] * 0.5f * (float)C.H;
+    d_means2D[3 * i + 0] = dndx; d_means2D[3 * i + 1] = dndy; d_means2D[3 * i + 2] = 0.f;
+    {
+        const float dhx = dndx * g.pw, dhy = dndy * g.pw;
+        const float dhw = -(dndx * g.hx + dndy * g.hy) * g.pw * g.pw;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dm[k] += dhx * F.P[k * 4 + 0] + dhy * F.P[k * 4 + 1] + dhw * F.P[k * 4 + 3];
+    }
+    // (7) depth
+    dt[2] += A[R_DEPTH];
+    // (9) normal (world) from the blend
+    float dn[3] = {A[R_N], A[R_N + 1], A[R_N + 2]};
+
+    // (11) UV Taylor pre-fold
+    if (!g.degen) {
+        const float* dG = &A[R_GM];
+        float dBm[6];                            // dB[k][c] = sum_r K[r][k] dG[r][c]
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                dBm[k * 2 + cc] = g.K[0 * 3 + k] * dG[0 * 2 + cc] + g.K[1 * 3 + k] * dG[1 * 2 + cc] + g.K[2 * 3 + k] * dG[2 * 2 + cc];
+        float dtz = dBm[0] / C.fx + dBm[3] / C.fy;
+        float dgt[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+            dgt[cc] = A[R_G2 + cc] - (dBm[0 * 2 + cc] * tx + dBm[1 * 2 + cc] * ty + dBm[2 * 2 + cc] * tz);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dt[k] -= dBm[k * 2 + 0] * g.gx + dBm[k * 2 + 1] * g.gy;
+        const float dax = dgt[0] / C.fx, day = dgt[1] / C.fy;
+        const float dot_a_nv = dax * g.nv[0] + day * g.nv[1];
+        dtz += dot_a_nv / g.sdot;
+        float dnv[3] = {tz * dax / g.sdot, tz * day / g.sdot, 0.f};
+        const float ds = -tz * dot_a_nv / (g.sdot * g.sdot);
+        dnv[0] += ds * tx; dnv[1] += ds * ty; dnv[2] += ds * tz;
+        dt[0] += ds * g.nv[0]; dt[1] += ds * g.nv[1]; dt[2] += ds * g.nv[2] + dtz;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            dn[k] += dnv[0] * WR(F, 0, k) + dnv[1] * WR(F, 1, k) + dnv[2] * WR(F, 2, k);
+    }
+    // n = sign * R[:, kmin]
+    dR[0 + g.kmin] += g.sign * dn[0]; dR[3 + g.kmin] += g.sign * dn[1]; dR[6 + g.kmin] += g.sign * dn[2];
+
+    // (10) view-dependent colour -> shs, view direction
+    const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, K) : 0;
+    if (d_shs) {
+        float* dsp = d_shs + (size_t)i * K * 3;
+        if (na > 0) {
+            float b[15], bx[15], by[15], bz[15];
+            sh_basis(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
+            sh_basis_grad(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], bx, by, bz);
+            const float* sp = shs + (size_t)i * K * 3;
+            const float v0 = A[R_VD], v1 = A[R_VD + 1], v2 = A[R_VD + 2];
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            for (int k = 0; k < na; ++k) {
+                dsp[3 * k + 0] = b[k] * v0; dsp[3 * k + 1] = b[k] * v1; dsp[3 * k + 2] = b[k] * v2;
+                const float w = sp[3 * k + 0] * v0 + sp[3 * k + 1] * v1 + sp[3 * k + 2] * v2;
+                ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+            }
+            // dir = d/|d|
+            const float dd = g.dir[0] * ddx + g.dir[1] * ddy + g.dir[2] * ddz;
+            dm[0] += (ddx - g.dir[0] * dd) / g.dlen;
+            dm[1] += (ddy - g.dir[1] * dd) / g.dlen;
+            dm[2] += (ddz - g.dir[2] * dd) / g.dlen;
+        }
+        for (int k = 3 * na; k < 3 * K; ++k) dsp[k] = 0.f;
+    }
+
+    // (8) t = [m,1] @ V
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dm[k] += dt[0] * F.V[k * 4 + 0] + dt[1] * F.V[k * 4 + 1] + dt[2] * F.V[k * 4 + 2];
+    d_means[3 * i + 0] = dm[0]; d_means[3 * i + 1] = dm[1]; d_means[3 * i + 2] = dm[2];
+    d_scales[3 * i + 0] = dscale[0]; d_scales[3 * i + 1] = dscale[1]; d_scales[3 * i + 2] = dscale[2];
+
+    // (5) R(q) -> q
+    const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
+    d_rots[4 * i + 0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    d_rots[4 * i + 1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+    d_rots[4 * i + 2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+    d_rots[4 * i + 3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+}
+
+// ------------------------------------------------------------------------------------------------ K9
+__global__ void __launch_bounds__(TG_BLOCK)
+k_mark_visible(int N, const float* __restrict__ vm, const float* __restrict__ means, uint8_t* __restrict__ visible) {
+    const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const float tz = vm[2] * means[3 * i] + vm[6] * means[3 * i + 1] + vm[10] * means[3 * i + 2] + vm[14];
+    visible[i] = tz > TG_NEAR_Z ? 1 : 0;
+}
+
+}  // namespace
+
+void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, TexGSGeom* g, hipStream_t s) {
+    if (c.N <= 0) return;
+    const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), 0, s, c, f->viewmatrix, f->projmatrix, f->campos,
+                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs,
+                       reinterpret_cast<float4*>(g->rec), g->depth, g->radii, reinterpret_cast<uint2*>(g->rect),
+                       g->tiles_touched);
+}
+
+void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
+                           TexGSGrads* gr, hipStream_t s) {
+    if (c.N <= 0) return;
+    const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), 0, s, c, f->viewmatrix, f->projmatrix, f->campos,
+                       in->means3D, in->shs, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
+                       gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
+                       gr->dL_drotations, gr->dL_duvs);
+}
+
+void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {
+    if (f->num_gaussians <= 0) return;
+    const int blocks = (f->num_gaussians + TG_BLOCK - 1) / TG_BLOCK;
+    hipLaunchKernelGGL(k_mark_visible, dim3(blocks), dim3(TG_BLOCK), 0, s, f->num_gaussians, f->viewmatrix, means3D, visible);
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of libtexgs.so (C ABI in include/texgs.h).  Fails loudly when the HIP library is missing:
+there is no CPU / eager fallback for the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtexgs.so")
+
+ABI_VERSION = 1
+TILE = 16
+REC_FLOATS = 32
+ACC_FLOATS = 24
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class Frame(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
+                ("sh_coeffs", C.c_int32), ("tex_res", C.c_int32), ("num_gaussians", C.c_int32),
+                ("debug", C.c_int32), ("bg", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [("means3D", _fp), ("shs", _fp), ("opacities", _fp), ("scales", _fp), ("rotations", _fp),
+                ("uvs", _fp), ("gradient_uvs", _fp), ("texture", _fp)]
+
+
+class Geom(C.Structure):
+    _fields_ = [("rec", _fp), ("depth", _fp), ("radii", _fp), ("rect", _fp), ("tiles_touched", _fp),
+                ("offsets", _fp), ("scan_temp", _fp), ("scan_temp_bytes", C.c_size_t)]
+
+
+class Binning(C.Structure):
+    _fields_ = [("num_rendered", C.c_uint32), ("keys_unsorted", _fp), ("keys_sorted", _fp),
+                ("vals_unsorted", _fp), ("point_list", _fp), ("ranges", _fp), ("sort_temp", _fp),
+                ("sort_temp_bytes", C.c_size_t)]
+
+
+class Image(C.Structure):
+    _fields_ = [("out_color", _fp), ("out_depth", _fp), ("out_norm", _fp), ("out_alpha", _fp),
+                ("final_T", _fp), ("n_contrib", _fp)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
+                ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
+                ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp)]
+
+
+EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
+           "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
+           "texgs_render_forward", "texgs_backward", "texgs_mark_visible"]
+
+_lib = None
+
+
+def load():
+    """Load libtexgs.so once.  Raises RuntimeError (never falls back) if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libtexgs.so not found at {LIB_PATH}: build it with `python texture-gs_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rasterizer.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.texgs_abi_version.restype = C.c_int
+    lib.texgs_last_error.restype = C.c_char_p
+    lib.texgs_scan_temp_bytes.restype = C.c_size_t
+    lib.texgs_scan_temp_bytes.argtypes = [C.c_int32]
+    lib.texgs_sort_temp_bytes.restype = C.c_size_t
+    lib.texgs_sort_temp_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.texgs_preprocess_forward.argtypes = [P(Frame), P(Inputs), P(Geom), C.c_void_p]
+    lib.texgs_read_num_rendered.argtypes = [P(Geom), C.c_int32, P(C.c_uint32), C.c_void_p]
+    lib.texgs_bin_sort_render_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), C.c_void_p]
+    lib.texgs_render_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), C.c_void_p]
+    lib.texgs_backward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), P(Grads), C.c_void_p]
+    lib.texgs_mark_visible.argtypes = [P(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+    for name in ("texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
+                 "texgs_render_forward", "texgs_backward", "texgs_mark_visible"):
+        getattr(lib, name).restype = C.c_int
+    v = lib.texgs_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libtexgs.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().texgs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,254 @@
+"""Host side of the textured Gaussian rasterizer: torch.autograd.Function over the C ABI of libtexgs.so.
+
+Mirrors the operator surface the reference imports at render/uv_tex_render.py:4 and calls at :25-38, :40,
+:56-66 (GaussianRasterizationSettings / GaussianRasterizer): same names, argument meaning and 6-tuple return.
+PyTorch is plumbing here (device memory through the caching allocator, the current HIP stream, autograd
+bookkeeping); all arithmetic runs in the hand-written gfx950 kernels.
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Field names and order = keywords at render/uv_tex_render.py:25-38."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _State:
+    """Everything one forward leaves behind for its backward (per call: no global scratch, two forwards may
+    be alive before a backward, models/texture_gaussian3d.py:318,378,410)."""
+    __slots__ = ("frame", "inputs", "geom", "bin", "img", "tensors", "N", "K", "R", "H", "W", "D")
+
+
+def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
+    H, W = int(st.image_height), int(st.image_width)
+    bg = _f32c(st.bg, "bg", device).reshape(-1)
+    vm = _f32c(st.viewmatrix, "viewmatrix", device).reshape(-1)
+    pm = _f32c(st.projmatrix, "projmatrix", device).reshape(-1)
+    cp = _f32c(st.campos, "campos", device).reshape(-1)
+    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
+        raise ValueError("bg/campos must have 3 elements and viewmatrix/projmatrix 16")
+    keep.extend([bg, vm, pm, cp])
+    f = _lib.Frame(H, W, float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier), int(st.sh_degree),
+                   int(K), int(R), int(N), 1 if st.debug else 0, _ptr(bg), _ptr(vm), _ptr(pm), _ptr(cp))
+    return f
+
+
+def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture):
+    """Run K1..K6.  Returns (outputs, state).  No autograd here."""
+    lib = _lib.load()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("the textured rasterizer runs on an AMD GPU (torch device 'cuda' = HIP); "
+                           f"got tensors on {device}. There is no CPU fallback.")
+    N = means3D.shape[0]
+    means3D = _f32c(means3D, "means3D", device)
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise ValueError("means3D must be [N,3]")
+    opacities = _f32c(opacities, "opacities", device)
+    scales = _f32c(scales, "scales", device)
+    rotations = _f32c(rotations, "rotations", device)
+    uvs = _f32c(uvs, "uvs", device)
+    gradient_uvs = _f32c(gradient_uvs, "gradient_uvs", device)
+    texture = _f32c(texture, "texture", device)
+    if opacities.numel() != N or scales.shape != (N, 3) or rotations.shape != (N, 4) or uvs.shape != (N, 3) \
+            or gradient_uvs.numel() != 9 * N:
+        raise ValueError("per-Gaussian inputs must have exactly N rows "
+                         f"(N={N}; opacities {tuple(opacities.shape)}, scales {tuple(scales.shape)}, "
+                         f"rotations {tuple(rotations.shape)}, uvs {tuple(uvs.shape)}, "
+                         f"gradient_uvs {tuple(gradient_uvs.shape)})")
+    if texture.dim() != 4 or texture.shape[0] != 6 or texture.shape[1] != texture.shape[2] or texture.shape[3] != 3:
+        raise ValueError(f"texture must be [6,R,R,3], got {tuple(texture.shape)}")
+    R = texture.shape[1]
+    K = 0
+    if shs is not None:
+        shs = _f32c(shs, "shs", device)
+        if shs.dim() != 3 or shs.shape[0] != N or shs.shape[2] != 3:
+            raise ValueError(f"shs must be [N,K,3], got {tuple(shs.shape)}")
+        K = shs.shape[1]
+        if K > 15:
+            raise ValueError("shs holds at most 15 view-dependent coefficients (degree 3)")
+    if int(st.sh_degree) < 0 or int(st.sh_degree) > 3:
+        raise ValueError("sh_degree must be in [0,3]")
+    H, W = int(st.image_height), int(st.image_width)
+    tiles = ((W + _lib.TILE - 1) // _lib.TILE) * ((H + _lib.TILE - 1) // _lib.TILE)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture]
+
+    with torch.cuda.device(device):
+        frame = _make_frame(st, N, K, R, device, keep)
+        inputs = _lib.Inputs(_ptr(means3D), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(rotations),
+                             _ptr(uvs), _ptr(gradient_uvs), _ptr(texture))
+        # per-Gaussian state
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        rec = torch.empty(max(N, 1), _lib.REC_FLOATS, **f32)
+        depth = torch.empty(max(N, 1), **f32)
+        radii = torch.zeros(N, **i32)
+        rect = torch.empty(max(N, 1), 2, **i32)
+        tiles_touched = torch.empty(max(N, 1), **i32)
+        offsets = torch.empty(max(N, 1), **i32)
+        scan_bytes = lib.texgs_scan_temp_bytes(N)
+        scan_temp = torch.empty(scan_bytes, dtype=torch.uint8, device=device)
+        geom = _lib.Geom(_ptr(rec), _ptr(depth), _ptr(radii), _ptr(rect), _ptr(tiles_touched), _ptr(offsets),
+                         _ptr(scan_temp), scan_bytes)
+        _lib.check(lib.texgs_preprocess_forward(C.byref(frame), C.byref(inputs), C.byref(geom), stream),
+                   "texgs_preprocess_forward")
+        d_host = C.c_uint32(0)
+        _lib.check(lib.texgs_read_num_rendered(C.byref(geom), N, C.byref(d_host), stream), "texgs_read_num_rendered")
+        D = int(d_host.value)
+        # binning buffers sized from D
+        keys_u = torch.empty(max(D, 1), dtype=torch.int64, device=device)
+        keys_s = torch.empty(max(D, 1), dtype=torch.int64, device=device)
+        vals_u = torch.empty(max(D, 1), **i32)
+        point_list = torch.empty(max(D, 1), **i32)
+        ranges = torch.zeros(tiles, 2, **i32)
+        sort_bytes = lib.texgs_sort_temp_bytes(D, tiles)
+        sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
+        binning = _lib.Binning(D, _ptr(keys_u), _ptr(keys_s), _ptr(vals_u), _ptr(point_list), _ptr(ranges),
+                               _ptr(sort_temp), sort_bytes)
+        out_color = torch.empty(3, H, W, **f32)
+        out_depth = torch.empty(1, H, W, **f32)
+        out_norm = torch.empty(3, H, W, **f32)
+        out_alpha = torch.empty(1, H, W, **f32)
+        final_T = torch.empty(H, W, **f32)
+        n_contrib = torch.empty(H, W, **i32)
+        img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), _ptr(final_T),
+                         _ptr(n_contrib))
+        _lib.check(lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom),
+                                                     C.byref(binning), C.byref(img), stream),
+                   "texgs_bin_sort_render_forward")
+    s = _State()
+    s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
+    s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
+    s.tensors = dict(keep=keep, rec=rec, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
+                     offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s, vals_unsorted=vals_u,
+                     point_list=point_list, ranges=ranges, final_T=final_T, n_contrib=n_contrib,
+                     scan_temp=scan_temp, sort_temp=sort_temp,
+                     out=(out_color, out_depth, out_norm, out_alpha))
+    return (out_color, out_depth, out_norm, out_alpha, radii), s
+
+
+def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha):
+    """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture)."""
+    lib = _lib.load()
+    means3D = s.tensors["keep"][0]
+    device = means3D.device
+    f32 = dict(dtype=torch.float32, device=device)
+    N, K, R = s.N, s.K, s.R
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def g(t, shape):
+        if t is None:
+            return None
+        t = t.to(torch.float32).contiguous()
+        assert tuple(t.shape) == shape, (tuple(t.shape), shape)
+        return t
+    H, W = s.H, s.W
+    dc, dd, dn, da = g(dL_dcolor, (3, H, W)), g(dL_ddepth, (1, H, W)), g(dL_dnorm, (3, H, W)), g(dL_dalpha, (1, H, W))
+    with torch.cuda.device(device):
+        acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
+        d_means3D = torch.empty(N, 3, **f32)
+        d_means2D = torch.empty(N, 3, **f32)
+        d_shs = torch.empty(N, K, 3, **f32) if K > 0 else None
+        d_op = torch.empty(N, 1, **f32)
+        d_scales = torch.empty(N, 3, **f32)
+        d_rot = torch.empty(N, 4, **f32)
+        d_uvs = torch.empty(N, 3, **f32)
+        d_tex = torch.zeros(6, R, R, 3, **f32)
+        grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(d_means3D), _ptr(d_means2D),
+                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex))
+        _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
+                                      C.byref(s.img), C.byref(grads), stream), "texgs_backward")
+    return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, acc
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st):
+        outs, state = forward_raw(st, means3D.detach(), None if shs is None else shs.detach(),
+                                  opacities.detach(), scales.detach(), rotations.detach(), uvs.detach(),
+                                  gradient_uvs.detach(), texture.detach())
+        color, depth, norm, alpha, radii = outs
+        ctx.state = state
+        ctx.op_shape = opacities.shape
+        ctx.juv_shape = gradient_uvs.shape
+        ctx.mark_non_differentiable(radii)
+        return color, depth, norm, alpha, radii
+
+    @staticmethod
+    def backward(ctx, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, _dradii):
+        s = ctx.state
+        d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, _ = backward_raw(
+            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha)
+        ctx.state = None
+        return (d_means3D, d_means2D, d_shs, d_op.reshape(ctx.op_shape), d_scales, d_rot, d_uvs, None, d_tex, None)
+
+
+class GaussianRasterizer(nn.Module):
+    """Same call surface as the reference's rasterizer (render/uv_tex_render.py:40,56-66)."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test only (lineage API; unused by the reference)."""
+        lib = _lib.load()
+        st = self.raster_settings
+        positions = _f32c(positions, "positions", positions.device)
+        N = positions.shape[0]
+        keep = []
+        frame = _make_frame(st, N, 0, 1, positions.device, keep)
+        vis = torch.zeros(N, dtype=torch.uint8, device=positions.device)
+        stream = torch.cuda.current_stream(positions.device).cuda_stream
+        with torch.cuda.device(positions.device):
+            _lib.check(lib.texgs_mark_visible(C.byref(frame), positions.data_ptr(), vis.data_ptr(), stream),
+                       "texgs_mark_visible")
+        return vis.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, scales=None, rotations=None, uvs=None,
+                gradient_uvs=None, texture=None, extra_attrs=None):
+        st = self.raster_settings
+        if scales is None or rotations is None:
+            raise ValueError("scales and rotations are required (the textured operator has no cov3D_precomp path)")
+        if uvs is None or gradient_uvs is None or texture is None:
+            raise ValueError("uvs, gradient_uvs and texture are required")
+        if extra_attrs is not None:
+            raise NotImplementedError("extra_attrs is always None in the reference (render/uv_tex_render.py:66); "
+                                      "blending of extra per-Gaussian attributes is not built yet")
+        if means2D is None:
+            means2D = torch.zeros_like(means3D)
+        color, depth, norm, alpha, radii = _RasterizeGaussians.apply(
+            means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st)
+        return color, depth, norm, alpha, radii, None
