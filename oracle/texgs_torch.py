@@ -40,8 +40,8 @@ FRUSTUM_CLAMP = 1.3       # tx/tz clamped to +-1.3 tanfov in the EWA Jacobian
 ALPHA_MAX = 0.99
 ALPHA_MIN = 1.0 / 255.0
 T_EPS = 1e-4              # stop when T*(1-alpha) < 1e-4 (before accumulating)
-PLANE_EPS = 1e-4          # |n.t| <= PLANE_EPS*|t|  -> plane seen edge-on: uv = phi (G = g = 0)
-DEN_MIN = 0.05            # 1 + g.dp < DEN_MIN   -> ray (nearly) parallel to the plane: uv = phi
+PLANE_EPS = 5e-2          # |n.t| <= PLANE_EPS*|t| (plane seen > 87.1 deg from its normal, > 20x in-plane stretch): uv = phi (G = g = 0)
+DEN_MIN = 0.2             # 1 + g.dp < DEN_MIN (intersection > 5x the centre depth): uv = phi
 MA_MIN = 1e-20            # guard on the cubemap major axis
 
 SH_C0 = 0.28209479177387814

@@ -79,3 +79,28 @@ def rel_err(a, b):
     a = a.double().reshape(-1)
     b = b.double().reshape(-1)
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=0.005, global_rel=2e-2):
+    """Robust gradient comparison.  fp32 (HIP) vs fp64 (oracle) differ by isolated discrete events -- a
+    bilinear cell chosen differently for one (pixel, Gaussian) pair changes that pair's dL/duv by O(1), a
+    1/255 or clamp threshold decided differently adds or removes one pair -- so a handful of rows may be off
+    while everything else agrees to rounding.  Rows = first dimension (Gaussians / cubemap faces*rows).
+    Returns (ok, message)."""
+    g = got.double().reshape(got.shape[0], -1) if got.dim() > 1 else got.double().reshape(-1, 1)
+    e = exp.double().reshape(g.shape)
+    if e.numel() == 0:
+        return True, "empty"
+    if g.shape[0] <= 6:                      # texture [6,R,R,3]: use texel rows
+        g = g.reshape(-1, 3)
+        e = e.reshape(-1, 3)
+    gmax = float(e.abs().max())
+    if gmax == 0.0:
+        return float(g.abs().max()) == 0.0, "reference gradient is identically zero"
+    err = (g - e).abs().max(dim=1).values
+    tol = row_rtol * e.abs().max(dim=1).values + row_atol_frac * gmax
+    nbad = int((err > tol).sum())
+    budget = max(int(max_outlier_frac * g.shape[0]), 20)    # ~13 cell flips per 256x256 image are expected
+    rel = float((g - e).norm() / e.norm())
+    ok = (nbad <= budget) and (rel <= global_rel)
+    return ok, f"outlier rows {nbad} (budget {budget} of {g.shape[0]}), global rel L2 {rel:.3e} (max {global_rel})"

@@ -11,8 +11,8 @@
 #define TG_ALPHA_MAX     0.99f
 #define TG_ALPHA_MIN     (1.0f / 255.0f)
 #define TG_T_EPS         1e-4f
-#define TG_PLANE_EPS     1e-4f
-#define TG_DEN_MIN       0.05f
+#define TG_PLANE_EPS     5e-2f
+#define TG_DEN_MIN       0.2f
 #define TG_MA_MIN        1e-20f
 #define TG_SH_C0         0.28209479177387814f
 
