@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd views/sec of the textured Gaussian rasterizer operator on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under
+torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[2], "C3"): 300k Gaussians + 6x1024^2x3 cubemap, 800x800, fwd+bwd, synthetic
+seeded scene.  A "step" = `--views-per-step` (default 8) views per rank, each a full
+operator forward + backward through the public GaussianRasterizer (the module render/uv_tex_render.py:40 builds),
+gradients accumulated into one flat fp32 bucket; with N>1 the bucket is all-reduced (RCCL, SUM) once per step --
+BASELINE configs[3]: 64-view batch over 8 GPUs = 8 views per rank per all-reduce.  value = views of all ranks / time.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "texture-gs_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # name: (N, R, W, H, mode)
+    "c1": (1000, 64, 256, 256, "fwd+bwd"),
+    "c2": (100_000, 512, 800, 800, "fwd"),
+    "c3": (300_000, 1024, 800, 800, "fwd+bwd"),
+    "c5": (1_000_000, 2048, 1600, 1200, "fwd+bwd"),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--views-per-step", type=int, default=8)
+    ap.add_argument("--num-views", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles sampled by the CPU baseline (0 = auto)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched):
+    """Per-launch algorithmic HBM bytes of every kernel (DESIGN.md section 5 states each term).  D_eff = sum over
+    tiles of the last contributor's position (the replay never needs the rest of the list); texels_touched =
+    distinct texels with a non-zero gradient in this view."""
+    bits = max(1, math.ceil(math.log2(max(T, 2))))
+    passes = math.ceil((32 + bits) / 8)
+    tex = 12 * texels_touched
+    return {
+        "preprocess_fwd": N * (92 + 12 * K) + n_vis * 96 + N * 20,
+        "scan": N * 8,
+        "duplicate": N * 20 + D * 12,
+        "sort": D * 8 + passes * D * 24,
+        "ranges": D * 8 + T * 8,
+        "render_fwd": D_eff * 100 + tex + P * 40 + T * 8,
+        "render_bwd": D_eff * 100 + P * 40 + tex + 2 * tex + n_touched * 192 + T * 8,
+        "preprocess_bwd": N * (96 + 12 * K) + n_vis * 96 + N * (68 + 12 * K),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from texgs import synth, _lib
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, forward_raw, backward_raw
+    from texgs.multiview import GradBucket, shard_views
+
+    N, R, W, H, mode = WORKLOADS[args.workload]
+    with_bwd = mode == "fwd+bwd"
+    K = 15
+    scene = synth.make_scene(N, R, seed=0)
+    cams = synth.fibonacci_cameras(args.num_views, W, H)
+    my_views = shard_views(args.num_views, rank, world)
+    bg = torch.zeros(3, device=dev)
+
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
+    leaves = {n: getattr(scene, n).to(dev).requires_grad_(with_bwd) for n in names}
+    juv = scene.gradient_uvs.to(dev)
+    means2D = torch.zeros(N, 3, device=dev, requires_grad=with_bwd)
+    params = [leaves[n] for n in names] + [means2D]
+    bucket = GradBucket(params) if with_bwd else None
+
+    def settings(cam):
+        return GaussianRasterizationSettings(
+            image_height=cam.image_height, image_width=cam.image_width,
+            tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,
+            viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev), sh_degree=3,
+            campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+    rasters = {v: GaussianRasterizer(settings(cams[v])) for v in my_views}
+
+    # fixed upstream gradients of the synthetic loss' shape: image, alpha, norm
+    g = torch.Generator().manual_seed(1234)
+    P = W * H
+    g_img = ((torch.rand(3, H, W, generator=g) > 0.5).float() * 2 - 1).to(dev) / (3 * P)
+    g_alpha = ((torch.rand(1, H, W, generator=g) > 0.5).float() * 2 - 1).to(dev) / P
+    nh = torch.randn(3, H, W, generator=g)
+    g_norm = (-0.1 * nh / nh.norm(dim=0, keepdim=True)).to(dev) / P
+
+    def one_view(v):
+        out = rasters[v](means3D=leaves["means3D"], means2D=means2D, shs=leaves["shs"],
+                         opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                         uvs=leaves["uvs"], gradient_uvs=juv, texture=leaves["texture"], extra_attrs=None)
+        if with_bwd:
+            torch.autograd.backward([out[0], out[3], out[2]], [g_img, g_alpha, g_norm])
+        return out
+
+    cursor = [0]
+
+    def step():
+        if with_bwd:
+            bucket.zero()
+        for _ in range(args.views_per_step):
+            one_view(my_views[cursor[0] % len(my_views)])
+            cursor[0] += 1
+        if with_bwd and world > 1:
+            bucket.all_reduce(dist)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    kern = _lib.profile_read()
+    _lib.profile_enable(False)
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_views = args.steps * args.views_per_step * world
+    value = total_views / elapsed
+
+    # ---- units of one representative launch (view my_views[0]), outside the timed region
+    st0 = settings(cams[my_views[0]])
+    with torch.no_grad():
+        outs, s = forward_raw(st0, leaves["means3D"].detach(), leaves["shs"].detach(), leaves["opacities"].detach(),
+                              leaves["scales"].detach(), leaves["rotations"].detach(), leaves["uvs"].detach(), juv,
+                              leaves["texture"].detach())
+        T = s.tensors["ranges"].shape[0]
+        nc = s.tensors["n_contrib"].to(torch.int64)
+        tx, ty = (W + 15) // 16, (H + 15) // 16
+        pad = torch.zeros(ty * 16, tx * 16, dtype=torch.int64, device=dev)
+        pad[:H, :W] = nc
+        D_eff = int(pad.reshape(ty, 16, tx, 16).amax(dim=(1, 3)).sum())
+        n_vis = int((outs[4] > 0).sum())
+        n_touched, texels = n_vis, 0
+        if with_bwd:
+            res = backward_raw(s, g_img, None, g_norm, g_alpha)
+            n_touched = int((res[-1].abs().sum(1) > 0).sum())
+            texels = int((res[7].abs().sum(-1) > 0).sum())
+        else:
+            texels = 0
+    ab = algorithmic_bytes(N, K, s.D, D_eff, P, T, R, n_vis, n_touched, texels)
+    kinfo = {}
+    for name, (ms, cnt) in kern.items():
+        if cnt:
+            kinfo[name] = {"avg_us": 1e3 * ms / cnt, "launches": cnt, "alg_MB": ab[name] / 1e6,
+                           "GBps": ab[name] / (ms / cnt * 1e-3) / 1e9}
+    dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"] * kinfo[k]["launches"]) if kinfo else None
+    roofline = None
+    if dom:
+        ach = kinfo[dom]["GBps"]
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "alg_bytes_per_launch": ab[dom], "avg_launch_us": round(kinfo[dom]["avg_us"], 2)}
+    view_bytes = sum(ab[k] for k in ab if (with_bwd or k not in ("render_bwd", "preprocess_bwd")))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from texgs_cpu_baseline import cpu_baseline   # bench-only helper at repo root; uses oracle/ as the checker's port
+        cpu = cpu_baseline(scene, cams[my_views[0]], W, H, with_bwd, args.cpu_tiles)
+
+    if rank == 0:
+        line = {
+            "metric": "fwd+bwd views/sec @800x800, 300k Gaussians + 1024^2 texture; HBM GB/s vs roofline"
+                      if args.workload == "c3" else f"{mode} views/sec ({args.workload})",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: N={N} Gaussians, cubemap 6x{R}x{R}x3 f32, {W}x{H}, {mode}, sh_degree 3",
+                       "views_per_step_per_gpu": args.views_per_step, "global_views_per_step": args.views_per_step * world,
+                       "num_rendered_D": s.D, "D_eff": D_eff, "parallelism": f"views sharded dp{world}",
+                       "grad_allreduce": "RCCL SUM of one flat f32 bucket per step" if world > 1 else "none (1 GPU)"},
+            "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
+            "alg_bytes_per_view": view_bytes,
+            "pipeline_GBps": round(view_bytes * value / world / 1e9, 2),
+            "pipeline_frac_of_hbm_peak": round(view_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
+            "roofline": roofline,
+            "kernels": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                        for k, v in kinfo.items()},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,6 +139,17 @@ int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const T
 int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                    const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream);
 
+/* Optional per-kernel HIP-event timing (used by bench.py for the live roofline figure).  While enabled,
+ * every kernel launch of this library is bracketed by hipEventRecord on the launch stream.
+ * texgs_profile_read synchronises the recorded events, adds elapsed ms / launch counts per kernel id into
+ * the caller's host arrays (length TEXGS_NUM_KERNELS) and clears the log. */
+enum {
+    TEXGS_K_PREPROCESS_FWD = 0, TEXGS_K_SCAN = 1, TEXGS_K_DUPLICATE = 2, TEXGS_K_SORT = 3, TEXGS_K_RANGES = 4,
+    TEXGS_K_RENDER_FWD = 5, TEXGS_K_RENDER_BWD = 6, TEXGS_K_PREPROCESS_BWD = 7, TEXGS_NUM_KERNELS = 8
+};
+int texgs_profile_enable(int on);
+int texgs_profile_read(float* ms_sum_host, uint32_t* launches_host);
+
 /* Frustum test only (upstream API `markVisible`; unused by the reference). visible: u8[N]. */
 int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream);
 

@@ -274,7 +274,7 @@ def cubemap_fetch(uv, texture):
     return tex, margin
 
 
-def render(pre, binning, texture, st, dtype, chunk=128):
+def render(pre, binning, texture, st, dtype, chunk=128, tile_subset=None):
     """K6 of SURVEY Appendix A.4, tile by tile, instance chunks processed front to back."""
     H, W = int(st.image_height), int(st.image_width)
     gx, gy = pre['grid']
@@ -287,7 +287,7 @@ def render(pre, binning, texture, st, dtype, chunk=128):
     pl = binning['point_list']
     ranges = binning['ranges']
     ly, lx = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing='ij')
-    for tile in range(gx * gy):
+    for tile in (range(gx * gy) if tile_subset is None else tile_subset):
         r0, r1 = int(ranges[tile, 0]), int(ranges[tile, 1])
         ty0, tx0 = (tile // gx) * TILE, (tile % gx) * TILE
         py = (ty0 + ly).reshape(-1)

@@ -4,9 +4,38 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 namespace {
 
 thread_local char g_err[512] = "";
+
+// ---- optional HIP-event kernel timing (profiling only; the data path keeps no global state) ----
+struct EvRec { int kid; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<EvRec> g_prof_log;
+std::vector<hipEvent_t> g_prof_free;
+
+hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+struct ProfScope {          // brackets the launches issued inside its lifetime
+    int kid; hipStream_t s; hipEvent_t a; bool on;
+    ProfScope(int k, hipStream_t st) : kid(k), s(st), a(nullptr), on(false) {
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        if (g_prof_on) { on = true; a = prof_event(); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope() {
+        if (!on) return;
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        hipEvent_t b = prof_event(); (void)hipEventRecord(b, s);
+        g_prof_log.push_back({kid, a, b});
+    }
+};
 
 int fail(const char* where, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
@@ -62,9 +91,10 @@ int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, Tex
     if (geom->scan_temp_bytes < scan_temp_bytes(frame->num_gaussians)) return fail_msg("scan_temp too small");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
-    launch_preprocess_fwd(c, frame, in, geom, s);
+    { ProfScope p(TEXGS_K_PREPROCESS_FWD, s); launch_preprocess_fwd(c, frame, in, geom, s); }
     if (int r = check(frame, s, "preprocess_fwd")) return r;
-    if (int r = launch_scan(geom, frame->num_gaussians, s)) return fail("inclusive_scan", (hipError_t)r);
+    { ProfScope p(TEXGS_K_SCAN, s);
+      if (int r = launch_scan(geom, frame->num_gaussians, s)) return fail("inclusive_scan", (hipError_t)r); }
     return check(frame, s, "inclusive_scan");
 }
 
@@ -87,7 +117,7 @@ int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const T
     if (!in->texture) return fail_msg("texture is NULL");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
-    launch_render_fwd(c, frame, in, geom, bin, img, s);
+    { ProfScope p(TEXGS_K_RENDER_FWD, s); launch_render_fwd(c, frame, in, geom, bin, img, s); }
     return check(frame, s, "render_fwd");
 }
 
@@ -100,11 +130,12 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     if (bin->num_rendered > 0) {
         if (bin->sort_temp_bytes < sort_temp_bytes(bin->num_rendered, (uint32_t)(c.tiles_x * c.tiles_y)))
             return fail_msg("sort_temp too small");
-        launch_duplicate(c, geom, bin, s);
+        { ProfScope p(TEXGS_K_DUPLICATE, s); launch_duplicate(c, geom, bin, s); }
         if (int r = check(frame, s, "duplicate_with_keys")) return r;
-        if (int r = launch_sort(c, bin, s)) return fail("radix_sort_pairs", (hipError_t)r);
+        { ProfScope p(TEXGS_K_SORT, s);
+          if (int r = launch_sort(c, bin, s)) return fail("radix_sort_pairs", (hipError_t)r); }
         if (int r = check(frame, s, "radix_sort_pairs")) return r;
-        launch_ranges(c, bin, s);
+        { ProfScope p(TEXGS_K_RANGES, s); launch_ranges(c, bin, s); }
         if (int r = check(frame, s, "tile_ranges")) return r;
     }
     return texgs_render_forward(frame, in, geom, bin, img, stream);
@@ -118,11 +149,37 @@ int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGe
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     if (bin->num_rendered > 0) {
-        launch_render_bwd(c, frame, in, geom, bin, img, grads, s);
+        { ProfScope p(TEXGS_K_RENDER_BWD, s); launch_render_bwd(c, frame, in, geom, bin, img, grads, s); }
         if (int r = check(frame, s, "render_bwd")) return r;
     }
-    launch_preprocess_bwd(c, frame, in, geom, grads, s);
+    { ProfScope p(TEXGS_K_PREPROCESS_BWD, s); launch_preprocess_bwd(c, frame, in, geom, grads, s); }
     return check(frame, s, "preprocess_bwd");
+}
+
+int texgs_profile_enable(int on) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof_on = on != 0;
+    if (!g_prof_on) {
+        for (auto& r : g_prof_log) { g_prof_free.push_back(r.a); g_prof_free.push_back(r.b); }
+        g_prof_log.clear();
+    }
+    return 0;
+}
+
+int texgs_profile_read(float* ms_sum_host, uint32_t* launches_host) {
+    if (!ms_sum_host || !launches_host) return fail_msg("NULL argument");
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    for (auto& r : g_prof_log) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return fail("profile event sync", e);
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return fail("profile elapsed", e);
+        if (r.kid >= 0 && r.kid < TEXGS_NUM_KERNELS) { ms_sum_host[r.kid] += ms; launches_host[r.kid] += 1; }
+        g_prof_free.push_back(r.a); g_prof_free.push_back(r.b);
+    }
+    g_prof_log.clear();
+    return 0;
 }
 
 int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream) {

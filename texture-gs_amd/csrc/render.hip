@@ -9,6 +9,7 @@
 //
 // No MFMA: there is no dense contraction on this path.  Bound: HBM / L2 gather + fp32 atomics (backward).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,17 +42,25 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-// blockIdx -> tile.  Workgroup b is observed to run on XCD b % 8; give each XCD a contiguous band of tiles so
-// neighbouring tiles (which share most of their Gaussians' records) hit the same 4 MiB L2.  Speed only.
+// blockIdx -> tile.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness).  Tiles are dealt to
+// XCDs in groups of 8 row-adjacent tiles, cyclically: neighbours inside a group share most of their Gaussians'
+// records (same 4 MiB L2), while every XCD still gets the same mix of light (border) and heavy (centre) tiles --
+// contiguous per-XCD bands left the centre XCDs with ~1.6x the mean work.
 __device__ __forceinline__ int tile_of_block(int b, int num_tiles) {
-    const int chunk = (num_tiles + 7) >> 3;
-    return (b & 7) * chunk + (b >> 3);
+    const int xcd = b & 7, idx = b >> 3;
+    return (((idx >> 3) << 3) + xcd) * 8 + (idx & 7);
+}
+
+struct __attribute__((packed, aligned(4))) Texel3 { float x, y, z; };   // one global_load_dwordx3 per tap
+__device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, int off) {
+    return *reinterpret_cast<const Texel3*>(tex + off);
 }
 
 // Cubemap address of direction u (not necessarily unit): face (+x,-x,+y,-y,+z,-z; NVDIFFREC/util.py:94-101
 // inverted), bilinear taps with clamp-to-edge inside the face, texel centres at (i+0.5)/R.
 struct CubeTap {
     int   o00, o01, o10, o11;   // float offsets of the 4 taps' first channel
+    int   x0, x1, y0, y1;       // clamped tap coordinates inside the face
     float fx, fy;
     // for the backward: sc/tc numerators, 0.5*R/ma, axis bookkeeping
     float sc, tc, h, rma, sm, su, sv;
@@ -78,6 +87,7 @@ __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, in
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int x0c = min(max(x0, 0), R - 1), x1c = min(max(x0 + 1, 0), R - 1);
     const int y0c = min(max(y0, 0), R - 1), y1c = min(max(y0 + 1, 0), R - 1);
+    t.x0 = x0c; t.x1 = x1c; t.y0 = y0c; t.y1 = y1c;
     const int fb = face * R;
     t.o00 = ((fb + y0c) * R + x0c) * 3; t.o01 = ((fb + y0c) * R + x1c) * 3;
     t.o10 = ((fb + y1c) * R + x0c) * 3; t.o11 = ((fb + y1c) * R + x1c) * 3;
@@ -94,10 +104,65 @@ struct PixArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ K6
+// Forward blend, decoupled in two interleaved phases per wave:
+//   (sequential) every lane walks the batch for its own pixel: 2D falloff, alpha, transmittance, weight
+//       w = alpha*T, depth / normal / alpha accumulation -- ~25 VALU per test, no global memory;
+//   (dense)      contributing (pixel, Gaussian, w) triples are compacted with ballot + mbcnt into a 128-entry
+//       per-wave LDS ring; whenever 64 are queued all 64 lanes pop one each and do the UV Taylor step, cubemap
+//       addressing and the 12 tap loads with full lane occupancy and 64 fetches in flight, then add w*colour
+//       into the pixel's LDS accumulator.  The colour sum is order-independent, so this equals the in-order blend.
+// Only ~8 of 64 pixels of a wave contribute to a given Gaussian; running the texture path inside the sequential
+// loop ran it at ~12 % lane efficiency and serialised one L2/HBM round trip per Gaussian.
+#define FQ_CAP 128
+
+struct FwdItemCtx {
+    int R, tile_px, tile_py;
+    const float* __restrict__ tex;
+};
+
+template <int FABL>
+__device__ __forceinline__ void fwd_drain(const float4 (*s_rec)[TG_BLOCK], const uint2* s_q, float* s_col,
+                                          int qhead, int n, int lane, int wave, const FwdItemCtx& cx) {
+    if (lane < n) {
+        const uint2 e = s_q[(qhead + lane) & (FQ_CAP - 1)];
+        const float w = __uint_as_float(e.x);
+        const int pl = (int)(e.y >> 8), j = (int)(e.y & 255u);
+        const float pxf = (float)(cx.tile_px + ((wave & 1) << 3) + (pl & 7));
+        const float pyf = (float)(cx.tile_py + ((wave >> 1) << 3) + (pl >> 3));
+        const float4 r0 = s_rec[0][j], r1 = s_rec[1][j], r2 = s_rec[2][j], r3 = s_rec[3][j], r4 = s_rec[4][j];
+        const float dpx = pxf - r0.x, dpy = pyf - r0.y;
+        const float den = 1.0f + r1.z * dpx + r1.w * dpy;
+        const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+        const float u0 = r3.z + (r2.x * dpx + r2.y * dpy) * inv;
+        const float u1 = r3.w + (r2.z * dpx + r2.w * dpy) * inv;
+        const float u2 = r4.x + (r3.x * dpx + r3.y * dpy) * inv;
+        const CubeTap ct = cube_address(u0, u1, u2, cx.R);
+        const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+        const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
+        Texel3 q00, q01, q10, q11;
+        if (FABL == 2) { q00 = {0.1f, 0.2f, 0.3f}; q01 = q00; q10 = q00; q11 = q00; }
+        else { q00 = load_texel(cx.tex, ct.o00); q01 = load_texel(cx.tex, ct.o01);
+               q10 = load_texel(cx.tex, ct.o10); q11 = load_texel(cx.tex, ct.o11); }
+        const float t0 = w00 * q00.x + w01 * q01.x + w10 * q10.x + w11 * q11.x;
+        const float t1 = w00 * q00.y + w01 * q01.y + w10 * q10.y + w11 * q11.y;
+        const float t2 = w00 * q00.z + w01 * q01.z + w10 * q10.z + w11 * q11.z;
+        const float c0 = fmaxf(0.f, TG_SH_C0 * t0 + r4.y + 0.5f);
+        const float c1 = fmaxf(0.f, TG_SH_C0 * t1 + r4.z + 0.5f);
+        const float c2 = fmaxf(0.f, TG_SH_C0 * t2 + r4.w + 0.5f);
+        float* cp = s_col + (wave * 64 + pl) * 3;
+        __hip_atomic_fetch_add(cp + 0, w * c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(cp + 1, w * c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(cp + 2, w * c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+template <int FABL>     // timing experiments only (0 = product): 1 skip the dense phase, 2 dense phase without loads
 __global__ void __launch_bounds__(TG_BLOCK)
 k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_norm,
              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     __shared__ float4 s_rec[6][TG_BLOCK];
+    __shared__ uint2 s_qall[4][FQ_CAP];
+    __shared__ float s_col[TG_BLOCK * 3];
     __shared__ int s_alive[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = tile_of_block(blockIdx.x, a.num_tiles);
@@ -109,12 +174,17 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = a.ranges[tile];
     const int todo = (int)(range.y - range.x);
-    const float* __restrict__ tex = a.texture;
+    uint2* s_q = s_qall[wave];
+    FwdItemCtx cx;
+    cx.R = a.R; cx.tile_px = tile_x * TEXGS_TILE; cx.tile_py = tile_y * TEXGS_TILE; cx.tex = a.texture;
+
+    s_col[tid * 3 + 0] = 0.f; s_col[tid * 3 + 1] = 0.f; s_col[tid * 3 + 2] = 0.f;   // own pixel; only this wave touches it
 
     bool done = !inside;
     float T = 1.0f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, Al = 0.f;
+    float Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, Al = 0.f;
     uint32_t last = 0;
+    int qhead = 0, qtail = 0;                                  // wave-uniform
 
     for (int base = 0; base < todo; base += TG_BLOCK) {
         const unsigned long long alive = __ballot(!done);
@@ -130,52 +200,51 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             s_rec[3][tid] = v3; s_rec[4][tid] = v4; s_rec[5][tid] = v5;
         }
         __syncthreads();
-        if (alive == 0ull) continue;                    // this wave is finished; it only helps staging
-        for (int j = 0; j < cnt; ++j) {
-            const float4 r0 = s_rec[0][j];              // xy.x xy.y conic.a conic.b
-            const float4 r1 = s_rec[1][j];              // conic.c opacity g.x g.y
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-            const float alpha = fminf(TG_ALPHA_MAX, r1.y * __expf(power));
-            bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-            const float Tn = T * (1.0f - alpha);
-            if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
-            if (ok) {
-                const float4 r2 = s_rec[2][j];          // G00 G01 G10 G11
-                const float4 r3 = s_rec[3][j];          // G20 G21 phi0 phi1
-                const float4 r4 = s_rec[4][j];          // phi2 vd0 vd1 vd2
-                const float4 r5 = s_rec[5][j];          // depth n0 n1 n2
-                const float dpx = -dx, dpy = -dy;
-                const float den = 1.0f + r1.z * dpx + r1.w * dpy;
-                const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-                const float u0 = r3.z + (r2.x * dpx + r2.y * dpy) * inv;
-                const float u1 = r3.w + (r2.z * dpx + r2.w * dpy) * inv;
-                const float u2 = r4.x + (r3.x * dpx + r3.y * dpy) * inv;
-                const CubeTap ct = cube_address(u0, u1, u2, a.R);
-                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
-                const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
-                const float* p00 = tex + ct.o00; const float* p01 = tex + ct.o01;
-                const float* p10 = tex + ct.o10; const float* p11 = tex + ct.o11;
-                const float t0 = w00 * p00[0] + w01 * p01[0] + w10 * p10[0] + w11 * p11[0];
-                const float t1 = w00 * p00[1] + w01 * p01[1] + w10 * p10[1] + w11 * p11[1];
-                const float t2 = w00 * p00[2] + w01 * p01[2] + w10 * p10[2] + w11 * p11[2];
-                const float c0 = fmaxf(0.f, TG_SH_C0 * t0 + r4.y + 0.5f);
-                const float c1 = fmaxf(0.f, TG_SH_C0 * t1 + r4.z + 0.5f);
-                const float c2 = fmaxf(0.f, TG_SH_C0 * t2 + r4.w + 0.5f);
-                const float w = alpha * T;
-                C0 += w * c0; C1 += w * c1; C2 += w * c2;
-                Dp += w * r5.x; N0 += w * r5.y; N1 += w * r5.z; N2 += w * r5.w; Al += w;
-                T = Tn;
-                last = (uint32_t)(base + j + 1);
+        if (alive != 0ull) {
+            for (int j = 0; j < cnt; ++j) {
+                const float4 r0 = s_rec[0][j];              // xy.x xy.y conic.a conic.b
+                const float4 r1 = s_rec[1][j];              // conic.c opacity g.x g.y
+                const float dx = r0.x - pxf, dy = r0.y - pyf;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float alpha = fminf(TG_ALPHA_MAX, r1.y * __expf(power));
+                bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                const float Tn = T * (1.0f - alpha);
+                if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
+                const unsigned long long bal = __ballot(ok);
+                if (bal != 0ull) {
+                    const float w = alpha * T;
+                    if (ok) {
+                        const float4 r5 = s_rec[5][j];      // depth n0 n1 n2
+                        Dp += w * r5.x; N0 += w * r5.y; N1 += w * r5.z; N2 += w * r5.w; Al += w;
+                        T = Tn;
+                        last = (uint32_t)(base + j + 1);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        s_q[(qtail + rank) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), ((uint32_t)lane << 8) | (uint32_t)j);
+                    }
+                    qtail += __popcll(bal);
+                    if (qtail - qhead >= 64) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (FABL != 1) fwd_drain<FABL>(s_rec, s_q, s_col, qhead, 64, lane, wave, cx);
+                        qhead += 64;
+                    }
+                }
+                if (__ballot(!done) == 0ull) break;
             }
-            if (__ballot(!done) == 0ull) break;
+            // items reference this batch's LDS records: finish them before the records are replaced
+            if (qtail - qhead > 0) {
+                __builtin_amdgcn_wave_barrier();
+                if (FABL != 1) fwd_drain<FABL>(s_rec, s_q, s_col, qhead, qtail - qhead, lane, wave, cx);
+                qhead = qtail;
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
-        out_color[pix] = C0 + T * a.bg[0];
-        out_color[HW + pix] = C1 + T * a.bg[1];
-        out_color[2 * HW + pix] = C2 + T * a.bg[2];
+        out_color[pix] = s_col[tid * 3 + 0] + T * a.bg[0];
+        out_color[HW + pix] = s_col[tid * 3 + 1] + T * a.bg[1];
+        out_color[2 * HW + pix] = s_col[tid * 3 + 2] + T * a.bg[2];
         out_depth[pix] = Dp;
         out_norm[pix] = N0; out_norm[HW + pix] = N1; out_norm[2 * HW + pix] = N2;
         out_alpha[pix] = Al;
@@ -185,26 +254,85 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 }
 
 // ------------------------------------------------------------------------------------------------ K7
+// Backward replay.  What the counters said about the first version (rocprofv3, profiles/r01_*):
+//   * 124 M L2 misses / 4.5 GB written per launch: on this multi-XCD part every global fp32 atomic executes
+//     memory-side, and a wave instruction whose 64 lanes hit 64 unrelated dwords is 64 requests (~21 G req/s chip
+//     wide); 6 adjacent lanes -> 6 adjacent dwords is 4.6x cheaper, 64 consecutive dwords 12.8x (scripts/ubench);
+//   * only ~8 of 64 pixels of a wave contribute to a given Gaussian, so texture math inside the per-pixel loop ran
+//     at ~12 % lane efficiency and the 24-value wave reduction ran for every (wave, Gaussian).
+// Structure now (one wave = one 8x8 pixel block, the 4 waves of a tile are independent; no block barrier in the loop):
+//   per chunk of 64 instances (back to front) lane l keeps instance l's (xy, conic, opacity, depth, normal) in
+//   registers; the sequential loops broadcast them with v_readlane -- no LDS traffic, no LDS latency in the chain.
+//   stage A  sequential, ~30 VALU / test: falloff, alpha, T /= (1-alpha); contributing (pixel, j) pairs are
+//            compacted (ballot + mbcnt) into an LDS item list {T, alpha_raw, q, key}; per-j ballots stay in VGPRs.
+//   stage B  dense, 64 items per round: UV Taylor step, cubemap address, 4 dwordx3 tap loads, colour and the scalar
+//            q = colour . dL/dpixel for stage C; everything that needs only w = alpha*T (view-dependent colour, uv ->
+//            phi/G/g/xy partials) goes to the per-wave LDS accumulators with ds_add_f32; the 12 texture-gradient
+//            updates of each pair are transposed through LDS so adjacent lanes issue adjacent dwords of a tap row.
+//   stage C  sequential, scalar suffix recurrence dL/dalpha = T (s - suffix) + bg term with s = q + geometry
+//            channels; 10 partials (xy, conic, opacity, depth, normal) reduced with a transposing butterfly
+//            (value k ends in lane k) and added to the LDS accumulators.
+//   chunk end: touched accumulator rows are flushed with row-coalesced atomics.
+#define BQ_CAP 256
+
+struct BItem { float T, araw, q; uint32_t key; };     // key = (pixel lane << 8) | j
+
+template <int CTRL>
+__device__ __forceinline__ float dppx(float v) { return dpp_mov<CTRL>(v); }
+
+// Transposing butterfly over 16 per-lane values: on return every lane l holds sum over the 64 lanes of v[l & 15].
+__device__ __forceinline__ float reduce16_transposed(float (&v)[16], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float n0[8], n1[4], n2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        n0[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b1 ? n0[2 * i + 1] : n0[2 * i], send = b1 ? n0[2 * i] : n0[2 * i + 1];
+        n1[i] = keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? n1[2 * i + 1] : n1[2 * i], send = b2 ? n1[2 * i] : n1[2 * i + 1];
+        n2[i] = keep + __shfl_xor(send, 4, 64);
+    }
+    const float keep = b3 ? n2[1] : n2[0], send = b3 ? n2[0] : n2[1];
+    float r = keep + __shfl_xor(send, 8, 64);
+    r += __shfl_xor(r, 16, 64);
+    r += __shfl_xor(r, 32, 64);
+    return r;
+}
+
+template <int ABL>      // timing experiments only (0 = product): 1 no texture atomics, 2 no stage-C reduce, 8 no tap loads
 __global__ void __launch_bounds__(TG_BLOCK)
 k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
              float* __restrict__ acc, float* __restrict__ dtex) {
-    __shared__ float4 s_rec[6][TG_BLOCK];
-    __shared__ float s_grad[TG_BLOCK][TEXGS_ACC_FLOATS];
-    __shared__ uint32_t s_id[TG_BLOCK];
-    __shared__ int s_max[4];
+    __shared__ float4 s_items_all[4][BQ_CAP];                 // 16 KB
+    __shared__ float s_grad_all[4][64 * TEXGS_ACC_FLOATS];    // 24 KB
+    __shared__ uint2 s_stage_all[4][64 * 12];                 // 24 KB
+    __shared__ float s_dpix[TG_BLOCK * 3];                    // 3 KB
+    __shared__ uint32_t s_id_all[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = tile_of_block(blockIdx.x, a.num_tiles);
     if (tile >= a.num_tiles) return;
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    const int px = tile_x * TEXGS_TILE + ((wave & 1) << 3) + (lane & 7);
-    const int py = tile_y * TEXGS_TILE + ((wave >> 1) << 3) + (lane >> 3);
+    const int wave_px = tile_x * TEXGS_TILE + ((wave & 1) << 3), wave_py = tile_y * TEXGS_TILE + ((wave >> 1) << 3);
+    const int px = wave_px + (lane & 7), py = wave_py + (lane >> 3);
     const bool inside = (px < a.W) && (py < a.H);
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = a.ranges[tile];
+    const int todo = (int)(range.y - range.x);
     const int HW = a.W * a.H, pix = py * a.W + px;
     const float* __restrict__ tex = a.texture;
+    float4* s_items = s_items_all[wave];
+    float* s_grad = s_grad_all[wave];
+    uint2* s_stage = s_stage_all[wave];
+    uint32_t* s_id = s_id_all[wave];
 
     float Tfin = 1.f; int last = 0;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
@@ -216,162 +344,218 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
         if (dL_dalpha) dpix[7] = dL_dalpha[pix];
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
-    {
-        const int wm = wave_max_i(last);
-        if (lane == 0) s_max[wave] = wm;
-    }
-    __syncthreads();
-    const int max_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    const int wave_last = s_max[wave];
+    s_dpix[tid * 3 + 0] = dpix[0]; s_dpix[tid * 3 + 1] = dpix[1]; s_dpix[tid * 3 + 2] = dpix[2];
+#pragma unroll
+    for (int k = 0; k < TEXGS_ACC_FLOATS; ++k) s_grad[k * 64 + lane] = 0.f;
+    const int wave_last = min(wave_max_i(last), todo);
+    __builtin_amdgcn_wave_barrier();
 
     float T = Tfin;
-    float accum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float last_alpha = 0.f;
-    float last_f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float suffix = 0.f, last_alpha = 0.f, last_s = 0.f;
 
-    const int nb = (max_last + TG_BLOCK - 1) / TG_BLOCK;
-    for (int b = nb - 1; b >= 0; --b) {
-        const int base = b * TG_BLOCK;
-        const int cnt = min(TG_BLOCK, max_last - base);
-        __syncthreads();
-        if (tid < cnt) {
-            const uint32_t id = a.point_list[range.x + base + tid];
-            s_id[tid] = id;
+    const int nchunks = (wave_last + 63) >> 6;
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const int base = c << 6;
+        const int jtop = min(64, wave_last - base);           // instances [0, jtop) of this chunk matter
+        // ---- lane l <- instance l of the chunk
+        uint32_t id = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r5 = r0;
+        if (lane < jtop) {
+            id = a.point_list[range.x + base + lane];
             const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            const float4 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5];
-            s_rec[0][tid] = v0; s_rec[1][tid] = v1; s_rec[2][tid] = v2;
-            s_rec[3][tid] = v3; s_rec[4][tid] = v4; s_rec[5][tid] = v5;
+            r0 = r[0]; r1 = r[1]; r5 = r[5];
         }
-#pragma unroll
-        for (int k = 0; k < TEXGS_ACC_FLOATS; ++k) s_grad[tid][k] = 0.f;
-        __syncthreads();
-        const int jhi = min(cnt, wave_last - base) - 1;          // nothing in this wave contributed beyond wave_last
-        for (int j = jhi; j >= 0; --j) {
-            const int pos = base + j;
-            const float4 r0 = s_rec[0][j];
-            const float4 r1 = s_rec[1][j];
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-            const float Gs = __expf(power);
-            const float araw = r1.y * Gs;
-            const float alpha = fminf(TG_ALPHA_MAX, araw);
-            const bool ok = inside && (pos < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-            if (__ballot(ok) == 0ull) continue;
-            float part[TEXGS_ACC_FLOATS];
-#pragma unroll
-            for (int k = 0; k < TEXGS_ACC_FLOATS; ++k) part[k] = 0.f;
-            if (ok) {
-                const float4 r2 = s_rec[2][j];
-                const float4 r3 = s_rec[3][j];
-                const float4 r4 = s_rec[4][j];
-                const float4 r5 = s_rec[5][j];
-                const float one_m_a = 1.0f - alpha;
-                T = T / one_m_a;
-                const float w = alpha * T;
-                // ---- recompute the texture branch
-                const float dpx = -dx, dpy = -dy;
-                const float den = 1.0f + r1.z * dpx + r1.w * dpy;
-                const bool good = den >= TG_DEN_MIN;
-                const float inv = good ? __builtin_amdgcn_rcpf(den) : 0.0f;
-                const float nu0 = r2.x * dpx + r2.y * dpy, nu1 = r2.z * dpx + r2.w * dpy, nu2 = r3.x * dpx + r3.y * dpy;
-                const float u0 = r3.z + nu0 * inv, u1 = r3.w + nu1 * inv, u2 = r4.x + nu2 * inv;
-                const CubeTap ct = cube_address(u0, u1, u2, a.R);
-                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
-                const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
-                float t00[3], t01[3], t10[3], t11[3], f[8];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    t00[ch] = tex[ct.o00 + ch]; t01[ch] = tex[ct.o01 + ch];
-                    t10[ch] = tex[ct.o10 + ch]; t11[ch] = tex[ct.o11 + ch];
+        s_id[lane] = id;
+        uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
+        int j = jtop - 1;
+        while (j >= 0) {
+            // ================================================================ stage A
+            const int seg_hi = j;
+            int n_items = 0;
+            for (; j >= 0; --j) {
+                const float gx_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.x), j));
+                const float gy_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.y), j));
+                const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.z), j));
+                const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.w), j));
+                const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), j));
+                const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), j));
+                const float dx = gx_ - pxf, dy = gy_ - pyf;
+                const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+                const float araw = op * __expf(power);
+                const float alpha = fminf(TG_ALPHA_MAX, araw);
+                const bool ok = inside && (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                const unsigned long long bal = __ballot(ok);
+                const int nb = __popcll(bal);
+                if (nb == 0) continue;
+                if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
+                if (lane == j) { touched_lo = (uint32_t)bal; touched_hi = (uint32_t)(bal >> 32); }
+                if (ok) {
+                    T = T / (1.0f - alpha);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    s_items[n_items + rank] = make_float4(T, araw, 0.f, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
                 }
-                const float vd[3] = {r4.y, r4.z, r4.w};
-                float pre[3];
+                n_items += nb;
+            }
+            const int seg_lo = j + 1;
+            __builtin_amdgcn_wave_barrier();
+            // ================================================================ stage B
+            for (int r = 0; r < n_items; r += 64) {
+                const int e = r + lane;
+                const bool have = e < n_items;
+                uint32_t toff[12]; float tval[12];
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float tv = w00 * t00[ch] + w01 * t01[ch] + w10 * t10[ch] + w11 * t11[ch];
-                    pre[ch] = TG_SH_C0 * tv + vd[ch] + 0.5f;
-                    f[ch] = fmaxf(0.f, pre[ch]);
-                }
-                f[3] = r5.x; f[4] = r5.y; f[5] = r5.z; f[6] = r5.w; f[7] = 1.0f;
-                // ---- alpha gradient: suffix accumulation behind this Gaussian (lineage back-to-front replay)
-                float dL_dalpha_ = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    accum[ch] = last_alpha * last_f[ch] + (1.f - last_alpha) * accum[ch];
-                    last_f[ch] = f[ch];
-                    dL_dalpha_ += (f[ch] - accum[ch]) * dpix[ch];
-                }
-                last_alpha = alpha;
-                dL_dalpha_ *= T;
-                dL_dalpha_ += (-Tfin / one_m_a) * bgdot;
-                // ---- 2D Gaussian: straight-through the 0.99 clamp (lineage)
-                const float dL_dpower = araw * dL_dalpha_;
-                const float gdx = -(r0.z * dx + r0.w * dy), gdy = -(r1.x * dy + r0.w * dx);
-                part[R_XY]        = dL_dpower * gdx;
-                part[R_XY + 1]    = dL_dpower * gdy;
-                part[R_CONIC]     = -0.5f * dx * dx * dL_dpower;
-                part[R_CONIC + 1] = -dx * dy * dL_dpower;
-                part[R_CONIC + 2] = -0.5f * dy * dy * dL_dpower;
-                part[R_OP]        = Gs * dL_dalpha_;
-                // ---- per-Gaussian blended features
-                part[R_DEPTH] = w * dpix[3];
-                part[R_N] = w * dpix[4]; part[R_N + 1] = w * dpix[5]; part[R_N + 2] = w * dpix[6];
-                // ---- colour -> view-dependent term, texture, uv
-                float dtexv[3];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float dcol = (pre[ch] > 0.f) ? w * dpix[ch] : 0.f;
-                    part[R_VD + ch] = dcol;
-                    dtexv[ch] = TG_SH_C0 * dcol;
-                }
-                float dLdcol = 0.f, dLdrow = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    if (dtexv[ch] != 0.f) {
-                        unsafeAtomicAdd(dtex + ct.o00 + ch, w00 * dtexv[ch]);
-                        unsafeAtomicAdd(dtex + ct.o01 + ch, w01 * dtexv[ch]);
-                        unsafeAtomicAdd(dtex + ct.o10 + ch, w10 * dtexv[ch]);
-                        unsafeAtomicAdd(dtex + ct.o11 + ch, w11 * dtexv[ch]);
+                for (int k = 0; k < 12; ++k) { toff[k] = 0u; tval[k] = 0.f; }
+                if (have) {
+                    const float4 it = s_items[e];
+                    const uint32_t key = __float_as_uint(it.w);
+                    const int pl = (int)(key >> 8), jj = (int)(key & 63u);
+                    const float alpha = fminf(TG_ALPHA_MAX, it.y);
+                    const float w = alpha * it.x;
+                    const float ipx = (float)(wave_px + (pl & 7)), ipy = (float)(wave_py + (pl >> 3));
+                    const float4* __restrict__ rr = a.rec + (size_t)s_id[jj] * (TEXGS_REC_FLOATS / 4);
+                    const float4 q0 = rr[0], q1 = rr[1], r2 = rr[2], r3 = rr[3], r4 = rr[4];
+                    const float dpx = ipx - q0.x, dpy = ipy - q0.y;
+                    const float den = 1.0f + q1.z * dpx + q1.w * dpy;
+                    const bool good = den >= TG_DEN_MIN;
+                    const float inv = good ? __builtin_amdgcn_rcpf(den) : 0.0f;
+                    const float nu0 = r2.x * dpx + r2.y * dpy, nu1 = r2.z * dpx + r2.w * dpy, nu2 = r3.x * dpx + r3.y * dpy;
+                    const float u0 = r3.z + nu0 * inv, u1 = r3.w + nu1 * inv, u2 = r4.x + nu2 * inv;
+                    const CubeTap ct = cube_address(u0, u1, u2, a.R);
+                    const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+                    const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
+                    Texel3 t00 = {0.1f, 0.2f, 0.3f}, t01 = t00, t10 = t00, t11 = t00;
+                    if (!(ABL & 8)) {
+                        t00 = load_texel(tex, ct.o00); t01 = load_texel(tex, ct.o01);
+                        t10 = load_texel(tex, ct.o10); t11 = load_texel(tex, ct.o11);
                     }
-                    dLdcol += dtexv[ch] * ((1.f - ct.fy) * (t01[ch] - t00[ch]) + ct.fy * (t11[ch] - t10[ch]));
-                    dLdrow += dtexv[ch] * ((1.f - ct.fx) * (t10[ch] - t00[ch]) + ct.fx * (t11[ch] - t01[ch]));
+                    const float d0 = s_dpix[(wave * 64 + pl) * 3 + 0], d1 = s_dpix[(wave * 64 + pl) * 3 + 1],
+                                d2 = s_dpix[(wave * 64 + pl) * 3 + 2];
+                    const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + r4.y + 0.5f;
+                    const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + r4.z + 0.5f;
+                    const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + r4.w + 0.5f;
+                    const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
+                    s_items[e].z = qv;
+                    // colour -> view-dependent term and texture
+                    const float dc0 = (pre0 > 0.f) ? w * d0 : 0.f, dc1 = (pre1 > 0.f) ? w * d1 : 0.f, dc2 = (pre2 > 0.f) ? w * d2 : 0.f;
+                    const float x0 = TG_SH_C0 * dc0, x1 = TG_SH_C0 * dc1, x2 = TG_SH_C0 * dc2;
+                    toff[0] = ct.o00; toff[1] = ct.o00 + 1; toff[2] = ct.o00 + 2; toff[3] = ct.o01; toff[4] = ct.o01 + 1; toff[5] = ct.o01 + 2;
+                    toff[6] = ct.o10; toff[7] = ct.o10 + 1; toff[8] = ct.o10 + 2; toff[9] = ct.o11; toff[10] = ct.o11 + 1; toff[11] = ct.o11 + 2;
+                    tval[0] = w00 * x0; tval[1] = w00 * x1; tval[2] = w00 * x2; tval[3] = w01 * x0; tval[4] = w01 * x1; tval[5] = w01 * x2;
+                    tval[6] = w10 * x0; tval[7] = w10 * x1; tval[8] = w10 * x2; tval[9] = w11 * x0; tval[10] = w11 * x1; tval[11] = w11 * x2;
+                    const float dLdcol = x0 * ((1.f - ct.fy) * (t01.x - t00.x) + ct.fy * (t11.x - t10.x))
+                                       + x1 * ((1.f - ct.fy) * (t01.y - t00.y) + ct.fy * (t11.y - t10.y))
+                                       + x2 * ((1.f - ct.fy) * (t01.z - t00.z) + ct.fy * (t11.z - t10.z));
+                    const float dLdrow = x0 * ((1.f - ct.fx) * (t10.x - t00.x) + ct.fx * (t11.x - t01.x))
+                                       + x1 * ((1.f - ct.fx) * (t10.y - t00.y) + ct.fx * (t11.y - t01.y))
+                                       + x2 * ((1.f - ct.fx) * (t10.z - t00.z) + ct.fx * (t11.z - t01.z));
+                    const float dua = dLdcol * ct.su * ct.h, dub = dLdrow * ct.sv * ct.h;
+                    const float dum = -(dLdcol * ct.sc + dLdrow * ct.tc) * ct.h * ct.rma * ct.sm;
+                    float du0, du1, du2;
+                    if (ct.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
+                    else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
+                    else                   { du2 = dum; du0 = dua; du1 = dub; }
+                    float* gr = s_grad + jj;                         // s_grad[k * 64 + j]
+#define GADD(K, V) do { const float v_ = (V); if (v_ != 0.f) __hip_atomic_fetch_add(gr + (K) * 64, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+                    GADD(R_VD, dc0); GADD(R_VD + 1, dc1); GADD(R_VD + 2, dc2);
+                    GADD(R_PHI, du0); GADD(R_PHI + 1, du1); GADD(R_PHI + 2, du2);
+                    if (good) {
+                        const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
+                        const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;
+                        GADD(R_GM + 0, dn0 * dpx); GADD(R_GM + 1, dn0 * dpy);
+                        GADD(R_GM + 2, dn1 * dpx); GADD(R_GM + 3, dn1 * dpy);
+                        GADD(R_GM + 4, dn2 * dpx); GADD(R_GM + 5, dn2 * dpy);
+                        GADD(R_G2, dden * dpx); GADD(R_G2 + 1, dden * dpy);
+                        GADD(R_XY, -((r2.x * dn0 + r2.z * dn1 + r3.x * dn2) + q1.z * dden));
+                        GADD(R_XY + 1, -((r2.y * dn0 + r2.w * dn1 + r3.y * dn2) + q1.w * dden));
+                    }
+#undef GADD
                 }
-                // (col,row) -> uv
-                const float dua = dLdcol * ct.su * ct.h, dub = dLdrow * ct.sv * ct.h;
-                const float dum = -(dLdcol * ct.sc + dLdrow * ct.tc) * ct.h * ct.rma * ct.sm;
-                float du0, du1, du2;
-                if (ct.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
-                else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
-                else                   { du2 = dum; du0 = dua; du1 = dub; }
-                part[R_PHI] = du0; part[R_PHI + 1] = du1; part[R_PHI + 2] = du2;
-                if (good) {
-                    const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;     // dL/d num
-                    const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;
-                    part[R_GM + 0] = dn0 * dpx; part[R_GM + 1] = dn0 * dpy;
-                    part[R_GM + 2] = dn1 * dpx; part[R_GM + 3] = dn1 * dpy;
-                    part[R_GM + 4] = dn2 * dpx; part[R_GM + 5] = dn2 * dpy;
-                    part[R_G2] = dden * dpx; part[R_G2 + 1] = dden * dpy;
-                    // dp = pix - xy
-                    part[R_XY]     -= (r2.x * dn0 + r2.z * dn1 + r3.x * dn2) + r1.z * dden;
-                    part[R_XY + 1] -= (r2.y * dn0 + r2.w * dn1 + r3.y * dn2) + r1.w * dden;
-                }
-            }
-            // ---- reduce the 24 partials over the wave, accumulate per instance in LDS
+                if (!(ABL & 1)) {
+                    // transpose (pair, k) -> lanes so that adjacent lanes carry adjacent dwords of a tap row
 #pragma unroll
+                    for (int k = 0; k < 12; ++k) s_stage[lane * 12 + k] = make_uint2(toff[k], __float_as_uint(tval[k]));
+                    __builtin_amdgcn_wave_barrier();
+                    const int nent = min(64, n_items - r) * 12;
+#pragma unroll
+                    for (int it2 = 0; it2 < 12; ++it2) {
+                        const int ee = it2 * 64 + lane;
+                        if (ee < nent) {
+                            const uint2 sv = s_stage[ee];
+                            const float v = __uint_as_float(sv.y);
+                            if (v != 0.f) unsafeAtomicAdd(dtex + sv.x, v);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ================================================================ stage C
+            int it0 = 0;
+            for (int jj = seg_hi; jj >= seg_lo; --jj) {
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)touched_lo, jj);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)touched_hi, jj);
+                const unsigned long long bal = ((unsigned long long)bhi << 32) | blo;
+                if (bal == 0ull) continue;
+                const bool ok = (bal >> lane) & 1ull;
+                float part[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) part[k] = 0.f;
+                if (ok) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                    const float4 it = s_items[it0 + rank];
+                    const float Ti = it.x, araw = it.y, qv = it.z;
+                    const float alpha = fminf(TG_ALPHA_MAX, araw);
+                    const float gx_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.x), jj));
+                    const float gy_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.y), jj));
+                    const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.z), jj));
+                    const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.w), jj));
+                    const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), jj));
+                    const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), jj));
+                    const float dep = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.x), jj));
+                    const float n0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.y), jj));
+                    const float n1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.z), jj));
+                    const float n2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.w), jj));
+                    const float dx = gx_ - pxf, dy = gy_ - pyf;
+                    const float w = alpha * Ti;
+                    const float s_i = qv + dep * dpix[3] + n0 * dpix[4] + n1 * dpix[5] + n2 * dpix[6] + dpix[7];
+                    suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
+                    last_s = s_i; last_alpha = alpha;
+                    float dL_dalpha_ = (s_i - suffix) * Ti + (-Tfin / (1.0f - alpha)) * bgdot;
+                    const float dL_dpower = araw * dL_dalpha_;        // straight through the 0.99 clamp (lineage)
+                    const float gdx = -(ca * dx + cb * dy), gdy = -(cc * dy + cb * dx);
+                    part[0] = dL_dpower * gdx;
+                    part[1] = dL_dpower * gdy;
+                    part[2] = -0.5f * dx * dx * dL_dpower;
+                    part[3] = -dx * dy * dL_dpower;
+                    part[4] = -0.5f * dy * dy * dL_dpower;
+                    part[5] = (araw / op) * dL_dalpha_;
+                    part[6] = w * dpix[3];
+                    part[7] = w * dpix[4]; part[8] = w * dpix[5]; part[9] = w * dpix[6];
+                }
+                it0 += __popcll(bal);
+                const float tot = (ABL & 2) ? part[lane & 15] : reduce16_transposed(part, lane);
+                // value k lives in lane k: 0,1 xy | 2..4 conic | 5 opacity | 6 depth | 7..9 normal
+                if (lane < 10) {
+                    const int slot = (lane < 6) ? lane : (lane == 6 ? R_DEPTH : (R_N + lane - 7));
+                    if (tot != 0.f) __hip_atomic_fetch_add(s_grad + slot * 64 + jj, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- chunk end: flush the rows this wave touched (row = 24 consecutive floats of acc)
+        {
+            const bool touched = (touched_lo | touched_hi) != 0u;      // lane j: instance j touched by this wave
+            const unsigned long long tb = __ballot(touched);
             for (int k = 0; k < TEXGS_ACC_FLOATS; ++k) {
-                const float s = wave_sum(part[k]);
-                if (lane == 0) __hip_atomic_fetch_add(&s_grad[j][k], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // lane j handles its own instance, slot k  (transposed layout s_grad[k][j] -> conflict-free LDS)
+                const float v = s_grad[k * 64 + lane];
+                s_grad[k * 64 + lane] = 0.f;
+                if (touched && v != 0.f) unsafeAtomicAdd(acc + (size_t)id * TEXGS_ACC_FLOATS + k, v);
             }
+            (void)tb;
         }
-        __syncthreads();
-        // flush: 32 lanes per instance (24 used) -> consecutive addresses inside one 96-B accumulator row
-        for (int idx = tid; idx < cnt * 32; idx += TG_BLOCK) {
-            const int j = idx >> 5, k = idx & 31;
-            if (k < TEXGS_ACC_FLOATS) {
-                const float v = s_grad[j][k];
-                if (v != 0.f) unsafeAtomicAdd(acc + (size_t)s_id[j] * TEXGS_ACC_FLOATS + k, v);
-            }
-        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -392,15 +576,28 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
     const PixArgs a = make_pix(c, f, in, g, b);
-    const int grid = ((a.num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm,
+    const int grid = ((a.num_tiles + 63) / 64) * 64;
+    static const int fabl = getenv("TEXGS_FWD_ABLATE") ? atoi(getenv("TEXGS_FWD_ABLATE")) : 0;
+    if (fabl == 1) { hipLaunchKernelGGL(k_render_fwd<1>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
+    if (fabl == 2) { hipLaunchKernelGGL(k_render_fwd<2>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
+    hipLaunchKernelGGL(k_render_fwd<0>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm,
                        img->out_alpha, img->final_T, img->n_contrib);
 }
 
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     const PixArgs a = make_pix(c, f, in, g, b);
-    const int grid = ((a.num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->final_T, img->n_contrib,
-                       gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture);
+    const int grid = ((a.num_tiles + 63) / 64) * 64;
+    static const int abl = getenv("TEXGS_ABLATE") ? atoi(getenv("TEXGS_ABLATE")) : 0;
+#define LAUNCH_BWD(A) hipLaunchKernelGGL(k_render_bwd<A>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->final_T, img->n_contrib, \
+                       gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
+    switch (abl) {
+        case 1: LAUNCH_BWD(1); break;
+        case 2: LAUNCH_BWD(2); break;
+        case 3: LAUNCH_BWD(3); break;
+        case 9: LAUNCH_BWD(9); break;
+        case 11: LAUNCH_BWD(11); break;
+        default: LAUNCH_BWD(0); break;
+    }
+#undef LAUNCH_BWD
 }

@@ -50,7 +50,9 @@ class Grads(C.Structure):
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-           "texgs_render_forward", "texgs_backward", "texgs_mark_visible"]
+           "texgs_render_forward", "texgs_backward", "texgs_mark_visible", "texgs_profile_enable",
+           "texgs_profile_read"]
+KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd"]
 
 _lib = None
 
@@ -78,6 +80,10 @@ def load():
     lib.texgs_render_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), C.c_void_p]
     lib.texgs_backward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), P(Grads), C.c_void_p]
     lib.texgs_mark_visible.argtypes = [P(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_profile_enable.argtypes = [C.c_int]
+    lib.texgs_profile_enable.restype = C.c_int
+    lib.texgs_profile_read.argtypes = [P(C.c_float), P(C.c_uint32)]
+    lib.texgs_profile_read.restype = C.c_int
     for name in ("texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
                  "texgs_render_forward", "texgs_backward", "texgs_mark_visible"):
         getattr(lib, name).restype = C.c_int
@@ -92,3 +98,16 @@ def check(rc, what):
     if rc != 0:
         msg = load().texgs_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def profile_enable(on: bool):
+    check(load().texgs_profile_enable(1 if on else 0), "texgs_profile_enable")
+
+
+def profile_read():
+    """-> {kernel_name: (total_ms, launches)} since the last read (synchronises the recorded events)."""
+    n = len(KERNEL_NAMES)
+    ms = (C.c_float * n)()
+    cnt = (C.c_uint32 * n)()
+    check(load().texgs_profile_read(ms, cnt), "texgs_profile_read")
+    return {KERNEL_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
