@@ -9,38 +9,10 @@
 //
 // No MFMA: there is no dense contraction on this path.  Bound: HBM / L2 gather + fp32 atomics (backward).
 #include "common.h"
+#include "wave_ops.h"
 #include <stdlib.h>
 
 namespace {
-
-#define DPP_QUAD_XOR1   0xB1     // quad_perm [1,0,3,2]
-#define DPP_QUAD_XOR2   0x4E     // quad_perm [2,3,0,1]
-#define DPP_ROW_HMIRROR 0x141
-#define DPP_ROW_MIRROR  0x140
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-
-// Sum over the 64 lanes of a wave; result is wave-uniform.
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_mov<DPP_QUAD_XOR1>(v);
-    v += dpp_mov<DPP_QUAD_XOR2>(v);
-    v += dpp_mov<DPP_ROW_HMIRROR>(v);
-    v += dpp_mov<DPP_ROW_MIRROR>(v);
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (a + b) + (c + d);
-}
-
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
-    return v;
-}
 
 // blockIdx -> tile.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness).  Tiles are dealt to
 // XCDs in groups of 8 row-adjacent tiles, cyclically: neighbours inside a group share most of their Gaussians'
@@ -265,58 +237,31 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //   registers; the sequential loops broadcast them with v_readlane -- no LDS traffic, no LDS latency in the chain.
 //   stage A  sequential, ~30 VALU / test: falloff, alpha, T /= (1-alpha); contributing (pixel, j) pairs are
 //            compacted (ballot + mbcnt) into an LDS item list {T, alpha_raw, q, key}; per-j ballots stay in VGPRs.
-//   stage B  dense, 64 items per round: UV Taylor step, cubemap address, 4 dwordx3 tap loads, colour and the scalar
-//            q = colour . dL/dpixel for stage C; everything that needs only w = alpha*T (view-dependent colour, uv ->
-//            phi/G/g/xy partials) goes to the per-wave LDS accumulators with ds_add_f32; the 12 texture-gradient
-//            updates of each pair are transposed through LDS so adjacent lanes issue adjacent dwords of a tap row.
+//   stage B  dense, 64 items per round: UV Taylor step, cubemap address, 4 dwordx3 tap loads, colour; stores per item
+//            q = colour . dL/dpixel (for the suffix recurrence) and dL/dcolour (3), dL/duv (3), 1/den, dL/dden;
+//            the 12 texture-gradient updates of each pair are transposed through LDS so adjacent lanes issue
+//            adjacent dwords of a tap row.  (A first cut added the uv-path partials to LDS accumulators with
+//            ds_add_f32: ~8 lanes per address serialise, 1.5 ms per launch.)
 //   stage C  sequential, scalar suffix recurrence dL/dalpha = T (s - suffix) + bg term with s = q + geometry
-//            channels; 10 partials (xy, conic, opacity, depth, normal) reduced with a transposing butterfly
-//            (value k ends in lane k) and added to the LDS accumulators.
-//   chunk end: touched accumulator rows are flushed with row-coalesced atomics.
-#define BQ_CAP 256
+//            channels; all 24 per-Gaussian partials are formed by the owning pixel lane, reduced over the wave with
+//            ONE transposing butterfly (value k ends in lane k, DPP + permlane swaps only) and lanes 0..23 add
+//            24 consecutive dwords of the accumulator row: one coalesced memory-side request.
+#ifndef BQ_CAP
+#define BQ_CAP 192
+#endif
 
-struct BItem { float T, araw, q; uint32_t key; };     // key = (pixel lane << 8) | j
-
-template <int CTRL>
-__device__ __forceinline__ float dppx(float v) { return dpp_mov<CTRL>(v); }
-
-// Transposing butterfly over 16 per-lane values: on return every lane l holds sum over the 64 lanes of v[l & 15].
-__device__ __forceinline__ float reduce16_transposed(float (&v)[16], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    float n0[8], n1[4], n2[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
-        n0[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float keep = b1 ? n0[2 * i + 1] : n0[2 * i], send = b1 ? n0[2 * i] : n0[2 * i + 1];
-        n1[i] = keep + dpp_mov<DPP_QUAD_XOR2>(send);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = b2 ? n1[2 * i + 1] : n1[2 * i], send = b2 ? n1[2 * i] : n1[2 * i + 1];
-        n2[i] = keep + __shfl_xor(send, 4, 64);
-    }
-    const float keep = b3 ? n2[1] : n2[0], send = b3 ? n2[0] : n2[1];
-    float r = keep + __shfl_xor(send, 8, 64);
-    r += __shfl_xor(r, 16, 64);
-    r += __shfl_xor(r, 32, 64);
-    return r;
-}
-
+#ifndef BWD_WAVES_PER_SIMD
+#define BWD_WAVES_PER_SIMD 3
+#endif
 template <int ABL>      // timing experiments only (0 = product): 1 no texture atomics, 2 no stage-C reduce, 8 no tap loads
-__global__ void __launch_bounds__(TG_BLOCK)
+__global__ void __launch_bounds__(TG_BLOCK, BWD_WAVES_PER_SIMD)
 k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
              float* __restrict__ acc, float* __restrict__ dtex) {
-    __shared__ float4 s_items_all[4][BQ_CAP];                 // 16 KB
-    __shared__ float s_grad_all[4][64 * TEXGS_ACC_FLOATS];    // 24 KB
-    __shared__ uint2 s_stage_all[4][64 * 12];                 // 24 KB
+    __shared__ float4 s_items_all[4][BQ_CAP * 3];             // 3 float4 per item: {T, araw, q, key} {dc, du0} {du1, du2, inv, dden}
+    __shared__ uint2 s_stage_all[4][64 * 6];                  // 12 KB
     __shared__ float s_dpix[TG_BLOCK * 3];                    // 3 KB
-    __shared__ uint32_t s_id_all[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = tile_of_block(blockIdx.x, a.num_tiles);
     if (tile >= a.num_tiles) return;
@@ -330,9 +275,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     const int HW = a.W * a.H, pix = py * a.W + px;
     const float* __restrict__ tex = a.texture;
     float4* s_items = s_items_all[wave];
-    float* s_grad = s_grad_all[wave];
     uint2* s_stage = s_stage_all[wave];
-    uint32_t* s_id = s_id_all[wave];
 
     float Tfin = 1.f; int last = 0;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
@@ -345,8 +288,6 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
     s_dpix[tid * 3 + 0] = dpix[0]; s_dpix[tid * 3 + 1] = dpix[1]; s_dpix[tid * 3 + 2] = dpix[2];
-#pragma unroll
-    for (int k = 0; k < TEXGS_ACC_FLOATS; ++k) s_grad[k * 64 + lane] = 0.f;
     const int wave_last = min(wave_max_i(last), todo);
     __builtin_amdgcn_wave_barrier();
 
@@ -359,13 +300,12 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
         const int jtop = min(64, wave_last - base);           // instances [0, jtop) of this chunk matter
         // ---- lane l <- instance l of the chunk
         uint32_t id = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r5 = r0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2v = r0, r3v = r0, r4v = r0, r5 = r0;
         if (lane < jtop) {
             id = a.point_list[range.x + base + lane];
             const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            r0 = r[0]; r1 = r[1]; r5 = r[5];
+            r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5];
         }
-        s_id[lane] = id;
         uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
         int j = jtop - 1;
         while (j >= 0) {
@@ -393,7 +333,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     T = T / (1.0f - alpha);
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    s_items[n_items + rank] = make_float4(T, araw, 0.f, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
+                    s_items[(n_items + rank) * 3] = make_float4(T, araw, 0.f, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
                 }
                 n_items += nb;
             }
@@ -406,15 +346,22 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 uint32_t toff[12]; float tval[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) { toff[k] = 0u; tval[k] = 0.f; }
+                float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
+                if (have) it = s_items[e * 3];
+                const uint32_t key = __float_as_uint(it.w);
+                const int pl = (int)(key >> 8) & 63, jj = (int)(key & 63u);
+                // the instance's record lives in lane jj's registers: cross-lane fetch through the LDS crossbar
+#define BP(V) __int_as_float(__builtin_amdgcn_ds_bpermute(jj << 2, __float_as_int(V)))
+                float4 q0, q1, r2, r3, r4;
+                q0.x = BP(r0.x); q0.y = BP(r0.y); q1.z = BP(r1.z); q1.w = BP(r1.w);
+                r2.x = BP(r2v.x); r2.y = BP(r2v.y); r2.z = BP(r2v.z); r2.w = BP(r2v.w);
+                r3.x = BP(r3v.x); r3.y = BP(r3v.y); r3.z = BP(r3v.z); r3.w = BP(r3v.w);
+                r4.x = BP(r4v.x); r4.y = BP(r4v.y); r4.z = BP(r4v.z); r4.w = BP(r4v.w);
+#undef BP
                 if (have) {
-                    const float4 it = s_items[e];
-                    const uint32_t key = __float_as_uint(it.w);
-                    const int pl = (int)(key >> 8), jj = (int)(key & 63u);
                     const float alpha = fminf(TG_ALPHA_MAX, it.y);
                     const float w = alpha * it.x;
                     const float ipx = (float)(wave_px + (pl & 7)), ipy = (float)(wave_py + (pl >> 3));
-                    const float4* __restrict__ rr = a.rec + (size_t)s_id[jj] * (TEXGS_REC_FLOATS / 4);
-                    const float4 q0 = rr[0], q1 = rr[1], r2 = rr[2], r3 = rr[3], r4 = rr[4];
                     const float dpx = ipx - q0.x, dpy = ipy - q0.y;
                     const float den = 1.0f + q1.z * dpx + q1.w * dpy;
                     const bool good = den >= TG_DEN_MIN;
@@ -435,7 +382,6 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + r4.z + 0.5f;
                     const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + r4.w + 0.5f;
                     const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
-                    s_items[e].z = qv;
                     // colour -> view-dependent term and texture
                     const float dc0 = (pre0 > 0.f) ? w * d0 : 0.f, dc1 = (pre1 > 0.f) ? w * d1 : 0.f, dc2 = (pre2 > 0.f) ? w * d2 : 0.f;
                     const float x0 = TG_SH_C0 * dc0, x1 = TG_SH_C0 * dc1, x2 = TG_SH_C0 * dc2;
@@ -455,38 +401,32 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     if (ct.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
                     else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
                     else                   { du2 = dum; du0 = dua; du1 = dub; }
-                    float* gr = s_grad + jj;                         // s_grad[k * 64 + j]
-#define GADD(K, V) do { const float v_ = (V); if (v_ != 0.f) __hip_atomic_fetch_add(gr + (K) * 64, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
-                    GADD(R_VD, dc0); GADD(R_VD + 1, dc1); GADD(R_VD + 2, dc2);
-                    GADD(R_PHI, du0); GADD(R_PHI + 1, du1); GADD(R_PHI + 2, du2);
-                    if (good) {
-                        const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
-                        const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;
-                        GADD(R_GM + 0, dn0 * dpx); GADD(R_GM + 1, dn0 * dpy);
-                        GADD(R_GM + 2, dn1 * dpx); GADD(R_GM + 3, dn1 * dpy);
-                        GADD(R_GM + 4, dn2 * dpx); GADD(R_GM + 5, dn2 * dpy);
-                        GADD(R_G2, dden * dpx); GADD(R_G2 + 1, dden * dpy);
-                        GADD(R_XY, -((r2.x * dn0 + r2.z * dn1 + r3.x * dn2) + q1.z * dden));
-                        GADD(R_XY + 1, -((r2.y * dn0 + r2.w * dn1 + r3.y * dn2) + q1.w * dden));
-                    }
-#undef GADD
+                    const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;   // inv = 0 when !good
+                    s_items[e * 3].z = qv;
+                    s_items[e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
+                    s_items[e * 3 + 2] = make_float4(du1, du2, inv, dden);
                 }
                 if (!(ABL & 1)) {
-                    // transpose (pair, k) -> lanes so that adjacent lanes carry adjacent dwords of a tap row
+                    // transpose (pair, k) -> lanes so that adjacent lanes carry adjacent dwords of a tap row (6 dwords:
+                    // two x-adjacent texels); one row of taps per half
+                    const int nent = min(64, n_items - r) * 6;
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) s_stage[lane * 12 + k] = make_uint2(toff[k], __float_as_uint(tval[k]));
-                    __builtin_amdgcn_wave_barrier();
-                    const int nent = min(64, n_items - r) * 12;
+                    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                    for (int it2 = 0; it2 < 12; ++it2) {
-                        const int ee = it2 * 64 + lane;
-                        if (ee < nent) {
-                            const uint2 sv = s_stage[ee];
-                            const float v = __uint_as_float(sv.y);
-                            if (v != 0.f) unsafeAtomicAdd(dtex + sv.x, v);
+                        for (int k = 0; k < 6; ++k)
+                            s_stage[lane * 6 + k] = make_uint2(toff[half * 6 + k], __float_as_uint(tval[half * 6 + k]));
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int it2 = 0; it2 < 6; ++it2) {
+                            const int ee = it2 * 64 + lane;
+                            if (ee < nent) {
+                                const uint2 sv = s_stage[ee];
+                                const float v = __uint_as_float(sv.y);
+                                if (v != 0.f) unsafeAtomicAdd(dtex + sv.x, v);
+                            }
                         }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -498,64 +438,55 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 const unsigned long long bal = ((unsigned long long)bhi << 32) | blo;
                 if (bal == 0ull) continue;
                 const bool ok = (bal >> lane) & 1ull;
-                float part[16];
+                float part[32];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) part[k] = 0.f;
+                for (int k = 0; k < 32; ++k) part[k] = 0.f;
+#define RL(V) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), jj))
                 if (ok) {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
-                    const float4 it = s_items[it0 + rank];
-                    const float Ti = it.x, araw = it.y, qv = it.z;
+                    const float4 i0 = s_items[(it0 + rank) * 3], i1 = s_items[(it0 + rank) * 3 + 1], i2 = s_items[(it0 + rank) * 3 + 2];
+                    const float Ti = i0.x, araw = i0.y, qv = i0.z;
                     const float alpha = fminf(TG_ALPHA_MAX, araw);
-                    const float gx_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.x), jj));
-                    const float gy_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.y), jj));
-                    const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.z), jj));
-                    const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.w), jj));
-                    const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), jj));
-                    const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), jj));
-                    const float dep = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.x), jj));
-                    const float n0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.y), jj));
-                    const float n1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.z), jj));
-                    const float n2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5.w), jj));
+                    const float gx_ = RL(r0.x), gy_ = RL(r0.y), ca = RL(r0.z), cb = RL(r0.w), cc = RL(r1.x), op = RL(r1.y);
+                    const float dep = RL(r5.x), n0 = RL(r5.y), n1 = RL(r5.z), n2 = RL(r5.w);
                     const float dx = gx_ - pxf, dy = gy_ - pyf;
                     const float w = alpha * Ti;
                     const float s_i = qv + dep * dpix[3] + n0 * dpix[4] + n1 * dpix[5] + n2 * dpix[6] + dpix[7];
                     suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
                     last_s = s_i; last_alpha = alpha;
-                    float dL_dalpha_ = (s_i - suffix) * Ti + (-Tfin / (1.0f - alpha)) * bgdot;
+                    const float dL_dalpha_ = (s_i - suffix) * Ti + (-Tfin / (1.0f - alpha)) * bgdot;
                     const float dL_dpower = araw * dL_dalpha_;        // straight through the 0.99 clamp (lineage)
                     const float gdx = -(ca * dx + cb * dy), gdy = -(cc * dy + cb * dx);
-                    part[0] = dL_dpower * gdx;
-                    part[1] = dL_dpower * gdy;
-                    part[2] = -0.5f * dx * dx * dL_dpower;
-                    part[3] = -dx * dy * dL_dpower;
-                    part[4] = -0.5f * dy * dy * dL_dpower;
-                    part[5] = (araw / op) * dL_dalpha_;
-                    part[6] = w * dpix[3];
-                    part[7] = w * dpix[4]; part[8] = w * dpix[5]; part[9] = w * dpix[6];
+                    // uv path (stage B results): dn = du * inv, dp = pix - xy
+                    const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
+                    const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
+                    const float dpx = -dx, dpy = -dy;
+                    const float ggx = RL(r1.z), ggy = RL(r1.w);
+                    const float G00 = RL(r2v.x), G01 = RL(r2v.y), G10 = RL(r2v.z), G11 = RL(r2v.w), G20 = RL(r3v.x), G21 = RL(r3v.y);
+                    part[R_XY]        = dL_dpower * gdx - ((G00 * dn0 + G10 * dn1 + G20 * dn2) + ggx * dden);
+                    part[R_XY + 1]    = dL_dpower * gdy - ((G01 * dn0 + G11 * dn1 + G21 * dn2) + ggy * dden);
+                    part[R_CONIC]     = -0.5f * dx * dx * dL_dpower;
+                    part[R_CONIC + 1] = -dx * dy * dL_dpower;
+                    part[R_CONIC + 2] = -0.5f * dy * dy * dL_dpower;
+                    part[R_OP]        = (araw / op) * dL_dalpha_;
+                    part[R_G2] = dden * dpx; part[R_G2 + 1] = dden * dpy;
+                    part[R_GM + 0] = dn0 * dpx; part[R_GM + 1] = dn0 * dpy;
+                    part[R_GM + 2] = dn1 * dpx; part[R_GM + 3] = dn1 * dpy;
+                    part[R_GM + 4] = dn2 * dpx; part[R_GM + 5] = dn2 * dpy;
+                    part[R_PHI] = du0; part[R_PHI + 1] = du1; part[R_PHI + 2] = du2;
+                    part[R_VD] = i1.x; part[R_VD + 1] = i1.y; part[R_VD + 2] = i1.z;
+                    part[R_DEPTH] = w * dpix[3];
+                    part[R_N] = w * dpix[4]; part[R_N + 1] = w * dpix[5]; part[R_N + 2] = w * dpix[6];
                 }
+#undef RL
                 it0 += __popcll(bal);
-                const float tot = (ABL & 2) ? part[lane & 15] : reduce16_transposed(part, lane);
-                // value k lives in lane k: 0,1 xy | 2..4 conic | 5 opacity | 6 depth | 7..9 normal
-                if (lane < 10) {
-                    const int slot = (lane < 6) ? lane : (lane == 6 ? R_DEPTH : (R_N + lane - 7));
-                    if (tot != 0.f) __hip_atomic_fetch_add(s_grad + slot * 64 + jj, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                const float tot = (ABL & 2) ? part[lane & 31] : reduce_transposed<32>(part, lane);
+                // accumulator slot k lives in lane k: 24 consecutive dwords of one row -> one coalesced request
+                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)id, jj);
+                if (lane < TEXGS_ACC_FLOATS && tot != 0.f) unsafeAtomicAdd(acc + (size_t)idj * TEXGS_ACC_FLOATS + lane, tot);
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- chunk end: flush the rows this wave touched (row = 24 consecutive floats of acc)
-        {
-            const bool touched = (touched_lo | touched_hi) != 0u;      // lane j: instance j touched by this wave
-            const unsigned long long tb = __ballot(touched);
-            for (int k = 0; k < TEXGS_ACC_FLOATS; ++k) {
-                // lane j handles its own instance, slot k  (transposed layout s_grad[k][j] -> conflict-free LDS)
-                const float v = s_grad[k * 64 + lane];
-                s_grad[k * 64 + lane] = 0.f;
-                if (touched && v != 0.f) unsafeAtomicAdd(acc + (size_t)id * TEXGS_ACC_FLOATS + k, v);
-            }
-            (void)tb;
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

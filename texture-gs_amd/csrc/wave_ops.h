@@ -1,0 +1,96 @@
+// Wave64 cross-lane primitives for gfx950 built on DPP and the CDNA4 permlane swaps (no LDS crossbar traffic).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DPP_QUAD_XOR1   0xB1     // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2   0x4E     // quad_perm [2,3,0,1]
+#define DPP_ROW_HMIRROR 0x141
+#define DPP_ROW_MIRROR  0x140
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// value of lane (l ^ 4): row_shl:4 feeds lanes 0-3/8-11 of each row, row_shr:4 feeds lanes 4-7/12-15
+__device__ __forceinline__ float lane_xor4(float v) {
+    const int x = __float_as_int(v);
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);
+    return __int_as_float(t);
+}
+// value of lane (l ^ 8)
+__device__ __forceinline__ float lane_xor8(float v) {
+    const int x = __float_as_int(v);
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);
+    t = __builtin_amdgcn_update_dpp(t, x, 0x118, 0xF, 0xC, false);
+    return __int_as_float(t);
+}
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] in every lane
+__device__ __forceinline__ float sum_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+// Sum over the 64 lanes of a wave; result in every lane.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HMIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    v = sum_xor16(v);
+    return sum_xor32(v);
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// Transposing butterfly over NV (= 16 or 32) per-lane values: on return every lane l holds the sum over the 64 lanes
+// of v[l & (NV-1)].  Each halving step keeps one of a pair and sends the other to the partner lane, so the live
+// value count halves per step: 3*NV/2 + ... VALU instead of NV full reductions.
+template <int NV>
+__device__ __forceinline__ float reduce_transposed(float (&v)[NV], int lane) {
+    static_assert(NV == 16 || NV == 32, "NV");
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8, b4 = lane & 16;
+    float a[NV / 2];
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        a[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+    }
+    float b[NV / 4];
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) {
+        const float keep = b1 ? a[2 * i + 1] : a[2 * i], send = b1 ? a[2 * i] : a[2 * i + 1];
+        b[i] = keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    }
+    float c[NV / 8];
+#pragma unroll
+    for (int i = 0; i < NV / 8; ++i) {
+        const float keep = b2 ? b[2 * i + 1] : b[2 * i], send = b2 ? b[2 * i] : b[2 * i + 1];
+        c[i] = keep + lane_xor4(send);
+    }
+    float d[NV / 16];
+#pragma unroll
+    for (int i = 0; i < NV / 16; ++i) {
+        const float keep = b3 ? c[2 * i + 1] : c[2 * i], send = b3 ? c[2 * i] : c[2 * i + 1];
+        d[i] = keep + lane_xor8(send);
+    }
+    float r;
+    if (NV == 32) {
+        const float keep = b4 ? d[NV / 16 - 1] : d[0], send = b4 ? d[0] : d[NV / 16 - 1];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_int(send), __float_as_int(send), false, false);
+        // lane l needs send[l ^ 16]: rows 0,2 take it from sw[1] (= odd rows), rows 1,3 from sw[0] (= even rows)
+        r = keep + (b4 ? __int_as_float(sw[0]) : __int_as_float(sw[1]));
+    } else {
+        r = sum_xor16(d[0]);
+    }
+    return sum_xor32(r);
+}
