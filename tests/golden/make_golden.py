@@ -1,0 +1,108 @@
+"""Generate tests/golden/*.npz.  Runs ONLY in the build container (needs /root/reference); the fixtures (arrays,
+no source) travel to the GPU box, the reference does not.
+
+  cameras.npz  utils/graphics.py getWorld2View2 / getProjectionMatrix composed exactly as utils/cameras.py:62-65
+               (without the .cuda() calls) -> world_view_transform, full_proj_transform, camera_center
+  sh.npz       utils/sh.py eval_sh, degrees 0..3, random coefficients and unit directions
+  cube.npz     models/modules/NVDIFFREC/util.py cube_to_dir for all six faces on a texel-centre grid
+               (the module imports nvdiffrast and imageio at top level, absent here; throw-away empty module objects are
+               registered under those names for the import only -- cube_to_dir itself is pure torch)
+  losses.npz   losses/pixelwise_loss.py l1_loss and losses/ssim_loss.py ssim_loss on small random images
+  op_small.npz the operator itself on a tiny seeded scene, as computed by oracle/texgs_torch.py in float64
+               (regression pin of the oracle; the reference holds no vector for the operator: parity unpinned)
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path[:0] = [ROOT, os.path.join(ROOT, "texture-gs_amd"), os.path.join(ROOT, "tests")]
+
+
+def cameras():
+    sys.path.insert(0, REF)
+    from utils.graphics import getWorld2View2, getProjectionMatrix
+    rng = np.random.RandomState(0)
+    out = {}
+    for i in range(4):
+        # random rotation (QR) and translation; (R, T) as utils/cameras.py:22-26 takes them
+        q, _ = np.linalg.qr(rng.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        T = rng.randn(3) * 2.0
+        fovx, fovy = 0.4 + 0.3 * i, 0.5 + 0.2 * i
+        wvt = torch.tensor(getWorld2View2(q, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+        proj = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+        full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+        center = wvt.inverse()[3, :3]
+        out[f"R{i}"] = q; out[f"T{i}"] = T; out[f"fov{i}"] = np.array([fovx, fovy])
+        out[f"wvt{i}"] = wvt.numpy(); out[f"proj{i}"] = proj.numpy(); out[f"full{i}"] = full.numpy()
+        out[f"center{i}"] = center.numpy()
+    np.savez(os.path.join(HERE, "cameras.npz"), **out)
+
+
+def sh():
+    sys.path.insert(0, REF)
+    from utils.sh import eval_sh, C0
+    g = torch.Generator().manual_seed(3)
+    dirs = torch.randn(64, 3, generator=g, dtype=torch.float64)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    coef = torch.randn(64, 3, 16, generator=g, dtype=torch.float64)      # [..., C, (deg+1)^2]
+    out = {"dirs": dirs.numpy(), "coef": coef.numpy(), "C0": np.array(C0)}
+    for deg in range(4):
+        out[f"deg{deg}"] = eval_sh(deg, coef, dirs).numpy()
+    np.savez(os.path.join(HERE, "sh.npz"), **out)
+
+
+def cube():
+    sys.path.insert(0, REF)
+    for name in ("nvdiffrast", "nvdiffrast.torch", "imageio"):   # import-only placeholders, see module docstring
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nvdiffrec_util", os.path.join(REF, "models/modules/NVDIFFREC/util.py"))
+    util = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(util)
+    Rr = 8
+    c = (torch.arange(Rr, dtype=torch.float64) + 0.5) / Rr * 2.0 - 1.0     # texel centres in [-1,1]
+    gy, gx = torch.meshgrid(c, c, indexing="ij")
+    dirs = torch.stack([util.cube_to_dir(s, gx, gy) for s in range(6)], 0)   # [6,R,R,3]; x <-> column, y <-> row
+    np.savez(os.path.join(HERE, "cube.npz"), dirs=dirs.numpy(), R=np.array(Rr))
+
+
+def losses():
+    sys.path.insert(0, REF)
+    from losses.pixelwise_loss import l1_loss
+    from losses.ssim_loss import ssim_loss
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(3, 24, 20, generator=g)
+    b = torch.rand(3, 24, 20, generator=g)
+    np.savez(os.path.join(HERE, "losses.npz"), a=a.numpy(), b=b.numpy(), l1=float(l1_loss(a, b)),
+             ssim=float(ssim_loss(a, b)))
+
+
+def op_small():
+    from texgs import synth
+    import helpers as Hh
+    scene = synth.make_scene(200, 16, seed=11, scale_mean=0.06)
+    cam = synth.fibonacci_cameras(4, 64, 48)[1]
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    target, nhat = synth.make_targets(48, 64, seed=2)
+    ref, dbg, grads = Hh.oracle_run(scene, cam, 2, bg, with_grad=True, target=target, nhat=nhat, depth_weight=0.05)
+    out = dict(image=ref[0].detach().numpy(), depth=ref[1].detach().numpy(), norm=ref[2].detach().numpy(),
+               alpha=ref[3].detach().numpy(), radii=ref[4].numpy(), n_contrib=dbg["n_contrib"].numpy(),
+               ambiguity=dbg["ambiguity"].numpy(), point_list=dbg["binning"]["point_list"].numpy(),
+               ranges=dbg["binning"]["ranges"].numpy(), tiles=dbg["pre"]["tiles"].numpy())
+    for k, v in grads.items():
+        out["grad_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "op_small.npz"), **out)
+
+
+if __name__ == "__main__":
+    cameras(); sh(); cube(); losses(); op_small()
+    print("golden fixtures written to", HERE)

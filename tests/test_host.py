@@ -1,0 +1,119 @@
+"""-m "not gpu": host logic -- drop-in module surface, argument validation, loud failure without a GPU, frame
+sharding and the flat gradient bucket under a 2-rank gloo group (the N>1 path of bench.py on CPU)."""
+import inspect
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_drop_in_module_surface():
+    import diff_gauss_uv_tex as m
+    fields = m.GaussianRasterizationSettings._fields
+    # keyword order at render/uv_tex_render.py:25-38
+    assert fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                      "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    sig = inspect.signature(m.GaussianRasterizer.forward)
+    for kw in ["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "gradient_uvs", "texture",
+               "extra_attrs"]:                                  # kwargs at render/uv_tex_render.py:56-66
+        assert kw in sig.parameters, kw
+    assert "raster_settings" in inspect.signature(m.GaussianRasterizer.__init__).parameters
+
+
+def _settings(m, dev="cpu"):
+    return m.GaussianRasterizationSettings(
+        image_height=32, image_width=32, tanfovx=0.4, tanfovy=0.4, bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+        viewmatrix=torch.eye(4, device=dev), projmatrix=torch.eye(4, device=dev), sh_degree=0,
+        campos=torch.zeros(3, device=dev), prefiltered=False, debug=False)
+
+
+def test_product_path_fails_loudly_without_gpu(lib_built):
+    """No CPU fallback: CPU tensors must raise, never route through the oracle."""
+    import diff_gauss_uv_tex as m
+    N = 4
+    r = m.GaussianRasterizer(raster_settings=_settings(m))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(means3D=torch.zeros(N, 3), means2D=torch.zeros(N, 3), shs=None, opacities=torch.ones(N, 1),
+          scales=torch.ones(N, 3), rotations=torch.ones(N, 4), uvs=torch.ones(N, 3), gradient_uvs=torch.zeros(N, 9),
+          texture=torch.zeros(6, 4, 4, 3), extra_attrs=None)
+
+
+def test_product_path_does_not_import_oracle():
+    import subprocess
+    code = ("import sys; sys.path[:0]=[%r, %r]; import diff_gauss_uv_tex, texgs.rasterizer, texgs.multiview; "
+            "assert not any(k == 'oracle' or k.startswith('oracle.') for k in sys.modules), 'oracle imported'"
+            % (ROOT, os.path.join(ROOT, "texture-gs_amd")))
+    subprocess.check_call([sys.executable, "-c", code])
+    import re
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include\s*[\"<][^\">]*oracle)", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "texture-gs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{f} pulls in oracle/"
+
+
+def test_argument_validation():
+    import diff_gauss_uv_tex as m
+    r = m.GaussianRasterizer(raster_settings=_settings(m))
+    with pytest.raises(ValueError):
+        r(means3D=torch.zeros(3, 3), means2D=None, opacities=torch.ones(3, 1), uvs=torch.ones(3, 3),
+          gradient_uvs=torch.zeros(3, 9), texture=torch.zeros(6, 4, 4, 3))            # scales / rotations missing
+    with pytest.raises(NotImplementedError):
+        r(means3D=torch.zeros(3, 3), means2D=None, opacities=torch.ones(3, 1), scales=torch.ones(3, 3),
+          rotations=torch.ones(3, 4), uvs=torch.ones(3, 3), gradient_uvs=torch.zeros(3, 9),
+          texture=torch.zeros(6, 4, 4, 3), extra_attrs=torch.zeros(3, 2))
+
+
+def test_shard_views_partition():
+    from texgs.multiview import shard_views
+    for V, W in [(64, 8), (10, 4), (7, 7)]:
+        seen = sorted(v for r in range(W) for v in shard_views(V, r, W))
+        assert seen == list(range(V))
+    with pytest.raises(ValueError):
+        shard_views(2, 3, 4)
+
+
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "texture-gs_amd")]
+    from texgs.multiview import GradBucket, shard_views
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = [torch.randn(5, 3, requires_grad=True), torch.randn(6, 2, 2, 3, requires_grad=True)]
+    bucket = GradBucket(params)
+    bucket.zero()
+    total = 0.0
+    for v in shard_views(6, rank, world):               # each view adds a view-dependent gradient
+        loss = sum(((p * (v + 1)) ** 2).sum() for p in params)
+        loss.backward()                                  # accumulates in place into the flat bucket
+    flat = bucket.all_reduce(dist, average_over=6).clone()
+    q.put((rank, flat))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_two_ranks_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    params = [torch.randn(5, 3, requires_grad=True), torch.randn(6, 2, 2, 3, requires_grad=True)]
+    ref = torch.zeros(sum(p.numel() for p in params))
+    off = 0
+    for p in params:
+        g = sum(2 * p.detach() * (v + 1) ** 2 for v in range(6)) / 6.0
+        ref[off:off + p.numel()] = g.reshape(-1)
+        off += p.numel()
+    assert torch.allclose(res[0], ref, atol=1e-5) and torch.allclose(res[1], ref, atol=1e-5)

@@ -138,3 +138,23 @@ def test_two_forwards_before_backward(lib_built):
     (2.0 * run(0)[0].mean()).backward()
     g_b = tex.grad.clone()
     assert Hh.rel_err(g_both.cpu(), (g_a + g_b).cpu()) < 1e-4
+
+
+def test_matches_committed_golden_fixture(lib_built):
+    """tests/golden/op_small.npz (float64 oracle outputs + gradients, committed) against the HIP operator."""
+    import os
+    import numpy as np
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "op_small.npz"))
+    scene = synth.make_scene(200, 16, seed=11, scale_mean=0.06)
+    cam = synth.fibonacci_cameras(4, 64, 48)[1]
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    target, nhat = synth.make_targets(48, 64, seed=2)
+    out, g = Hh.hip_run(scene, cam, 2, bg, with_grad=True, target=target, nhat=nhat, depth_weight=0.05)
+    amb = torch.tensor(d["ambiguity"]) < 1e-4
+    for k, name in enumerate(["image", "depth", "norm", "alpha"]):
+        err = (out[k].detach().cpu().double() - torch.tensor(d[name])).abs()[:, ~amb]
+        assert float(err.max()) < (4e-4 if name == "depth" else 1e-4), (name, float(err.max()))
+    assert np.array_equal(out[4].cpu().numpy(), d["radii"])
+    for name in ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture", "means2D"]:
+        ok, msg = Hh.grad_close(g[name], torch.tensor(d["grad_" + name]))
+        assert ok, (name, msg)
