@@ -44,7 +44,6 @@ def parse():
     ap.add_argument("--views-per-step", type=int, default=8)
     ap.add_argument("--num-views", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles sampled by the CPU baseline (0 = auto)")
     return ap.parse_args()
 
 
@@ -204,7 +203,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from texgs_cpu_baseline import cpu_baseline   # bench-only helper at repo root; uses oracle/ as the checker's port
-        cpu = cpu_baseline(scene, cams[my_views[0]], W, H, with_bwd, args.cpu_tiles)
+        cpu = cpu_baseline(scene, cams[my_views[0]], W, H, with_bwd)
 
     if rank == 0:
         line = {

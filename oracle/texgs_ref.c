@@ -1,0 +1,588 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- plain-C (fp32) restatement of the textured Gaussian rasterizer operator.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; never the product path.
+ *
+ * PARITY UNPINNED: the reference's arithmetic for this path lives in the un-vendored, un-pinned pip dependency
+ * `diff_gauss_uv_tex` (reference requirements.txt:15); /root/reference holds no source, test or golden vector for
+ * it.  This file restates the published algorithm (3DGS tile rasterizer lineage, reference README.md:170;
+ * Texture-GS paper arXiv 2403.10050) on the reference's own call-site contract and in-tree conventions:
+ *   operator arguments           render/uv_tex_render.py:25-38,56-66
+ *   row-vector matrices          utils/cameras.py:62-65, utils/graphics.py:22-29,51-71
+ *   pixel<->ndc, depth = view z  models/texture_gaussian3d.py:299-309
+ *   quaternion, cov = RS(RS)^T   utils/general.py:87-119, models/gaussian3d.py:17-21
+ *   SH constants / signs         utils/sh.py:26-112; colour clamp render/render.py:68
+ *   texel = SH-DC                models/texture_gaussian3d.py:16-21
+ *   cubemap faces                models/modules/NVDIFFREC/util.py:94-101
+ * It is validated (tests/test_c_oracle.py, CPU) against oracle/texgs_torch.py: forward to fp32 rounding, and its
+ * hand-written backward against torch autograd of the float64 restatement.
+ *
+ * Role: (1) bit-exact contract for the integer stages -- built with -ffp-contract=off and written in the same fp32
+ * operation order as the HIP preprocess kernel, so radii, tile rects, tiles_touched, offsets, 64-bit keys, the
+ * sorted point list and the tile ranges must be IDENTICAL to the GPU's; (2) full-size parity (BASELINE configs at
+ * 800x800 / 300k) in seconds; (3) bench.py's CPU baseline ("port", OpenMP over Gaussians / tiles).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TILE 16
+#define NEAR_Z 0.2f
+#define LOWPASS 0.3f
+#define FRUSTUM_CLAMP 1.3f
+#define ALPHA_MAX 0.99f
+#define ALPHA_MIN (1.0f / 255.0f)
+#define T_EPS 1e-4f
+#define PLANE_EPS 5e-2f
+#define DEN_MIN 0.2f
+#define MA_MIN 1e-20f
+#define SH_C0 0.28209479177387814f
+#define REC 24
+
+typedef struct {
+    int H, W, N, K, R, sh_degree;
+    float tanfovx, tanfovy, scale_modifier;
+    const float *bg, *V, *P, *cam;               /* host pointers: bg[3], viewmatrix[16], projmatrix[16], campos[3] */
+    const float *means, *shs, *opac, *scales, *rots, *uvs, *juv, *tex;
+} RefIn;
+
+typedef struct {           /* per-Gaussian forward intermediates (same fields as the HIP kernel's) */
+    int valid;
+    float m[3], t[3], hx, hy, hw, pw, xy[2], q[4], s[3], R[9], M[9], S[6], txc, tyc;
+    int clx, cly;
+    float J00, J02, J11, J12, T0[3], T1[3], a, b, c, det, inv, conic[3];
+    int radius, kmin;
+    float sign, n[3], nv[3], sdot;
+    int degen;
+    float gx, gy, G[6], Km[9], dir[3], dlen;
+} Geo;
+
+#define WR(V, r, c) ((V)[(c) * 4 + (r)])
+
+static int sh_active(int deg, int K) { int w = (deg + 1) * (deg + 1) - 1; return w < K ? w : K; }
+
+static void sh_basis(int deg, float x, float y, float z, float *b) {
+    const float C1 = 0.4886025119029199f;
+    b[0] = -C1 * y; b[1] = C1 * z; b[2] = -C1 * x;
+    if (deg > 1) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[3] = 1.0925484305920792f * xy; b[4] = -1.0925484305920792f * yz;
+        b[5] = 0.31539156525252005f * (2.0f * zz - xx - yy); b[6] = -1.0925484305920792f * xz;
+        b[7] = 0.5462742152960396f * (xx - yy);
+        if (deg > 2) {
+            b[8] = -0.5900435899266435f * y * (3.0f * xx - yy); b[9] = 2.890611442640554f * xy * z;
+            b[10] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+            b[11] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            b[12] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+            b[13] = 1.445305721320277f * z * (xx - yy); b[14] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+        }
+    }
+}
+
+static void sh_basis_grad(int deg, float x, float y, float z, float *bx, float *by, float *bz) {
+    const float C1 = 0.4886025119029199f;
+    bx[0] = 0; by[0] = -C1; bz[0] = 0; bx[1] = 0; by[1] = 0; bz[1] = C1; bx[2] = -C1; by[2] = 0; bz[2] = 0;
+    if (deg > 1) {
+        const float c20 = 1.0925484305920792f, c22 = 0.31539156525252005f, c24 = 0.5462742152960396f;
+        bx[3] = c20 * y; by[3] = c20 * x; bz[3] = 0;
+        bx[4] = 0; by[4] = -c20 * z; bz[4] = -c20 * y;
+        bx[5] = c22 * (-2.0f * x); by[5] = c22 * (-2.0f * y); bz[5] = c22 * 4.0f * z;
+        bx[6] = -c20 * z; by[6] = 0; bz[6] = -c20 * x;
+        bx[7] = c24 * 2.0f * x; by[7] = -c24 * 2.0f * y; bz[7] = 0;
+        if (deg > 2) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f,
+                        c33 = 0.3731763325901154f, c35 = 1.445305721320277f;
+            bx[8] = c30 * 6.0f * x * y; by[8] = c30 * (3.0f * xx - 3.0f * yy); bz[8] = 0;
+            bx[9] = c31 * y * z; by[9] = c31 * x * z; bz[9] = c31 * x * y;
+            bx[10] = c32 * (-2.0f * x * y); by[10] = c32 * (4.0f * zz - xx - 3.0f * yy); bz[10] = c32 * 8.0f * y * z;
+            bx[11] = c33 * (-6.0f * x * z); by[11] = c33 * (-6.0f * y * z); bz[11] = c33 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+            bx[12] = c32 * (4.0f * zz - 3.0f * xx - yy); by[12] = c32 * (-2.0f * x * y); bz[12] = c32 * 8.0f * x * z;
+            bx[13] = c35 * 2.0f * x * z; by[13] = -c35 * 2.0f * y * z; bz[13] = c35 * (xx - yy);
+            bx[14] = c30 * (3.0f * xx - 3.0f * yy); by[14] = c30 * (-6.0f * x * y); bz[14] = 0;
+        }
+    }
+}
+
+/* Same fp32 operation order as geo_forward() in the HIP preprocess kernel (bit-exact contract). */
+static void geo_forward(Geo *g, const RefIn *in, int i) {
+    const float *V = in->V, *P = in->P;
+    const int W = in->W, H = in->H;
+    const float fx = (float)W / (2.0f * in->tanfovx), fy = (float)H / (2.0f * in->tanfovy);
+    g->m[0] = in->means[3 * i]; g->m[1] = in->means[3 * i + 1]; g->m[2] = in->means[3 * i + 2];
+    const float mx = g->m[0], my = g->m[1], mz = g->m[2];
+    g->t[0] = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+    g->t[1] = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+    g->t[2] = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+    g->valid = g->t[2] > NEAR_Z;
+    g->radius = 0;
+    if (!g->valid) return;
+    const float tx = g->t[0], ty = g->t[1], tz = g->t[2];
+    g->hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
+    g->hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
+    g->hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
+    g->pw = 1.0f / (g->hw + 1e-7f);
+    const float ndcx = g->hx * g->pw, ndcy = g->hy * g->pw;
+    g->xy[0] = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+    g->xy[1] = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+    for (int k = 0; k < 4; ++k) g->q[k] = in->rots[4 * i + k];
+    const float r = g->q[0], x = g->q[1], y = g->q[2], z = g->q[3];
+    g->R[0] = 1.0f - 2.0f * (y * y + z * z); g->R[1] = 2.0f * (x * y - r * z); g->R[2] = 2.0f * (x * z + r * y);
+    g->R[3] = 2.0f * (x * y + r * z); g->R[4] = 1.0f - 2.0f * (x * x + z * z); g->R[5] = 2.0f * (y * z - r * x);
+    g->R[6] = 2.0f * (x * z - r * y); g->R[7] = 2.0f * (y * z + r * x); g->R[8] = 1.0f - 2.0f * (x * x + y * y);
+    const float s0 = in->scales[3 * i], s1 = in->scales[3 * i + 1], s2 = in->scales[3 * i + 2];
+    g->s[0] = in->scale_modifier * s0; g->s[1] = in->scale_modifier * s1; g->s[2] = in->scale_modifier * s2;
+    for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) g->M[rr * 3 + cc] = g->R[rr * 3 + cc] * g->s[cc];
+    const float *M = g->M;
+    g->S[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    g->S[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    g->S[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    g->S[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    g->S[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    g->S[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    const float limx = FRUSTUM_CLAMP * in->tanfovx, limy = FRUSTUM_CLAMP * in->tanfovy;
+    const float txtz = tx / tz, tytz = ty / tz;
+    g->clx = (txtz < -limx) || (txtz > limx);
+    g->cly = (tytz < -limy) || (tytz > limy);
+    g->txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    g->tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    if (!g->clx) g->txc = tx;
+    if (!g->cly) g->tyc = ty;
+    const float tz2 = tz * tz;
+    g->J00 = fx / tz; g->J02 = -(fx * g->txc) / tz2;
+    g->J11 = fy / tz; g->J12 = -(fy * g->tyc) / tz2;
+    for (int k = 0; k < 3; ++k) {
+        g->T0[k] = g->J00 * WR(V, 0, k) + g->J02 * WR(V, 2, k);
+        g->T1[k] = g->J11 * WR(V, 1, k) + g->J12 * WR(V, 2, k);
+    }
+    const float *S = g->S;
+    const float v00 = S[0] * g->T0[0] + S[1] * g->T0[1] + S[2] * g->T0[2];
+    const float v01 = S[1] * g->T0[0] + S[3] * g->T0[1] + S[4] * g->T0[2];
+    const float v02 = S[2] * g->T0[0] + S[4] * g->T0[1] + S[5] * g->T0[2];
+    const float v10 = S[0] * g->T1[0] + S[1] * g->T1[1] + S[2] * g->T1[2];
+    const float v11 = S[1] * g->T1[0] + S[3] * g->T1[1] + S[4] * g->T1[2];
+    const float v12 = S[2] * g->T1[0] + S[4] * g->T1[1] + S[5] * g->T1[2];
+    g->a = (g->T0[0] * v00 + g->T0[1] * v01 + g->T0[2] * v02) + LOWPASS;
+    g->b = g->T1[0] * v00 + g->T1[1] * v01 + g->T1[2] * v02;
+    g->c = (g->T1[0] * v10 + g->T1[1] * v11 + g->T1[2] * v12) + LOWPASS;
+    g->det = g->a * g->c - g->b * g->b;
+    if (g->det == 0.0f) { g->valid = 0; return; }
+    g->inv = 1.0f / g->det;
+    g->conic[0] = g->c * g->inv; g->conic[1] = -g->b * g->inv; g->conic[2] = g->a * g->inv;
+    const float mid = 0.5f * (g->a + g->c);
+    const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - g->det));
+    g->radius = (int)ceilf(3.0f * sqrtf(lam));
+    g->kmin = 0; float smin = s0;
+    if (s1 < smin) { smin = s1; g->kmin = 1; }
+    if (s2 < smin) { smin = s2; g->kmin = 2; }
+    g->dir[0] = mx - in->cam[0]; g->dir[1] = my - in->cam[1]; g->dir[2] = mz - in->cam[2];
+    float n0 = g->R[0 + g->kmin], n1 = g->R[3 + g->kmin], n2 = g->R[6 + g->kmin];
+    g->sign = ((n0 * g->dir[0] + n1 * g->dir[1] + n2 * g->dir[2]) > 0.0f) ? -1.0f : 1.0f;
+    g->n[0] = g->sign * n0; g->n[1] = g->sign * n1; g->n[2] = g->sign * n2;
+    g->dlen = sqrtf(g->dir[0] * g->dir[0] + g->dir[1] * g->dir[1] + g->dir[2] * g->dir[2]);
+    g->dir[0] /= g->dlen; g->dir[1] /= g->dlen; g->dir[2] /= g->dlen;
+    for (int k = 0; k < 3; ++k) g->nv[k] = WR(V, k, 0) * g->n[0] + WR(V, k, 1) * g->n[1] + WR(V, k, 2) * g->n[2];
+    g->sdot = g->nv[0] * tx + g->nv[1] * ty + g->nv[2] * tz;
+    const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
+    g->degen = fabsf(g->sdot) <= PLANE_EPS * tn;
+    const float *juv = in->juv;
+    for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc)
+        g->Km[rr * 3 + cc] = juv[9 * i + rr * 3 + 0] * WR(V, cc, 0) + juv[9 * i + rr * 3 + 1] * WR(V, cc, 1)
+                           + juv[9 * i + rr * 3 + 2] * WR(V, cc, 2);
+    if (g->degen) {
+        g->gx = 0; g->gy = 0; for (int k = 0; k < 6; ++k) g->G[k] = 0;
+    } else {
+        const float ax = tz * g->nv[0] / g->sdot, ay = tz * g->nv[1] / g->sdot;
+        g->gx = ax / fx; g->gy = ay / fy;
+        const float B00 = tz / fx - tx * g->gx, B01 = -tx * g->gy;
+        const float B10 = -ty * g->gx, B11 = tz / fy - ty * g->gy;
+        const float B20 = -tz * g->gx, B21 = -tz * g->gy;
+        for (int rr = 0; rr < 3; ++rr) {
+            g->G[rr * 2 + 0] = g->Km[rr * 3 + 0] * B00 + g->Km[rr * 3 + 1] * B10 + g->Km[rr * 3 + 2] * B20;
+            g->G[rr * 2 + 1] = g->Km[rr * 3 + 0] * B01 + g->Km[rr * 3 + 1] * B11 + g->Km[rr * 3 + 2] * B21;
+        }
+    }
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+static void tile_rect(const Geo *g, int gxn, int gyn, int *x0, int *y0, int *x1, int *y1) {
+    const float rf = (float)g->radius;
+    *x0 = imin(gxn, imax(0, (int)((g->xy[0] - rf) / (float)TILE)));
+    *y0 = imin(gyn, imax(0, (int)((g->xy[1] - rf) / (float)TILE)));
+    *x1 = imin(gxn, imax(0, (int)((g->xy[0] + rf + (float)(TILE - 1)) / (float)TILE)));
+    *y1 = imin(gyn, imax(0, (int)((g->xy[1] + rf + (float)(TILE - 1)) / (float)TILE)));
+}
+
+/* K1+K2: rec[N,24], depth[N], radii[N], rect[N,4], tiles[N], offsets[N]; returns D */
+uint32_t texgs_ref_preprocess(const RefIn *in, float *rec, float *depth, int32_t *radii, int32_t *rect,
+                              uint32_t *tiles, uint32_t *offsets) {
+    const int N = in->N, gxn = (in->W + TILE - 1) / TILE, gyn = (in->H + TILE - 1) / TILE;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        Geo g;
+        geo_forward(&g, in, i);
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        if (g.valid) { tile_rect(&g, gxn, gyn, &x0, &y0, &x1, &y1); if ((x1 - x0) * (y1 - y0) == 0) g.valid = 0; }
+        float *r = rec + (size_t)i * REC;
+        if (!g.valid) {
+            radii[i] = 0; tiles[i] = 0; depth[i] = 0; rect[4 * i] = rect[4 * i + 1] = rect[4 * i + 2] = rect[4 * i + 3] = 0;
+            memset(r, 0, sizeof(float) * REC);
+            continue;
+        }
+        float vd[3] = {0, 0, 0};
+        const int na = (in->shs && in->sh_degree > 0) ? sh_active(in->sh_degree, in->K) : 0;
+        if (na > 0) {
+            float b[15];
+            sh_basis(in->sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
+            const float *sp = in->shs + (size_t)i * in->K * 3;
+            for (int k = 0; k < na; ++k) { vd[0] += b[k] * sp[3 * k]; vd[1] += b[k] * sp[3 * k + 1]; vd[2] += b[k] * sp[3 * k + 2]; }
+        }
+        radii[i] = g.radius; tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0)); depth[i] = g.t[2];
+        rect[4 * i] = x0; rect[4 * i + 1] = y0; rect[4 * i + 2] = x1; rect[4 * i + 3] = y1;
+        r[0] = g.xy[0]; r[1] = g.xy[1]; r[2] = g.conic[0]; r[3] = g.conic[1]; r[4] = g.conic[2]; r[5] = in->opac[i];
+        r[6] = g.gx; r[7] = g.gy; for (int k = 0; k < 6; ++k) r[8 + k] = g.G[k];
+        r[14] = in->uvs[3 * i]; r[15] = in->uvs[3 * i + 1]; r[16] = in->uvs[3 * i + 2];
+        r[17] = vd[0]; r[18] = vd[1]; r[19] = vd[2]; r[20] = g.t[2]; r[21] = g.n[0]; r[22] = g.n[1]; r[23] = g.n[2];
+    }
+    uint32_t run = 0;
+    for (int i = 0; i < N; ++i) { run += tiles[i]; offsets[i] = run; }
+    return run;
+}
+
+/* K3-K5: keys (tile<<32 | depth bits), stable LSD radix sort (8-bit digits), ranges[T,2] */
+void texgs_ref_bin(const RefIn *in, uint32_t D, const float *depth, const int32_t *rect, const uint32_t *tiles,
+                   const uint32_t *offsets, uint64_t *keys_unsorted, uint32_t *vals_unsorted, uint64_t *keys_sorted,
+                   uint32_t *point_list, uint32_t *ranges) {
+    const int N = in->N, gxn = (in->W + TILE - 1) / TILE, gyn = (in->H + TILE - 1) / TILE;
+    const int T = gxn * gyn;
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T);
+    if (D == 0) return;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        if (tiles[i] == 0) continue;
+        uint32_t off = offsets[i] - tiles[i];
+        uint32_t db; memcpy(&db, &depth[i], 4);
+        for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
+            for (int x = rect[4 * i]; x < rect[4 * i + 2]; ++x) {
+                keys_unsorted[off] = ((uint64_t)(uint32_t)(y * gxn + x) << 32) | db;
+                vals_unsorted[off] = (uint32_t)i; ++off;
+            }
+    }
+    int bits = 0; while ((1u << bits) < (uint32_t)T && bits < 31) ++bits; if (bits == 0) bits = 1;
+    const int end_bit = 32 + bits;
+    uint64_t *ka = (uint64_t *)malloc(sizeof(uint64_t) * D), *kb = (uint64_t *)malloc(sizeof(uint64_t) * D);
+    uint32_t *va = (uint32_t *)malloc(sizeof(uint32_t) * D), *vb = (uint32_t *)malloc(sizeof(uint32_t) * D);
+    memcpy(ka, keys_unsorted, sizeof(uint64_t) * D); memcpy(va, vals_unsorted, sizeof(uint32_t) * D);
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        size_t cnt[257]; memset(cnt, 0, sizeof(cnt));
+        const int nb = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const uint64_t mask = (1ull << nb) - 1ull;
+        for (uint32_t i = 0; i < D; ++i) cnt[((ka[i] >> shift) & mask) + 1]++;
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (uint32_t i = 0; i < D; ++i) { size_t p = cnt[(ka[i] >> shift) & mask]++; kb[p] = ka[i]; vb[p] = va[i]; }
+        uint64_t *tk = ka; ka = kb; kb = tk; uint32_t *tv = va; va = vb; vb = tv;
+    }
+    memcpy(keys_sorted, ka, sizeof(uint64_t) * D); memcpy(point_list, va, sizeof(uint32_t) * D);
+    free(ka); free(kb); free(va); free(vb);
+    for (uint32_t i = 0; i < D; ++i) {
+        const uint32_t cur = (uint32_t)(keys_sorted[i] >> 32);
+        if (i == 0) ranges[2 * cur] = 0;
+        else { const uint32_t prev = (uint32_t)(keys_sorted[i - 1] >> 32); if (cur != prev) { ranges[2 * prev + 1] = i; ranges[2 * cur] = i; } }
+        if (i == D - 1) ranges[2 * cur + 1] = D;
+    }
+}
+
+typedef struct { int o00, o01, o10, o11, axis; float fx, fy, sc, tc, h, rma, sm, su, sv; } Tap;
+
+static Tap cube_address(float u0, float u1, float u2, int R) {
+    Tap t; float m, ua, ub;
+    const float a0 = fabsf(u0), a1 = fabsf(u1), a2 = fabsf(u2);
+    if (a0 >= a1 && a0 >= a2) { t.axis = 0; m = u0; t.sm = (u0 >= 0.f) ? 1.f : -1.f; ua = u2; t.su = -t.sm; ub = u1; t.sv = -1.f; }
+    else if (a1 >= a2)        { t.axis = 1; m = u1; t.sm = (u1 >= 0.f) ? 1.f : -1.f; ua = u0; t.su = 1.f;   ub = u2; t.sv = t.sm; }
+    else                      { t.axis = 2; m = u2; t.sm = (u2 >= 0.f) ? 1.f : -1.f; ua = u0; t.su = t.sm;  ub = u1; t.sv = -1.f; }
+    const int face = 2 * t.axis + (t.sm > 0.f ? 0 : 1);
+    const float ma = fmaxf(fabsf(m), MA_MIN);
+    t.rma = 1.0f / ma; t.sc = t.su * ua; t.tc = t.sv * ub;
+    const float halfR = 0.5f * (float)R;
+    t.h = halfR * t.rma;
+    const float col = (t.sc * t.rma + 1.0f) * halfR - 0.5f, row = (t.tc * t.rma + 1.0f) * halfR - 0.5f;
+    const float x0f = floorf(col), y0f = floorf(row);
+    t.fx = col - x0f; t.fy = row - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x0c = imin(imax(x0, 0), R - 1), x1c = imin(imax(x0 + 1, 0), R - 1);
+    const int y0c = imin(imax(y0, 0), R - 1), y1c = imin(imax(y0 + 1, 0), R - 1);
+    const int fb = face * R;
+    t.o00 = ((fb + y0c) * R + x0c) * 3; t.o01 = ((fb + y0c) * R + x1c) * 3;
+    t.o10 = ((fb + y1c) * R + x0c) * 3; t.o11 = ((fb + y1c) * R + x1c) * 3;
+    return t;
+}
+
+/* K6: outputs out[8,H,W] (r,g,b,depth,nx,ny,nz,alpha), final_T[H,W], n_contrib[H,W] */
+void texgs_ref_render_fwd(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                          float *out, float *final_T, uint32_t *n_contrib) {
+    const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE, HW = W * H;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gxn * gyn; ++tile) {
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const int tx0 = (tile % gxn) * TILE, ty0 = (tile / gxn) * TILE;
+        for (int ly = 0; ly < TILE; ++ly) for (int lx = 0; lx < TILE; ++lx) {
+            const int px = tx0 + lx, py = ty0 + ly;
+            if (px >= W || py >= H) continue;
+            const float pxf = (float)px, pyf = (float)py;
+            float T = 1.0f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t last = 0;
+            for (uint32_t k = r0; k < r1; ++k) {
+                const float *r = rec + (size_t)point_list[k] * REC;
+                const float dx = r[0] - pxf, dy = r[1] - pyf;
+                const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = fminf(ALPHA_MAX, r[5] * expf(power));
+                if (alpha < ALPHA_MIN) continue;
+                const float Tn = T * (1.0f - alpha);
+                if (Tn < T_EPS) break;
+                const float dpx = -dx, dpy = -dy;
+                const float den = 1.0f + r[6] * dpx + r[7] * dpy;
+                const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
+                const float u0 = r[14] + (r[8] * dpx + r[9] * dpy) * inv;
+                const float u1 = r[15] + (r[10] * dpx + r[11] * dpy) * inv;
+                const float u2 = r[16] + (r[12] * dpx + r[13] * dpy) * inv;
+                const Tap ct = cube_address(u0, u1, u2, in->R);
+                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+                const float w10 = (1.f - ct.fx) * ct.fy, w11 = ct.fx * ct.fy;
+                const float w = alpha * T;
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float tv = w00 * in->tex[ct.o00 + ch] + w01 * in->tex[ct.o01 + ch] + w10 * in->tex[ct.o10 + ch]
+                                   + w11 * in->tex[ct.o11 + ch];
+                    A[ch] += w * fmaxf(0.f, SH_C0 * tv + r[17 + ch] + 0.5f);
+                }
+                A[3] += w * r[20]; A[4] += w * r[21]; A[5] += w * r[22]; A[6] += w * r[23]; A[7] += w;
+                T = Tn; last = k - r0 + 1;
+            }
+            const int pix = py * W + px;
+            out[pix] = A[0] + T * in->bg[0]; out[HW + pix] = A[1] + T * in->bg[1]; out[2 * HW + pix] = A[2] + T * in->bg[2];
+            for (int ch = 3; ch < 8; ++ch) out[ch * HW + pix] = A[ch];
+            final_T[pix] = T; n_contrib[pix] = last;
+        }
+    }
+}
+
+static void atomic_addf(float *p, float v) {
+#pragma omp atomic
+    *p += v;
+}
+static void atomic_addd(double *p, double v) {
+#pragma omp atomic
+    *p += v;
+}
+
+/* K7: dout[8,H,W] upstream grads; acc[N,24] (double, zero-filled by caller), dtex (float, zero-filled) */
+void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                          const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex) {
+    const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE, HW = W * H;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gxn * gyn; ++tile) {
+        const uint32_t r0 = ranges[2 * tile];
+        const int tx0 = (tile % gxn) * TILE, ty0 = (tile / gxn) * TILE;
+        for (int ly = 0; ly < TILE; ++ly) for (int lx = 0; lx < TILE; ++lx) {
+            const int px = tx0 + lx, py = ty0 + ly;
+            if (px >= W || py >= H) continue;
+            const int pix = py * W + px;
+            const float pxf = (float)px, pyf = (float)py;
+            const float Tfin = final_T[pix];
+            const int last = (int)n_contrib[pix];
+            float dpix[8];
+            for (int ch = 0; ch < 8; ++ch) dpix[ch] = dout[ch * HW + pix];
+            const float bgdot = in->bg[0] * dpix[0] + in->bg[1] * dpix[1] + in->bg[2] * dpix[2];
+            float T = Tfin, accum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_alpha = 0, last_f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int pos = last - 1; pos >= 0; --pos) {
+                const uint32_t id = point_list[r0 + pos];
+                const float *r = rec + (size_t)id * REC;
+                const float dx = r[0] - pxf, dy = r[1] - pyf;
+                const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
+                if (power > 0.0f) continue;
+                const float Gs = expf(power), araw = r[5] * Gs, alpha = fminf(ALPHA_MAX, araw);
+                if (alpha < ALPHA_MIN) continue;
+                T = T / (1.0f - alpha);
+                const float w = alpha * T;
+                const float dpx = -dx, dpy = -dy;
+                const float den = 1.0f + r[6] * dpx + r[7] * dpy;
+                const int good = den >= DEN_MIN;
+                const float inv = good ? 1.0f / den : 0.0f;
+                const float nu0 = r[8] * dpx + r[9] * dpy, nu1 = r[10] * dpx + r[11] * dpy, nu2 = r[12] * dpx + r[13] * dpy;
+                const float u0 = r[14] + nu0 * inv, u1 = r[15] + nu1 * inv, u2 = r[16] + nu2 * inv;
+                const Tap ct = cube_address(u0, u1, u2, in->R);
+                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+                const float w10 = (1.f - ct.fx) * ct.fy, w11 = ct.fx * ct.fy;
+                float f[8], pre[3], t00[3], t01[3], t10[3], t11[3];
+                for (int ch = 0; ch < 3; ++ch) {
+                    t00[ch] = in->tex[ct.o00 + ch]; t01[ch] = in->tex[ct.o01 + ch];
+                    t10[ch] = in->tex[ct.o10 + ch]; t11[ch] = in->tex[ct.o11 + ch];
+                    pre[ch] = SH_C0 * (w00 * t00[ch] + w01 * t01[ch] + w10 * t10[ch] + w11 * t11[ch]) + r[17 + ch] + 0.5f;
+                    f[ch] = fmaxf(0.f, pre[ch]);
+                }
+                f[3] = r[20]; f[4] = r[21]; f[5] = r[22]; f[6] = r[23]; f[7] = 1.0f;
+                float dLda = 0.f;
+                for (int ch = 0; ch < 8; ++ch) {
+                    accum[ch] = last_alpha * last_f[ch] + (1.f - last_alpha) * accum[ch];
+                    last_f[ch] = f[ch];
+                    dLda += (f[ch] - accum[ch]) * dpix[ch];
+                }
+                last_alpha = alpha;
+                dLda *= T;
+                dLda += (-Tfin / (1.0f - alpha)) * bgdot;
+                const float dLdp = araw * dLda;
+                const float gdx = -(r[2] * dx + r[3] * dy), gdy = -(r[4] * dy + r[3] * dx);
+                float part[REC];
+                memset(part, 0, sizeof(part));
+                part[0] = dLdp * gdx; part[1] = dLdp * gdy;
+                part[2] = -0.5f * dx * dx * dLdp; part[3] = -dx * dy * dLdp; part[4] = -0.5f * dy * dy * dLdp;
+                part[5] = Gs * dLda;
+                part[20] = w * dpix[3]; part[21] = w * dpix[4]; part[22] = w * dpix[5]; part[23] = w * dpix[6];
+                float dtexv[3], dLdcol = 0.f, dLdrow = 0.f;
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float dc = (pre[ch] > 0.f) ? w * dpix[ch] : 0.f;
+                    part[17 + ch] = dc; dtexv[ch] = SH_C0 * dc;
+                    if (dtexv[ch] != 0.f) {
+                        atomic_addf(dtex + ct.o00 + ch, w00 * dtexv[ch]); atomic_addf(dtex + ct.o01 + ch, w01 * dtexv[ch]);
+                        atomic_addf(dtex + ct.o10 + ch, w10 * dtexv[ch]); atomic_addf(dtex + ct.o11 + ch, w11 * dtexv[ch]);
+                    }
+                    dLdcol += dtexv[ch] * ((1.f - ct.fy) * (t01[ch] - t00[ch]) + ct.fy * (t11[ch] - t10[ch]));
+                    dLdrow += dtexv[ch] * ((1.f - ct.fx) * (t10[ch] - t00[ch]) + ct.fx * (t11[ch] - t01[ch]));
+                }
+                const float dua = dLdcol * ct.su * ct.h, dub = dLdrow * ct.sv * ct.h;
+                const float dum = -(dLdcol * ct.sc + dLdrow * ct.tc) * ct.h * ct.rma * ct.sm;
+                float du0, du1, du2;
+                if (ct.axis == 0) { du0 = dum; du2 = dua; du1 = dub; }
+                else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
+                else { du2 = dum; du0 = dua; du1 = dub; }
+                part[14] = du0; part[15] = du1; part[16] = du2;
+                if (good) {
+                    const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
+                    const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;
+                    part[8] = dn0 * dpx; part[9] = dn0 * dpy; part[10] = dn1 * dpx; part[11] = dn1 * dpy;
+                    part[12] = dn2 * dpx; part[13] = dn2 * dpy; part[6] = dden * dpx; part[7] = dden * dpy;
+                    part[0] -= (r[8] * dn0 + r[10] * dn1 + r[12] * dn2) + r[6] * dden;
+                    part[1] -= (r[9] * dn0 + r[11] * dn1 + r[13] * dn2) + r[7] * dden;
+                }
+                double *ap = acc + (size_t)id * REC;
+                for (int k = 0; k < REC; ++k) if (part[k] != 0.f) atomic_addd(ap + k, (double)part[k]);
+            }
+        }
+    }
+}
+
+/* K8: acc[N,24] -> input gradients */
+void texgs_ref_preprocess_bwd(const RefIn *in, const int32_t *radii, const double *acc, float *d_means, float *d_means2D,
+                              float *d_shs, float *d_op, float *d_scales, float *d_rots, float *d_uvs) {
+    const int N = in->N, K = in->K;
+    const float fx = (float)in->W / (2.0f * in->tanfovx), fy = (float)in->H / (2.0f * in->tanfovy);
+    const float *V = in->V, *P = in->P;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        for (int k = 0; k < 3; ++k) { d_means[3 * i + k] = 0; d_means2D[3 * i + k] = 0; d_scales[3 * i + k] = 0; d_uvs[3 * i + k] = 0; }
+        for (int k = 0; k < 4; ++k) d_rots[4 * i + k] = 0;
+        d_op[i] = 0;
+        if (d_shs) for (int k = 0; k < 3 * K; ++k) d_shs[(size_t)i * 3 * K + k] = 0;
+        if (radii[i] <= 0) continue;
+        Geo g; geo_forward(&g, in, i);
+        float A[REC]; for (int k = 0; k < REC; ++k) A[k] = (float)acc[(size_t)i * REC + k];
+        const float tx = g.t[0], ty = g.t[1], tz = g.t[2];
+        float dt[3] = {0, 0, 0}, dm[3] = {0, 0, 0}, dR[9]; for (int k = 0; k < 9; ++k) dR[k] = 0;
+        d_op[i] = A[5]; d_uvs[3 * i] = A[14]; d_uvs[3 * i + 1] = A[15]; d_uvs[3 * i + 2] = A[16];
+        const float dA = A[2], dB = A[3], dC = A[4], inv = g.inv, inv2 = inv * inv;
+        const float da = dA * (-g.c * g.c * inv2) + dB * (g.b * g.c * inv2) + dC * (inv - g.a * g.c * inv2);
+        const float db = dA * (2.0f * g.b * g.c * inv2) + dB * (-inv - 2.0f * g.b * g.b * inv2) + dC * (2.0f * g.a * g.b * inv2);
+        const float dc = dA * (inv - g.a * g.c * inv2) + dB * (g.a * g.b * inv2) + dC * (-g.a * g.a * inv2);
+        const float hb = 0.5f * db; const float *S = g.S;
+        float TS0[3], TS1[3], dT0[3], dT1[3];
+        TS0[0] = g.T0[0] * S[0] + g.T0[1] * S[1] + g.T0[2] * S[2]; TS0[1] = g.T0[0] * S[1] + g.T0[1] * S[3] + g.T0[2] * S[4];
+        TS0[2] = g.T0[0] * S[2] + g.T0[1] * S[4] + g.T0[2] * S[5];
+        TS1[0] = g.T1[0] * S[0] + g.T1[1] * S[1] + g.T1[2] * S[2]; TS1[1] = g.T1[0] * S[1] + g.T1[1] * S[3] + g.T1[2] * S[4];
+        TS1[2] = g.T1[0] * S[2] + g.T1[1] * S[4] + g.T1[2] * S[5];
+        for (int k = 0; k < 3; ++k) { dT0[k] = 2.0f * (da * TS0[k] + hb * TS1[k]); dT1[k] = 2.0f * (hb * TS0[k] + dc * TS1[k]); }
+        float dS[9], dM[9], dscale[3];
+        for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l)
+            dS[k * 3 + l] = g.T0[k] * g.T0[l] * da + (g.T0[k] * g.T1[l] + g.T1[k] * g.T0[l]) * hb + g.T1[k] * g.T1[l] * dc;
+        for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc)
+            dM[rr * 3 + cc] = 2.0f * (dS[rr * 3] * g.M[cc] + dS[rr * 3 + 1] * g.M[3 + cc] + dS[rr * 3 + 2] * g.M[6 + cc]);
+        for (int cc = 0; cc < 3; ++cc) {
+            dscale[cc] = (dM[cc] * g.R[cc] + dM[3 + cc] * g.R[3 + cc] + dM[6 + cc] * g.R[6 + cc]) * in->scale_modifier;
+            for (int rr = 0; rr < 3; ++rr) dR[rr * 3 + cc] += dM[rr * 3 + cc] * g.s[cc];
+        }
+        const float dJ00 = dT0[0] * WR(V, 0, 0) + dT0[1] * WR(V, 0, 1) + dT0[2] * WR(V, 0, 2);
+        const float dJ02 = dT0[0] * WR(V, 2, 0) + dT0[1] * WR(V, 2, 1) + dT0[2] * WR(V, 2, 2);
+        const float dJ11 = dT1[0] * WR(V, 1, 0) + dT1[1] * WR(V, 1, 1) + dT1[2] * WR(V, 1, 2);
+        const float dJ12 = dT1[0] * WR(V, 2, 0) + dT1[1] * WR(V, 2, 1) + dT1[2] * WR(V, 2, 2);
+        const float tz2 = tz * tz, tz3 = tz2 * tz;
+        dt[2] += -dJ00 * fx / tz2 - dJ11 * fy / tz2 + 2.0f * dJ02 * fx * g.txc / tz3 + 2.0f * dJ12 * fy * g.tyc / tz3;
+        if (!g.clx) dt[0] += -dJ02 * fx / tz2;
+        if (!g.cly) dt[1] += -dJ12 * fy / tz2;
+        const float dndx = A[0] * 0.5f * (float)in->W, dndy = A[1] * 0.5f * (float)in->H;
+        d_means2D[3 * i] = dndx; d_means2D[3 * i + 1] = dndy;
+        {
+            const float dhx = dndx * g.pw, dhy = dndy * g.pw, dhw = -(dndx * g.hx + dndy * g.hy) * g.pw * g.pw;
+            for (int k = 0; k < 3; ++k) dm[k] += dhx * P[k * 4] + dhy * P[k * 4 + 1] + dhw * P[k * 4 + 3];
+        }
+        dt[2] += A[20];
+        float dn[3] = {A[21], A[22], A[23]};
+        if (!g.degen) {
+            const float *dG = &A[8]; float dBm[6];
+            for (int k = 0; k < 3; ++k) for (int cc = 0; cc < 2; ++cc)
+                dBm[k * 2 + cc] = g.Km[k] * dG[cc] + g.Km[3 + k] * dG[2 + cc] + g.Km[6 + k] * dG[4 + cc];
+            float dtz = dBm[0] / fx + dBm[3] / fy, dgt[2];
+            for (int cc = 0; cc < 2; ++cc) dgt[cc] = A[6 + cc] - (dBm[cc] * tx + dBm[2 + cc] * ty + dBm[4 + cc] * tz);
+            for (int k = 0; k < 3; ++k) dt[k] -= dBm[k * 2] * g.gx + dBm[k * 2 + 1] * g.gy;
+            const float dax = dgt[0] / fx, day = dgt[1] / fy, dot_a_nv = dax * g.nv[0] + day * g.nv[1];
+            dtz += dot_a_nv / g.sdot;
+            float dnv[3] = {tz * dax / g.sdot, tz * day / g.sdot, 0.f};
+            const float ds = -tz * dot_a_nv / (g.sdot * g.sdot);
+            dnv[0] += ds * tx; dnv[1] += ds * ty; dnv[2] += ds * tz;
+            dt[0] += ds * g.nv[0]; dt[1] += ds * g.nv[1]; dt[2] += ds * g.nv[2] + dtz;
+            for (int k = 0; k < 3; ++k) dn[k] += dnv[0] * WR(V, 0, k) + dnv[1] * WR(V, 1, k) + dnv[2] * WR(V, 2, k);
+        }
+        dR[g.kmin] += g.sign * dn[0]; dR[3 + g.kmin] += g.sign * dn[1]; dR[6 + g.kmin] += g.sign * dn[2];
+        const int na = (in->shs && in->sh_degree > 0) ? sh_active(in->sh_degree, K) : 0;
+        if (d_shs && na > 0) {
+            float b[15], bx[15], by[15], bz[15];
+            sh_basis(in->sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
+            sh_basis_grad(in->sh_degree, g.dir[0], g.dir[1], g.dir[2], bx, by, bz);
+            const float *sp = in->shs + (size_t)i * K * 3; float *dsp = d_shs + (size_t)i * K * 3;
+            const float v0 = A[17], v1 = A[18], v2 = A[19];
+            float ddx = 0, ddy = 0, ddz = 0;
+            for (int k = 0; k < na; ++k) {
+                dsp[3 * k] = b[k] * v0; dsp[3 * k + 1] = b[k] * v1; dsp[3 * k + 2] = b[k] * v2;
+                const float w = sp[3 * k] * v0 + sp[3 * k + 1] * v1 + sp[3 * k + 2] * v2;
+                ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+            }
+            const float dd = g.dir[0] * ddx + g.dir[1] * ddy + g.dir[2] * ddz;
+            dm[0] += (ddx - g.dir[0] * dd) / g.dlen; dm[1] += (ddy - g.dir[1] * dd) / g.dlen; dm[2] += (ddz - g.dir[2] * dd) / g.dlen;
+        }
+        for (int k = 0; k < 3; ++k) dm[k] += dt[0] * V[k * 4] + dt[1] * V[k * 4 + 1] + dt[2] * V[k * 4 + 2];
+        for (int k = 0; k < 3; ++k) { d_means[3 * i + k] = dm[k]; d_scales[3 * i + k] = dscale[k]; }
+        const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
+        d_rots[4 * i] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        d_rots[4 * i + 1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+        d_rots[4 * i + 2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+        d_rots[4 * i + 3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+}
+
+int texgs_ref_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void texgs_ref_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,113 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes wrapper of oracle/libtexgs_ref.so (the plain-C restatement, texgs_ref.c).
+Loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libtexgs_ref.so")
+REC = 24
+
+
+class RefIn(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("N", C.c_int), ("K", C.c_int), ("R", C.c_int), ("sh_degree", C.c_int),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float)] + \
+               [(n, C.c_void_p) for n in ["bg", "V", "P", "cam", "means", "shs", "opac", "scales", "rots", "uvs", "juv", "tex"]]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "texgs_ref.c")):
+            subprocess.check_call(["make", "-s", "-C", HERE])
+        _lib = C.CDLL(LIB)
+        _lib.texgs_ref_preprocess.restype = C.c_uint32
+        _lib.texgs_ref_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(t):
+    return None if t is None else np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+
+
+class RefRun:
+    """One forward (and optionally backward) of the C oracle.  All arrays are numpy, float32 / integer."""
+
+    def __init__(self, scene, st, threads=0):
+        lib = load()
+        if threads:
+            lib.texgs_ref_set_threads(int(threads))
+        self.lib = lib
+        self.N = scene.means3D.shape[0]
+        self.K = 0 if scene.shs is None else scene.shs.shape[1]
+        self.R = scene.texture.shape[1]
+        self.H, self.W = int(st.image_height), int(st.image_width)
+        self.arr = dict(bg=_f32(st.bg), V=_f32(st.viewmatrix), P=_f32(st.projmatrix), cam=_f32(st.campos),
+                        means=_f32(scene.means3D), shs=_f32(scene.shs), opac=_f32(scene.opacities.reshape(-1)),
+                        scales=_f32(scene.scales), rots=_f32(scene.rotations), uvs=_f32(scene.uvs),
+                        juv=_f32(scene.gradient_uvs), tex=_f32(scene.texture))
+        a = self.arr
+        self.inp = RefIn(self.H, self.W, self.N, self.K, self.R, int(st.sh_degree), float(st.tanfovx), float(st.tanfovy),
+                         float(st.scale_modifier), _p(a["bg"]), _p(a["V"]), _p(a["P"]), _p(a["cam"]), _p(a["means"]),
+                         _p(a["shs"]), _p(a["opac"]), _p(a["scales"]), _p(a["rots"]), _p(a["uvs"]), _p(a["juv"]),
+                         _p(a["tex"]))
+        self.T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+
+    def forward(self):
+        N, H, W, T, lib = self.N, self.H, self.W, self.T, self.lib
+        n1 = max(N, 1)
+        self.rec = np.zeros((n1, REC), np.float32)
+        self.depth = np.zeros(n1, np.float32)
+        self.radii = np.zeros(n1, np.int32)
+        self.rect = np.zeros((n1, 4), np.int32)
+        self.tiles = np.zeros(n1, np.uint32)
+        self.offsets = np.zeros(n1, np.uint32)
+        self.D = int(lib.texgs_ref_preprocess(C.byref(self.inp), _p(self.rec), _p(self.depth), _p(self.radii),
+                                              _p(self.rect), _p(self.tiles), _p(self.offsets))) if N else 0
+        d1 = max(self.D, 1)
+        self.keys_unsorted = np.zeros(d1, np.uint64)
+        self.vals_unsorted = np.zeros(d1, np.uint32)
+        self.keys_sorted = np.zeros(d1, np.uint64)
+        self.point_list = np.zeros(d1, np.uint32)
+        self.ranges = np.zeros((T, 2), np.uint32)
+        lib.texgs_ref_bin(C.byref(self.inp), C.c_uint32(self.D), _p(self.depth), _p(self.rect), _p(self.tiles),
+                          _p(self.offsets), _p(self.keys_unsorted), _p(self.vals_unsorted), _p(self.keys_sorted),
+                          _p(self.point_list), _p(self.ranges))
+        self.out = np.zeros((8, H, W), np.float32)
+        self.final_T = np.ones((H, W), np.float32)
+        self.n_contrib = np.zeros((H, W), np.uint32)
+        lib.texgs_ref_render_fwd(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(self.out),
+                                 _p(self.final_T), _p(self.n_contrib))
+        return self.out
+
+    def backward(self, dout):
+        """dout: float32 [8,H,W] (r,g,b,depth,nx,ny,nz,alpha).  Returns dict of input gradients."""
+        N, K, R, lib = self.N, self.K, self.R, self.lib
+        dout = np.ascontiguousarray(dout.astype(np.float32))
+        acc = np.zeros((max(N, 1), REC), np.float64)
+        dtex = np.zeros((6, R, R, 3), np.float32)
+        lib.texgs_ref_render_bwd(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(self.final_T),
+                                 _p(self.n_contrib), _p(dout), _p(acc), _p(dtex))
+        g = dict(means3D=np.zeros((N, 3), np.float32), means2D=np.zeros((N, 3), np.float32),
+                 shs=np.zeros((N, K, 3), np.float32) if K else None, opacities=np.zeros((N, 1), np.float32),
+                 scales=np.zeros((N, 3), np.float32), rotations=np.zeros((N, 4), np.float32),
+                 uvs=np.zeros((N, 3), np.float32), texture=dtex)
+        lib.texgs_ref_preprocess_bwd(C.byref(self.inp), _p(self.radii), _p(acc), _p(g["means3D"]), _p(g["means2D"]),
+                                     _p(g["shs"]), _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["uvs"]))
+        self.acc = acc
+        return g
+
+    @property
+    def threads(self):
+        return int(self.lib.texgs_ref_num_threads())
