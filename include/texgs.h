@@ -81,6 +81,8 @@ typedef struct TexGSBinning {
     uint32_t* vals_unsorted;   /* u32[D]  Gaussian index                                               */
     uint32_t* point_list;      /* u32[D]  Gaussian index, sorted by (tile, depth), stable              */
     uint32_t* ranges;          /* u32[T,2] [first,last) into point_list per tile; caller zero-fills    */
+    uint32_t* tile_order;      /* u32[T] tile ids, longest list first (launch order of the blend kernels) */
+    uint32_t* order_keys;      /* u32[3*T] scratch for the ordering sort                               */
     void*     sort_temp;       /* >= texgs_sort_temp_bytes(D, T)                                       */
     size_t    sort_temp_bytes;
 } TexGSBinning;

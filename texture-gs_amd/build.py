@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _newer([sp] + HEADERS + [os.path.abspath(__file__)], op):
-            cmd = [HIPCC] + COMMON + flags + ["-c", sp, "-o", op]
+            cmd = [HIPCC] + COMMON + flags + os.environ.get("TEXGS_EXTRA_FLAGS", "").split() + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

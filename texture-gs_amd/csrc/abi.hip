@@ -128,16 +128,15 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     if (bin->num_rendered > 0) {
-        if (bin->sort_temp_bytes < sort_temp_bytes(bin->num_rendered, (uint32_t)(c.tiles_x * c.tiles_y)))
-            return fail_msg("sort_temp too small");
+
         { ProfScope p(TEXGS_K_DUPLICATE, s); launch_duplicate(c, geom, bin, s); }
         if (int r = check(frame, s, "duplicate_with_keys")) return r;
         { ProfScope p(TEXGS_K_SORT, s);
           if (int r = launch_sort(c, bin, s)) return fail("radix_sort_pairs", (hipError_t)r); }
         if (int r = check(frame, s, "radix_sort_pairs")) return r;
-        { ProfScope p(TEXGS_K_RANGES, s); launch_ranges(c, bin, s); }
-        if (int r = check(frame, s, "tile_ranges")) return r;
     }
+    { ProfScope p(TEXGS_K_RANGES, s); launch_ranges(c, bin, s); }
+    if (int r = check(frame, s, "tile_ranges")) return r;
     return texgs_render_forward(frame, in, geom, bin, img, stream);
 }
 

@@ -44,6 +44,17 @@ k_ranges(uint32_t D, const uint64_t* __restrict__ keys, uint2* __restrict__ rang
     if (i == D - 1) ranges[cur].y = D;
 }
 
+// Launch order of the blend kernels: longest tile list first (LPT).  key = 0xFFFF - min(len / 4, 0xFFFF).
+__global__ void __launch_bounds__(TG_BLOCK)
+k_order_keys(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+    const uint32_t i = blockIdx.x * TG_BLOCK + threadIdx.x;
+    if (i >= T) return;
+    const uint2 r = ranges[i];
+    const uint32_t len = r.y - r.x;
+    keys[i] = 0xFFFFu - min(len >> 2, 0xFFFFu);
+    ids[i] = i;
+}
+
 inline int key_end_bit(uint32_t T) {
     int bits = 0;
     while ((1u << bits) < T && bits < 31) ++bits;     // ceil(log2 T)
@@ -69,12 +80,21 @@ int launch_scan(const TexGSGeom* g, int N, hipStream_t s) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+static size_t order_temp_bytes(uint32_t T) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, (size_t)T, 0u, 16u, (hipStream_t)0);
+    return bytes < 256 ? 256 : bytes;
+}
+
 size_t sort_temp_bytes(uint32_t D, uint32_t T) {
     size_t bytes = 0;
-    if (D == 0) return 256;
+    if (D == 0) return order_temp_bytes(T);
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)D, 0u,
                                     (unsigned)key_end_bit(T), (hipStream_t)0);
+    const size_t ob = order_temp_bytes(T);
+    if (bytes < ob) bytes = ob;
     return bytes < 256 ? 256 : bytes;
 }
 
@@ -96,8 +116,21 @@ int launch_sort(const CamConst& c, TexGSBinning* b, hipStream_t s) {
 }
 
 void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s) {
-    if (b->num_rendered == 0) return;
-    const int blocks = (int)((b->num_rendered + TG_BLOCK - 1) / TG_BLOCK);
-    hipLaunchKernelGGL(k_ranges, dim3(blocks), dim3(TG_BLOCK), 0, s, b->num_rendered, b->keys_sorted,
-                       reinterpret_cast<uint2*>(b->ranges));
+    const uint32_t T = (uint32_t)(c.tiles_x * c.tiles_y);
+    if (b->num_rendered > 0) {
+        const int blocks = (int)((b->num_rendered + TG_BLOCK - 1) / TG_BLOCK);
+        hipLaunchKernelGGL(k_ranges, dim3(blocks), dim3(TG_BLOCK), 0, s, b->num_rendered, b->keys_sorted,
+                           reinterpret_cast<uint2*>(b->ranges));
+    }
+    // tile launch order (stable: equal lengths keep tile-index order)
+    uint32_t* keys_in = b->order_keys; uint32_t* keys_out = b->order_keys + T;
+    uint32_t* ids_in = b->order_keys + 2 * T;                             // sorted ids land here, then copied back
+    hipLaunchKernelGGL(k_order_keys, dim3((T + TG_BLOCK - 1) / TG_BLOCK), dim3(TG_BLOCK), 0, s, T,
+                       reinterpret_cast<const uint2*>(b->ranges), keys_in, b->tile_order);
+    (void)ids_in;
+    size_t bytes = b->sort_temp_bytes;
+    // in-place on values is not allowed: sort (keys_in, tile_order) -> (keys_out, order_keys scratch) then copy back
+    (void)rocprim::radix_sort_pairs(b->sort_temp, bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)b->tile_order,
+                                    ids_in, (size_t)T, 0u, 16u, s);
+    (void)hipMemcpyAsync(b->tile_order, ids_in, sizeof(uint32_t) * T, hipMemcpyDeviceToDevice, s);
 }

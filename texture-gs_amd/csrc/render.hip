@@ -69,6 +69,7 @@ __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, in
 struct PixArgs {
     int W, H, tiles_x, num_tiles, R;
     const uint2* ranges;
+    const uint32_t* tile_order;
     const uint32_t* point_list;
     const float4* rec;
     const float* texture;
@@ -137,8 +138,8 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     __shared__ float s_col[TG_BLOCK * 3];
     __shared__ int s_alive[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = tile_of_block(blockIdx.x, a.num_tiles);
-    if (tile >= a.num_tiles) return;
+    if ((int)blockIdx.x >= a.num_tiles) return;
+    const int tile = (int)a.tile_order[blockIdx.x];      // longest list first
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int px = tile_x * TEXGS_TILE + ((wave & 1) << 3) + (lane & 7);
     const int py = tile_y * TEXGS_TILE + ((wave >> 1) << 3) + (lane >> 3);
@@ -247,11 +248,20 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //            ONE transposing butterfly (value k ends in lane k, DPP + permlane swaps only) and lanes 0..23 add
 //            24 consecutive dwords of the accumulator row: one coalesced memory-side request.
 #ifndef BQ_CAP
-#define BQ_CAP 192
+#define BQ_CAP 128
 #endif
+// Tile-local texture-gradient cache: direct-mapped, toroidal spatial hash slot = (x mod 64) + 64 * (y mod TC_H), tag =
+// texel offset.  A footprint narrower than 64 x TC_H texels is collision-free wherever it sits; aliasing updates (other
+// face, far side, parallax spread) fall through to the transposed global atomics.  Flushed once per tile, coalesced.
+#define TC_W 64
+#ifndef TC_H
+#define TC_H 32
+#endif
+#define TC_SLOTS (TC_W * TC_H)
+#define TC_EMPTY 0xFFFFFFFFu
 
 #ifndef BWD_WAVES_PER_SIMD
-#define BWD_WAVES_PER_SIMD 3
+#define BWD_WAVES_PER_SIMD 2
 #endif
 template <int ABL>      // timing experiments only (0 = product): 1 no texture atomics, 2 no stage-C reduce, 8 no tap loads
 __global__ void __launch_bounds__(TG_BLOCK, BWD_WAVES_PER_SIMD)
@@ -260,11 +270,13 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
              float* __restrict__ acc, float* __restrict__ dtex) {
     __shared__ float4 s_items_all[4][BQ_CAP * 3];             // 3 float4 per item: {T, araw, q, key} {dc, du0} {du1, du2, inv, dden}
-    __shared__ uint2 s_stage_all[4][64 * 6];                  // 12 KB
+    __shared__ uint2 s_stage_all[4][64 * 7];                  // 14 KB; row stride 7 (56 B): conflict-free ds_write_b64
     __shared__ float s_dpix[TG_BLOCK * 3];                    // 3 KB
+    __shared__ uint32_t s_ttag[TC_SLOTS];                     // 8 KB
+    __shared__ float s_tval[TC_SLOTS * 3];                    // 24 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = tile_of_block(blockIdx.x, a.num_tiles);
-    if (tile >= a.num_tiles) return;
+    if ((int)blockIdx.x >= a.num_tiles) return;
+    const int tile = (int)a.tile_order[blockIdx.x];      // longest list first
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int wave_px = tile_x * TEXGS_TILE + ((wave & 1) << 3), wave_py = tile_y * TEXGS_TILE + ((wave >> 1) << 3);
     const int px = wave_px + (lane & 7), py = wave_py + (lane >> 3);
@@ -288,6 +300,8 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
     s_dpix[tid * 3 + 0] = dpix[0]; s_dpix[tid * 3 + 1] = dpix[1]; s_dpix[tid * 3 + 2] = dpix[2];
+    for (int k = tid; k < TC_SLOTS; k += TG_BLOCK) { s_ttag[k] = TC_EMPTY; s_tval[3 * k] = 0.f; s_tval[3 * k + 1] = 0.f; s_tval[3 * k + 2] = 0.f; }
+    __syncthreads();
     const int wave_last = min(wave_max_i(last), todo);
     __builtin_amdgcn_wave_barrier();
 
@@ -389,6 +403,31 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     toff[6] = ct.o10; toff[7] = ct.o10 + 1; toff[8] = ct.o10 + 2; toff[9] = ct.o11; toff[10] = ct.o11 + 1; toff[11] = ct.o11 + 2;
                     tval[0] = w00 * x0; tval[1] = w00 * x1; tval[2] = w00 * x2; tval[3] = w01 * x0; tval[4] = w01 * x1; tval[5] = w01 * x2;
                     tval[6] = w10 * x0; tval[7] = w10 * x1; tval[8] = w10 * x2; tval[9] = w11 * x0; tval[10] = w11 * x1; tval[11] = w11 * x2;
+                    if (!(ABL & 4)) {
+                        // cache probe per tap: hit -> LDS accumulate and drop the global update.  Tags are read
+                        // first (4 independent ds_read in flight); the CAS runs only on a tap's first touch.
+                        const int tx_[4] = {ct.x0, ct.x1, ct.x0, ct.x1}, ty_[4] = {ct.y0, ct.y0, ct.y1, ct.y1};
+                        int slot_[4]; uint32_t cur_[4];
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            slot_[tp] = (tx_[tp] & (TC_W - 1)) | ((ty_[tp] & (TC_H - 1)) << 6);
+                            cur_[tp] = s_ttag[slot_[tp]];
+                        }
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            const uint32_t tag = toff[tp * 3];
+                            uint32_t old = cur_[tp];
+                            if (old == TC_EMPTY) old = atomicCAS(&s_ttag[slot_[tp]], TC_EMPTY, tag);
+                            if (old == TC_EMPTY || old == tag) {
+#pragma unroll
+                                for (int ch = 0; ch < 3; ++ch) {
+                                    const float v_ = tval[tp * 3 + ch];
+                                    if (v_ != 0.f) __hip_atomic_fetch_add(&s_tval[slot_[tp] * 3 + ch], v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    tval[tp * 3 + ch] = 0.f;
+                                }
+                            }
+                        }
+                    }
                     const float dLdcol = x0 * ((1.f - ct.fy) * (t01.x - t00.x) + ct.fy * (t11.x - t10.x))
                                        + x1 * ((1.f - ct.fy) * (t01.y - t00.y) + ct.fy * (t11.y - t10.y))
                                        + x2 * ((1.f - ct.fy) * (t01.z - t00.z) + ct.fy * (t11.z - t10.z));
@@ -414,13 +453,13 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     for (int half = 0; half < 2; ++half) {
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
-                            s_stage[lane * 6 + k] = make_uint2(toff[half * 6 + k], __float_as_uint(tval[half * 6 + k]));
+                            s_stage[lane * 7 + k] = make_uint2(toff[half * 6 + k], __float_as_uint(tval[half * 6 + k]));
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int it2 = 0; it2 < 6; ++it2) {
                             const int ee = it2 * 64 + lane;
                             if (ee < nent) {
-                                const uint2 sv = s_stage[ee];
+                                const uint2 sv = s_stage[(ee / 6) * 7 + (ee % 6)];
                                 const float v = __uint_as_float(sv.y);
                                 if (v != 0.f) unsafeAtomicAdd(dtex + sv.x, v);
                             }
@@ -488,6 +527,16 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             __builtin_amdgcn_wave_barrier();
         }
     }
+    // flush the texel cache: thread -> dword, consecutive slots are consecutive texels of a row (coalesced atomics)
+    __syncthreads();
+    if (!(ABL & 1)) {
+        for (int k = tid; k < TC_SLOTS * 3; k += TG_BLOCK) {
+            const int slot = k / 3, ch = k - slot * 3;
+            const uint32_t tag = s_ttag[slot];
+            const float v = s_tval[k];
+            if (tag != TC_EMPTY && v != 0.f) unsafeAtomicAdd(dtex + tag + ch, v);
+        }
+    }
 }
 
 inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
@@ -496,6 +545,7 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
     a.W = c.W; a.H = c.H; a.tiles_x = c.tiles_x; a.num_tiles = c.tiles_x * c.tiles_y; a.R = c.R;
     a.ranges = reinterpret_cast<const uint2*>(b->ranges);
     a.point_list = b->point_list;
+    a.tile_order = b->tile_order;
     a.rec = reinterpret_cast<const float4*>(g->rec);
     a.texture = in->texture;
     a.bg = f->bg;
@@ -507,7 +557,7 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
     const PixArgs a = make_pix(c, f, in, g, b);
-    const int grid = ((a.num_tiles + 63) / 64) * 64;
+    const int grid = a.num_tiles;
     static const int fabl = getenv("TEXGS_FWD_ABLATE") ? atoi(getenv("TEXGS_FWD_ABLATE")) : 0;
     if (fabl == 1) { hipLaunchKernelGGL(k_render_fwd<1>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
     if (fabl == 2) { hipLaunchKernelGGL(k_render_fwd<2>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
@@ -518,7 +568,7 @@ void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     const PixArgs a = make_pix(c, f, in, g, b);
-    const int grid = ((a.num_tiles + 63) / 64) * 64;
+    const int grid = a.num_tiles;
     static const int abl = getenv("TEXGS_ABLATE") ? atoi(getenv("TEXGS_ABLATE")) : 0;
 #define LAUNCH_BWD(A) hipLaunchKernelGGL(k_render_bwd<A>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->final_T, img->n_contrib, \
                        gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
@@ -526,6 +576,7 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
         case 1: LAUNCH_BWD(1); break;
         case 2: LAUNCH_BWD(2); break;
         case 3: LAUNCH_BWD(3); break;
+        case 4: LAUNCH_BWD(4); break;
         case 9: LAUNCH_BWD(9); break;
         case 11: LAUNCH_BWD(11); break;
         default: LAUNCH_BWD(0); break;

@@ -33,7 +33,8 @@ class Geom(C.Structure):
 
 class Binning(C.Structure):
     _fields_ = [("num_rendered", C.c_uint32), ("keys_unsorted", _fp), ("keys_sorted", _fp),
-                ("vals_unsorted", _fp), ("point_list", _fp), ("ranges", _fp), ("sort_temp", _fp),
+                ("vals_unsorted", _fp), ("point_list", _fp), ("ranges", _fp), ("tile_order", _fp), ("order_keys", _fp),
+                ("sort_temp", _fp),
                 ("sort_temp_bytes", C.c_size_t)]
 
 

@@ -133,10 +133,12 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         vals_u = torch.empty(max(D, 1), **i32)
         point_list = torch.empty(max(D, 1), **i32)
         ranges = torch.zeros(tiles, 2, **i32)
+        tile_order = torch.empty(tiles, **i32)
+        order_keys = torch.empty(3 * tiles, **i32)
         sort_bytes = lib.texgs_sort_temp_bytes(D, tiles)
         sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
         binning = _lib.Binning(D, _ptr(keys_u), _ptr(keys_s), _ptr(vals_u), _ptr(point_list), _ptr(ranges),
-                               _ptr(sort_temp), sort_bytes)
+                               _ptr(tile_order), _ptr(order_keys), _ptr(sort_temp), sort_bytes)
         out_color = torch.empty(3, H, W, **f32)
         out_depth = torch.empty(1, H, W, **f32)
         out_norm = torch.empty(3, H, W, **f32)
@@ -153,7 +155,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
     s.tensors = dict(keep=keep, rec=rec, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
                      offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s, vals_unsorted=vals_u,
-                     point_list=point_list, ranges=ranges, final_T=final_T, n_contrib=n_contrib,
+                     point_list=point_list, ranges=ranges, tile_order=tile_order, order_keys=order_keys, final_T=final_T, n_contrib=n_contrib,
                      scan_temp=scan_temp, sort_temp=sort_temp,
                      out=(out_color, out_depth, out_norm, out_alpha))
     return (out_color, out_depth, out_norm, out_alpha, radii), s
