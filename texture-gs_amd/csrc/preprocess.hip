@@ -270,6 +270,17 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     r[3] = make_float4(g.G[4], g.G[5], uvs[3 * i + 0], uvs[3 * i + 1]);
     r[4] = make_float4(uvs[3 * i + 2], vd[0], vd[1], vd[2]);
     r[5] = make_float4(g.t[2], g.n[0], g.n[1], g.n[2]);
+    // spare slots, conservative culling aids for the blend kernels (never change a decision, only skip sure misses):
+    //   thr   : alpha >= 1/255  <=>  power >= ln(1/(255*opacity)); lowered by a margin far above fp32 rounding
+    //   rcull : pixel distance beyond which power < thr for every direction (largest eigenvalue of cov2D)
+    {
+        const float op = opac[i];
+        const float thr = (op > 0.0f) ? (-logf(255.0f * op) - 1e-3f) : 1.0f;          // > 0: nothing can pass
+        const float mid = 0.5f * (g.a + g.c);
+        const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - g.det));
+        const float rcull = (thr < 0.0f) ? (sqrtf(-2.0f * thr * lam) * 1.001f + 0.01f) : -1.0f;
+        r[6] = make_float4(rcull, thr, 0.f, 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K8

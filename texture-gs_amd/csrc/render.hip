@@ -77,81 +77,42 @@ struct PixArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ K6
-// Forward blend, decoupled in two interleaved phases per wave:
-//   (sequential) every lane walks the batch for its own pixel: 2D falloff, alpha, transmittance, weight
-//       w = alpha*T, depth / normal / alpha accumulation -- ~25 VALU per test, no global memory;
-//   (dense)      contributing (pixel, Gaussian, w) triples are compacted with ballot + mbcnt into a 128-entry
-//       per-wave LDS ring; whenever 64 are queued all 64 lanes pop one each and do the UV Taylor step, cubemap
-//       addressing and the 12 tap loads with full lane occupancy and 64 fetches in flight, then add w*colour
-//       into the pixel's LDS accumulator.  The colour sum is order-independent, so this equals the in-order blend.
-// Only ~8 of 64 pixels of a wave contribute to a given Gaussian; running the texture path inside the sequential
-// loop ran it at ~12 % lane efficiency and serialised one L2/HBM round trip per Gaussian.
+// Forward blend.  One wave = one 8x8 pixel block; the 4 waves of a tile are independent (no block barrier, no LDS
+// staging of records).  Per chunk of 64 instances lane l keeps instance l's whole 96-byte record in registers.
+//   (sequential) every lane walks the chunk for its own pixel; the tested Gaussian's (xy, conic, opacity) arrive by
+//       v_readlane broadcast -- no LDS traffic or LDS latency in the dependent chain; ~30 VALU per test.  Depth,
+//       normal and alpha accumulate here (w = alpha*T needs no texture).
+//   (dense)      contributing (pixel, j, w) triples are compacted with ballot + mbcnt into a 128-entry per-wave LDS
+//       ring; whenever 64 are queued all 64 lanes pop one each, fetch the item's Gaussian fields from lane j's
+//       registers through the LDS crossbar (ds_bpermute), do the UV Taylor step, cubemap addressing and 4 dwordx3
+//       tap loads with full lane occupancy and 64 fetches in flight, then add w*colour into the pixel's LDS
+//       accumulator.  The colour sum is order-independent, so this equals the in-order blend.
+// (Only ~8 of 64 pixels of a wave contribute to a given Gaussian: with the texture path inside the sequential loop it
+//  ran at ~12 % lane efficiency; with LDS-staged records the LDS was 50 % busy and 22 % of wave time was LDS issue stall.)
 #define FQ_CAP 128
-
-struct FwdItemCtx {
-    int R, tile_px, tile_py;
-    const float* __restrict__ tex;
-};
-
-template <int FABL>
-__device__ __forceinline__ void fwd_drain(const float4 (*s_rec)[TG_BLOCK], const uint2* s_q, float* s_col,
-                                          int qhead, int n, int lane, int wave, const FwdItemCtx& cx) {
-    if (lane < n) {
-        const uint2 e = s_q[(qhead + lane) & (FQ_CAP - 1)];
-        const float w = __uint_as_float(e.x);
-        const int pl = (int)(e.y >> 8), j = (int)(e.y & 255u);
-        const float pxf = (float)(cx.tile_px + ((wave & 1) << 3) + (pl & 7));
-        const float pyf = (float)(cx.tile_py + ((wave >> 1) << 3) + (pl >> 3));
-        const float4 r0 = s_rec[0][j], r1 = s_rec[1][j], r2 = s_rec[2][j], r3 = s_rec[3][j], r4 = s_rec[4][j];
-        const float dpx = pxf - r0.x, dpy = pyf - r0.y;
-        const float den = 1.0f + r1.z * dpx + r1.w * dpy;
-        const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-        const float u0 = r3.z + (r2.x * dpx + r2.y * dpy) * inv;
-        const float u1 = r3.w + (r2.z * dpx + r2.w * dpy) * inv;
-        const float u2 = r4.x + (r3.x * dpx + r3.y * dpy) * inv;
-        const CubeTap ct = cube_address(u0, u1, u2, cx.R);
-        const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
-        const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
-        Texel3 q00, q01, q10, q11;
-        if (FABL == 2) { q00 = {0.1f, 0.2f, 0.3f}; q01 = q00; q10 = q00; q11 = q00; }
-        else { q00 = load_texel(cx.tex, ct.o00); q01 = load_texel(cx.tex, ct.o01);
-               q10 = load_texel(cx.tex, ct.o10); q11 = load_texel(cx.tex, ct.o11); }
-        const float t0 = w00 * q00.x + w01 * q01.x + w10 * q10.x + w11 * q11.x;
-        const float t1 = w00 * q00.y + w01 * q01.y + w10 * q10.y + w11 * q11.y;
-        const float t2 = w00 * q00.z + w01 * q01.z + w10 * q10.z + w11 * q11.z;
-        const float c0 = fmaxf(0.f, TG_SH_C0 * t0 + r4.y + 0.5f);
-        const float c1 = fmaxf(0.f, TG_SH_C0 * t1 + r4.z + 0.5f);
-        const float c2 = fmaxf(0.f, TG_SH_C0 * t2 + r4.w + 0.5f);
-        float* cp = s_col + (wave * 64 + pl) * 3;
-        __hip_atomic_fetch_add(cp + 0, w * c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(cp + 1, w * c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(cp + 2, w * c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
 
 template <int FABL>     // timing experiments only (0 = product): 1 skip the dense phase, 2 dense phase without loads
 __global__ void __launch_bounds__(TG_BLOCK)
 k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_norm,
              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-    __shared__ float4 s_rec[6][TG_BLOCK];
     __shared__ uint2 s_qall[4][FQ_CAP];
     __shared__ float s_col[TG_BLOCK * 3];
-    __shared__ int s_alive[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= a.num_tiles) return;
     const int tile = (int)a.tile_order[blockIdx.x];      // longest list first
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    const int px = tile_x * TEXGS_TILE + ((wave & 1) << 3) + (lane & 7);
-    const int py = tile_y * TEXGS_TILE + ((wave >> 1) << 3) + (lane >> 3);
+    const int wave_px = tile_x * TEXGS_TILE + ((wave & 1) << 3), wave_py = tile_y * TEXGS_TILE + ((wave >> 1) << 3);
+    const int px = wave_px + (lane & 7), py = wave_py + (lane >> 3);
     const bool inside = (px < a.W) && (py < a.H);
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = a.ranges[tile];
     const int todo = (int)(range.y - range.x);
+    const float* __restrict__ tex = a.texture;
     uint2* s_q = s_qall[wave];
-    FwdItemCtx cx;
-    cx.R = a.R; cx.tile_px = tile_x * TEXGS_TILE; cx.tile_py = tile_y * TEXGS_TILE; cx.tex = a.texture;
+    float* s_c = s_col + wave * 192;
 
     s_col[tid * 3 + 0] = 0.f; s_col[tid * 3 + 1] = 0.f; s_col[tid * 3 + 2] = 0.f;   // own pixel; only this wave touches it
+    __builtin_amdgcn_wave_barrier();
 
     bool done = !inside;
     float T = 1.0f;
@@ -159,59 +120,98 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     uint32_t last = 0;
     int qhead = 0, qtail = 0;                                  // wave-uniform
 
-    for (int base = 0; base < todo; base += TG_BLOCK) {
-        const unsigned long long alive = __ballot(!done);
-        if (lane == 0) s_alive[wave] = (alive != 0ull);
-        __syncthreads();
-        if (!(s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3])) break;
-        const int cnt = min(TG_BLOCK, todo - base);
-        if (tid < cnt) {
-            const uint32_t id = a.point_list[range.x + base + tid];
+#define FWD_DRAIN(NITEMS)                                                                                              \
+    do {                                                                                                               \
+        const int n_ = (NITEMS);                                                                                       \
+        uint2 e_ = make_uint2(0u, 0u);                                                                                 \
+        if (lane < n_) e_ = s_q[(qhead + lane) & (FQ_CAP - 1)];                                                        \
+        const int pl_ = (int)(e_.y >> 8) & 63, jj_ = (int)(e_.y & 63u);                                                \
+        const float gx_ = BP(r0.x, jj_), gy_ = BP(r0.y, jj_), g0_ = BP(r1.z, jj_), g1_ = BP(r1.w, jj_);                \
+        const float G00 = BP(r2.x, jj_), G01 = BP(r2.y, jj_), G10 = BP(r2.z, jj_), G11 = BP(r2.w, jj_);                \
+        const float G20 = BP(r3.x, jj_), G21 = BP(r3.y, jj_), ph0 = BP(r3.z, jj_), ph1 = BP(r3.w, jj_);                \
+        const float ph2 = BP(r4.x, jj_), vd0 = BP(r4.y, jj_), vd1 = BP(r4.z, jj_), vd2 = BP(r4.w, jj_);                \
+        if (lane < n_) {                                                                                               \
+            const float w_ = __uint_as_float(e_.x);                                                                    \
+            const float dpx = (float)(wave_px + (pl_ & 7)) - gx_, dpy = (float)(wave_py + (pl_ >> 3)) - gy_;           \
+            const float den = 1.0f + g0_ * dpx + g1_ * dpy;                                                            \
+            const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;                                 \
+            const float u0 = ph0 + (G00 * dpx + G01 * dpy) * inv;                                                      \
+            const float u1 = ph1 + (G10 * dpx + G11 * dpy) * inv;                                                      \
+            const float u2 = ph2 + (G20 * dpx + G21 * dpy) * inv;                                                      \
+            const CubeTap ct = cube_address(u0, u1, u2, a.R);                                                          \
+            const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);                              \
+            const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;                                      \
+            Texel3 q00 = {0.1f, 0.2f, 0.3f}, q01 = q00, q10 = q00, q11 = q00;                                          \
+            if (FABL != 2) { q00 = load_texel(tex, ct.o00); q01 = load_texel(tex, ct.o01);                             \
+                             q10 = load_texel(tex, ct.o10); q11 = load_texel(tex, ct.o11); }                           \
+            const float t0 = w00 * q00.x + w01 * q01.x + w10 * q10.x + w11 * q11.x;                                    \
+            const float t1 = w00 * q00.y + w01 * q01.y + w10 * q10.y + w11 * q11.y;                                    \
+            const float t2 = w00 * q00.z + w01 * q01.z + w10 * q10.z + w11 * q11.z;                                    \
+            float* cp = s_c + pl_ * 3;                                                                                 \
+            __hip_atomic_fetch_add(cp + 0, w_ * fmaxf(0.f, TG_SH_C0 * t0 + vd0 + 0.5f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            __hip_atomic_fetch_add(cp + 1, w_ * fmaxf(0.f, TG_SH_C0 * t1 + vd1 + 0.5f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            __hip_atomic_fetch_add(cp + 2, w_ * fmaxf(0.f, TG_SH_C0 * t2 + vd2 + 0.5f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        }                                                                                                              \
+    } while (0)
+#define BP(V, J) __int_as_float(__builtin_amdgcn_ds_bpermute((J) << 2, __float_as_int(V)))
+#define RLF(V, J) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), (J)))
+
+    for (int base = 0; base < todo; base += 64) {
+        if (__ballot(!done) == 0ull) break;
+        const int cnt = min(64, todo - base);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
+        if (lane < cnt) {
+            const uint32_t id = a.point_list[range.x + base + lane];
             const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            const float4 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5];
-            s_rec[0][tid] = v0; s_rec[1][tid] = v1; s_rec[2][tid] = v2;
-            s_rec[3][tid] = v3; s_rec[4][tid] = v4; s_rec[5][tid] = v5;
+            r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6];
         }
-        __syncthreads();
-        if (alive != 0ull) {
-            for (int j = 0; j < cnt; ++j) {
-                const float4 r0 = s_rec[0][j];              // xy.x xy.y conic.a conic.b
-                const float4 r1 = s_rec[1][j];              // conic.c opacity g.x g.y
-                const float dx = r0.x - pxf, dy = r0.y - pyf;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float alpha = fminf(TG_ALPHA_MAX, r1.y * __expf(power));
-                bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-                const float Tn = T * (1.0f - alpha);
-                if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
-                const unsigned long long bal = __ballot(ok);
-                if (bal != 0ull) {
+        // per-wave cull, lane-parallel: can instance `lane` reach alpha >= 1/255 anywhere in this wave's 8x8 block?
+        unsigned long long todo_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
+                                                (r0.y + r6.x >= (float)wave_py) && (r0.y - r6.x <= (float)(wave_py + 7)));
+        while (todo_mask != 0ull) {
+            const int j = __ffsll((long long)todo_mask) - 1;
+            todo_mask &= todo_mask - 1ull;
+            const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
+            const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
+            const float dx = gx_ - pxf, dy = gy_ - pyf;
+            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+            if (__ballot((!done) && (power <= 0.0f) && (power >= thr)) == 0ull) continue;   // conservative prefilter
+            const float op = RLF(r1.y, j);
+            const float alpha = fminf(TG_ALPHA_MAX, op * __expf(power));
+            bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+            const float Tn = T * (1.0f - alpha);
+            if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
+            const unsigned long long bal = __ballot(ok);
+            if (bal != 0ull) {
+                const float dep = RLF(r5.x, j), n0 = RLF(r5.y, j), n1 = RLF(r5.z, j), n2 = RLF(r5.w, j);
+                if (ok) {
                     const float w = alpha * T;
-                    if (ok) {
-                        const float4 r5 = s_rec[5][j];      // depth n0 n1 n2
-                        Dp += w * r5.x; N0 += w * r5.y; N1 += w * r5.z; N2 += w * r5.w; Al += w;
-                        T = Tn;
-                        last = (uint32_t)(base + j + 1);
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                              __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        s_q[(qtail + rank) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), ((uint32_t)lane << 8) | (uint32_t)j);
-                    }
-                    qtail += __popcll(bal);
-                    if (qtail - qhead >= 64) {
-                        __builtin_amdgcn_wave_barrier();
-                        if (FABL != 1) fwd_drain<FABL>(s_rec, s_q, s_col, qhead, 64, lane, wave, cx);
-                        qhead += 64;
-                    }
+                    Dp += w * dep; N0 += w * n0; N1 += w * n1; N2 += w * n2; Al += w;
+                    T = Tn;
+                    last = (uint32_t)(base + j + 1);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    s_q[(qtail + rank) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), ((uint32_t)lane << 8) | (uint32_t)j);
+                }
+                qtail += __popcll(bal);
+                if (qtail - qhead >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (FABL != 1) FWD_DRAIN(64);
+                    qhead += 64;
                 }
                 if (__ballot(!done) == 0ull) break;
             }
-            // items reference this batch's LDS records: finish them before the records are replaced
-            if (qtail - qhead > 0) {
-                __builtin_amdgcn_wave_barrier();
-                if (FABL != 1) fwd_drain<FABL>(s_rec, s_q, s_col, qhead, qtail - qhead, lane, wave, cx);
-                qhead = qtail;
-            }
+        }
+        // items reference this chunk's registers: finish them before the next chunk is loaded
+        if (qtail - qhead > 0) {
+            __builtin_amdgcn_wave_barrier();
+            if (FABL != 1) FWD_DRAIN(qtail - qhead);
+            qhead = qtail;
         }
     }
+#undef FWD_DRAIN
+#undef BP
+#undef RLF
     __builtin_amdgcn_wave_barrier();
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
@@ -314,34 +314,43 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
         const int jtop = min(64, wave_last - base);           // instances [0, jtop) of this chunk matter
         // ---- lane l <- instance l of the chunk
         uint32_t id = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2v = r0, r3v = r0, r4v = r0, r5 = r0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2v = r0, r3v = r0, r4v = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
         if (lane < jtop) {
             id = a.point_list[range.x + base + lane];
             const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5];
+            r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5]; r6 = r[6];
         }
+        // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
+        const unsigned long long cull_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
+                                                      (r0.y + r6.x >= (float)wave_py) && (r0.y - r6.x <= (float)(wave_py + 7)));
         uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
-        int j = jtop - 1;
-        while (j >= 0) {
+        unsigned long long amask = cull_mask;                 // instances still to be tested (stage A), high to low
+        while (amask != 0ull) {
             // ================================================================ stage A
-            const int seg_hi = j;
             int n_items = 0;
-            for (; j >= 0; --j) {
+            unsigned long long seg_mask = 0ull;                 // instances of this segment that produced items
+            while (amask != 0ull) {
+                const int j = 63 - __clzll((long long)amask);
+                const unsigned long long jbit = 1ull << j;
                 const float gx_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.x), j));
                 const float gy_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.y), j));
                 const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.z), j));
                 const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.w), j));
                 const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), j));
-                const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), j));
+                const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r6.y), j));
                 const float dx = gx_ - pxf, dy = gy_ - pyf;
                 const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+                if (__ballot(inside && (base + j < last) && (power <= 0.0f) && (power >= thr)) == 0ull) { amask &= ~jbit; continue; }
+                const float op = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), j));
                 const float araw = op * __expf(power);
                 const float alpha = fminf(TG_ALPHA_MAX, araw);
                 const bool ok = inside && (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
                 const unsigned long long bal = __ballot(ok);
                 const int nb = __popcll(bal);
-                if (nb == 0) continue;
+                if (nb == 0) { amask &= ~jbit; continue; }
                 if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
+                amask &= ~jbit;
+                seg_mask |= jbit;
                 if (lane == j) { touched_lo = (uint32_t)bal; touched_hi = (uint32_t)(bal >> 32); }
                 if (ok) {
                     T = T / (1.0f - alpha);
@@ -351,7 +360,6 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 }
                 n_items += nb;
             }
-            const int seg_lo = j + 1;
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage B
             for (int r = 0; r < n_items; r += 64) {
@@ -471,11 +479,12 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage C
             int it0 = 0;
-            for (int jj = seg_hi; jj >= seg_lo; --jj) {
+            while (seg_mask != 0ull) {
+                const int jj = 63 - __clzll((long long)seg_mask);
+                seg_mask &= ~(1ull << jj);
                 const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)touched_lo, jj);
                 const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)touched_hi, jj);
                 const unsigned long long bal = ((unsigned long long)bhi << 32) | blo;
-                if (bal == 0ull) continue;
                 const bool ok = (bal >> lane) & 1ull;
                 float part[32];
 #pragma unroll
