@@ -259,6 +259,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 #endif
 #define TC_SLOTS (TC_W * TC_H)
 #define TC_EMPTY 0xFFFFFFFFu
+#ifndef TC_SECOND_CHANCE
+#define TC_SECOND_CHANCE 0
+#endif
 
 #ifndef BWD_WAVES_PER_SIMD
 #define BWD_WAVES_PER_SIMD 2
@@ -426,6 +429,13 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                             const uint32_t tag = toff[tp * 3];
                             uint32_t old = cur_[tp];
                             if (old == TC_EMPTY) old = atomicCAS(&s_ttag[slot_[tp]], TC_EMPTY, tag);
+#if TC_SECOND_CHANCE
+                            if (old != TC_EMPTY && old != tag) {     // taken by another texel: one more try at a hashed slot
+                                slot_[tp] = (int)((tag * 2654435761u) >> (32 - 11)) & (TC_SLOTS - 1);
+                                old = s_ttag[slot_[tp]];
+                                if (old == TC_EMPTY) old = atomicCAS(&s_ttag[slot_[tp]], TC_EMPTY, tag);
+                            }
+#endif
                             if (old == TC_EMPTY || old == tag) {
 #pragma unroll
                                 for (int ch = 0; ch < 3; ++ch) {
