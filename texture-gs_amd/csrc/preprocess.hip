@@ -124,7 +124,9 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
     if (s1 < smin) { smin = s1; g.kmin = 1; }
     if (s2 < smin) { smin = s2; g.kmin = 2; }
     g.dir[0] = mx - F.cam[0]; g.dir[1] = my - F.cam[1]; g.dir[2] = mz - F.cam[2];
-    float n0 = g.R[0 + g.kmin], n1 = g.R[3 + g.kmin], n2 = g.R[6 + g.kmin];
+    const float n0 = (g.kmin == 0) ? g.R[0] : ((g.kmin == 1) ? g.R[1] : g.R[2]);      // selects, not a runtime index:
+    const float n1 = (g.kmin == 0) ? g.R[3] : ((g.kmin == 1) ? g.R[4] : g.R[5]);      // keeps R[] in registers
+    const float n2 = (g.kmin == 0) ? g.R[6] : ((g.kmin == 1) ? g.R[7] : g.R[8]);
     g.sign = ((n0 * g.dir[0] + n1 * g.dir[1] + n2 * g.dir[2]) > 0.0f) ? -1.0f : 1.0f;
     g.n[0] = g.sign * n0; g.n[1] = g.sign * n1; g.n[2] = g.sign * n2;
     g.dlen = sqrtf(g.dir[0] * g.dir[0] + g.dir[1] * g.dir[1] + g.dir[2] * g.dir[2]);
@@ -234,29 +236,43 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  const float* __restrict__ juv,
                  float4* __restrict__ rec, float* __restrict__ depth, int32_t* __restrict__ radii,
                  uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
-    if (i >= C.N) return;
+    const bool live = i < C.N;
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
-    geo_forward(g, F, C, i, means, scales, rots, juv);
+    g.valid = false;
+    if (live) geo_forward(g, F, C, i, means, scales, rots, juv);
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (g.valid) {
         tile_rect(g, C, x0, y0, x1, y1);
         if ((x1 - x0) * (y1 - y0) == 0) g.valid = false;
     }
+    const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, C.sh_coeffs) : 0;
+    const int row = 3 * C.sh_coeffs;
+    if (na > 0) {           // block-cooperative, contiguous read of this block's SH rows (180 B per Gaussian at K = 15)
+        const size_t first = (size_t)blockIdx.x * TG_BLOCK * row;
+        const size_t total = (size_t)C.N * row;
+        const int count = (int)min((size_t)TG_BLOCK * row, total - first);
+        for (int k = threadIdx.x; k < count; k += TG_BLOCK) s_sh[k] = shs[first + k];
+        __syncthreads();
+    }
+    if (!live) return;
     if (!g.valid) {
         radii[i] = 0; tiles_touched[i] = 0; depth[i] = 0.0f; rect[i] = make_uint2(0u, 0u);
         return;                                   // record left unwritten: never gathered (no instances)
     }
     // view-dependent colour: SH bands 1..deg at the (unit) view direction
     float vd[3] = {0.f, 0.f, 0.f};
-    const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, C.sh_coeffs) : 0;
     if (na > 0) {
         float b[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) b[k] = 0.f;
         sh_basis(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
-        const float* sp = shs + (size_t)i * C.sh_coeffs * 3;
-        for (int k = 0; k < na; ++k) {
-            vd[0] += b[k] * sp[3 * k + 0]; vd[1] += b[k] * sp[3 * k + 1]; vd[2] += b[k] * sp[3 * k + 2];
+        const float* sp = s_sh + threadIdx.x * row;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            if (k < na) { vd[0] += b[k] * sp[3 * k + 0]; vd[1] += b[k] * sp[3 * k + 1]; vd[2] += b[k] * sp[3 * k + 2]; }
         }
     }
     radii[i] = g.radius;
@@ -292,19 +308,28 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
                  float* __restrict__ d_uvs) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K]: SH rows in, dL/dSH rows out
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
-    if (i >= C.N) return;
     const int K = C.sh_coeffs;
-    if (radii[i] <= 0) {
+    const bool live = i < C.N;
+    const int row = 3 * K;
+    const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, K) : 0;
+    const size_t first = (size_t)blockIdx.x * TG_BLOCK * row;
+    const int count = d_shs ? (int)min((size_t)TG_BLOCK * row, (size_t)C.N * row - first) : 0;
+    if (na > 0 && d_shs) {
+        for (int k = threadIdx.x; k < count; k += TG_BLOCK) s_sh[k] = shs[first + k];
+        __syncthreads();
+    }
+    const bool visible = live && radii[i] > 0;
+    if (live && !visible) {
         d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
         d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
         d_op[i] = 0.f;
         d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
         d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
         d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
-        if (d_shs) for (int k = 0; k < 3 * K; ++k) d_shs[(size_t)i * 3 * K + k] = 0.f;
-        return;
     }
+    if (visible) {
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     geo_forward(g, F, C, i, means, scales, rots, juv);
@@ -423,31 +448,36 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
             dn[k] += dnv[0] * WR(F, 0, k) + dnv[1] * WR(F, 1, k) + dnv[2] * WR(F, 2, k);
     }
     // n = sign * R[:, kmin]
-    dR[0 + g.kmin] += g.sign * dn[0]; dR[3 + g.kmin] += g.sign * dn[1]; dR[6 + g.kmin] += g.sign * dn[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float on = (g.kmin == k) ? g.sign : 0.0f;
+        dR[0 + k] += on * dn[0]; dR[3 + k] += on * dn[1]; dR[6 + k] += on * dn[2];
+    }
 
-    // (10) view-dependent colour -> shs, view direction
-    const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, K) : 0;
-    if (d_shs) {
-        float* dsp = d_shs + (size_t)i * K * 3;
-        if (na > 0) {
-            float b[15], bx[15], by[15], bz[15];
-            sh_basis(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
-            sh_basis_grad(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], bx, by, bz);
-            const float* sp = shs + (size_t)i * K * 3;
-            const float v0 = A[R_VD], v1 = A[R_VD + 1], v2 = A[R_VD + 2];
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-            for (int k = 0; k < na; ++k) {
-                dsp[3 * k + 0] = b[k] * v0; dsp[3 * k + 1] = b[k] * v1; dsp[3 * k + 2] = b[k] * v2;
+    // (10) view-dependent colour -> shs, view direction (rows staged in LDS; dL/dSH overwrites the row in place)
+    if (d_shs && na > 0) {
+        float b[15], bx[15], by[15], bz[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) { b[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+        sh_basis(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], b);
+        sh_basis_grad(C.sh_degree, g.dir[0], g.dir[1], g.dir[2], bx, by, bz);
+        float* sp = s_sh + threadIdx.x * row;
+        const float v0 = A[R_VD], v1 = A[R_VD + 1], v2 = A[R_VD + 2];
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            if (k < na) {
                 const float w = sp[3 * k + 0] * v0 + sp[3 * k + 1] * v1 + sp[3 * k + 2] * v2;
                 ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+                sp[3 * k + 0] = b[k] * v0; sp[3 * k + 1] = b[k] * v1; sp[3 * k + 2] = b[k] * v2;
             }
-            // dir = d/|d|
-            const float dd = g.dir[0] * ddx + g.dir[1] * ddy + g.dir[2] * ddz;
-            dm[0] += (ddx - g.dir[0] * dd) / g.dlen;
-            dm[1] += (ddy - g.dir[1] * dd) / g.dlen;
-            dm[2] += (ddz - g.dir[2] * dd) / g.dlen;
         }
-        for (int k = 3 * na; k < 3 * K; ++k) dsp[k] = 0.f;
+        for (int k = 3 * na; k < row; ++k) sp[k] = 0.f;
+        // dir = d/|d|
+        const float dd = g.dir[0] * ddx + g.dir[1] * ddy + g.dir[2] * ddz;
+        dm[0] += (ddx - g.dir[0] * dd) / g.dlen;
+        dm[1] += (ddy - g.dir[1] * dd) / g.dlen;
+        dm[2] += (ddz - g.dir[2] * dd) / g.dlen;
     }
 
     // (8) t = [m,1] @ V
@@ -462,6 +492,14 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     d_rots[4 * i + 1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
     d_rots[4 * i + 2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
     d_rots[4 * i + 3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }   // visible
+    if (d_shs) {            // dL/dSH: zero rows for culled Gaussians / inactive degree, then one coalesced block store
+        if (na == 0 || (live && !visible)) {
+            if (live) for (int k = 0; k < row; ++k) s_sh[threadIdx.x * row + k] = 0.f;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < count; k += TG_BLOCK) d_shs[first + k] = s_sh[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K9
@@ -478,7 +516,8 @@ k_mark_visible(int N, const float* __restrict__ vm, const float* __restrict__ me
 void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, TexGSGeom* g, hipStream_t s) {
     if (c.N <= 0) return;
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
-    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), 0, s, c, f->viewmatrix, f->projmatrix, f->campos,
+    const size_t lds = (in->shs && c.sh_degree > 0) ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs,
                        reinterpret_cast<float4*>(g->rec), g->depth, g->radii, reinterpret_cast<uint2*>(g->rect),
                        g->tiles_touched);
@@ -488,7 +527,8 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
                            TexGSGrads* gr, hipStream_t s) {
     if (c.N <= 0) return;
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), 0, s, c, f->viewmatrix, f->projmatrix, f->campos,
+    const size_t lds = gr->dL_dshs ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
                        gr->dL_drotations, gr->dL_duvs);

@@ -66,6 +66,13 @@ __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, in
     return t;
 }
 
+#ifdef TEXGS_STATS
+__device__ unsigned long long g_stats[16];
+#define STAT(i, v) atomicAdd(&g_stats[i], (unsigned long long)(v))
+#else
+#define STAT(i, v) do {} while (0)
+#endif
+
 struct PixArgs {
     int W, H, tiles_x, num_tiles, R;
     const uint2* ranges;
@@ -324,9 +331,11 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5]; r6 = r[6];
         }
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
+        if (lane == 0) STAT(8, 1);                                      /* wave-chunks */
         const unsigned long long cull_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
                                                       (r0.y + r6.x >= (float)wave_py) && (r0.y - r6.x <= (float)(wave_py + 7)));
         uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
+        if (lane == 0) STAT(0, __popcll(cull_mask));                     /* tests after per-wave cull */
         unsigned long long amask = cull_mask;                 // instances still to be tested (stage A), high to low
         while (amask != 0ull) {
             // ================================================================ stage A
@@ -350,6 +359,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 const bool ok = inside && (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
                 const unsigned long long bal = __ballot(ok);
                 const int nb = __popcll(bal);
+                if (lane == 0) STAT(1, 1);                              /* full tests (post prefilter) */
                 if (nb == 0) { amask &= ~jbit; continue; }
                 if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
                 amask &= ~jbit;
@@ -365,6 +375,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             }
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage B
+            if (lane == 0) { STAT(2, n_items); STAT(3, (n_items + 63) / 64); STAT(4, 1); }   /* items, rounds, segments */
             for (int r = 0; r < n_items; r += 64) {
                 const int e = r + lane;
                 const bool have = e < n_items;
@@ -436,6 +447,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                                 if (old == TC_EMPTY) old = atomicCAS(&s_ttag[slot_[tp]], TC_EMPTY, tag);
                             }
 #endif
+                            STAT((old == TC_EMPTY || old == tag) ? 5 : 6, 1);           /* cache hits / misses (taps) */
                             if (old == TC_EMPTY || old == tag) {
 #pragma unroll
                                 for (int ch = 0; ch < 3; ++ch) {
@@ -537,6 +549,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     part[R_N] = w * dpix[4]; part[R_N + 1] = w * dpix[5]; part[R_N + 2] = w * dpix[6];
                 }
 #undef RL
+                if (lane == 0) STAT(7, 1);                              /* stage C heavy iterations */
                 it0 += __popcll(bal);
                 const float tot = (ABL & 2) ? part[lane & 31] : reduce_transposed<32>(part, lane);
                 // accumulator slot k lives in lane k: 24 consecutive dwords of one row -> one coalesced request
@@ -602,3 +615,11 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     }
 #undef LAUNCH_BWD
 }
+
+#ifdef TEXGS_STATS
+extern "C" int texgs_debug_stats(unsigned long long* host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
