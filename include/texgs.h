@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 1
+#define TEXGS_ABI_VERSION 2
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
@@ -59,6 +59,9 @@ typedef struct TexGSInputs {
     const float* uvs;          /* f32[N,3] phi(mu) on the unit sphere (:229-236)                       */
     const float* gradient_uvs; /* f32[N,9] [3*i+j] = d uv_i / d x_j (:216-227)                         */
     const float* texture;      /* f32[6,R,R,3] SH-DC valued cubemap (:51, :16-21)                      */
+    const float* color_offset; /* f32[N,3] or NULL: added to the view-dependent colour term.  Used by the
+                                  untextured `diff_gauss` surface (render/render.py:75-84): C0*SH_DC or
+                                  colors_precomp - 0.5                                                    */
 } TexGSInputs;
 
 /* Per-Gaussian state written by texgs_preprocess_forward. */
@@ -112,6 +115,7 @@ typedef struct TexGSGrads {
     float* dL_drotations;      /* f32[N,4]                                                             */
     float* dL_duvs;            /* f32[N,3]                                                             */
     float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
+    float* dL_dcolor_offset;   /* f32[N,3] or NULL                                                     */
 } TexGSGrads;
 
 int         texgs_abi_version(void);

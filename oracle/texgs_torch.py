@@ -106,7 +106,7 @@ def sh_view_dependent(deg, shs, dirs):
     return res
 
 
-def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, st, dtype):
+def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, st, dtype, color_offset=None):
     """K1 of SURVEY Appendix A.2 (+ the texture pre-fold).  Returns a dict of per-Gaussian state."""
     H, W = int(st.image_height), int(st.image_width)
     V = st.viewmatrix.to(dtype)      # row-vector: p_view = [x,y,z,1] @ V   (utils/cameras.py:62)
@@ -173,6 +173,8 @@ def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradien
     dirs = means3D - cam[None, :]
     dirn = dirs / dirs.norm(dim=1, keepdim=True)          # render/render.py:65-66
     viewdep = sh_view_dependent(int(st.sh_degree), shs, dirn)
+    if color_offset is not None:          # untextured surface (render/render.py:63-68): C0*SH_DC or colors_precomp - 0.5
+        viewdep = viewdep + color_offset
 
     # normal = shortest axis, flipped to face the camera, world space
     kmin = torch.argmin(scales.detach(), dim=1)
@@ -383,13 +385,13 @@ def _scatter_image(out, PY, PX, VAL):
 
 
 def rasterize(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture,
-              st: Settings, dtype=torch.float64, debug=False):
+              st: Settings, dtype=torch.float64, debug=False, color_offset=None):
     """Whole operator (reference call: render/uv_tex_render.py:56-66).  Returns
     (image[3,H,W], depth[1,H,W], norm[3,H,W], alpha[1,H,W], radii[N] int32, extra=None) and, with
     debug=True, a dict of intermediates for the integer-stage parity tests."""
     cv = lambda t: None if t is None else t.to(dtype)
     pre = preprocess(cv(means3D), cv(means2D), cv(shs), cv(opacities), cv(scales), cv(rotations),
-                     cv(uvs), cv(gradient_uvs), st, dtype)
+                     cv(uvs), cv(gradient_uvs), st, dtype, color_offset=cv(color_offset))
     binning = bin_and_sort(pre)
     out, final_T, n_contrib, amb = render(pre, binning, cv(texture), st, dtype)
     res = (out[0:3], out[3:4], out[4:7], out[7:8], pre['radius'].to(torch.int32), None)

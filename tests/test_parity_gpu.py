@@ -158,3 +158,46 @@ def test_matches_committed_golden_fixture(lib_built):
     for name in ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture", "means2D"]:
         ok, msg = Hh.grad_close(g[name], torch.tensor(d["grad_" + name]))
         assert ok, (name, msg)
+
+
+def test_untextured_diff_gauss_surface(lib_built):
+    """`diff_gauss` (render/render.py:4,75-84) on the same kernels: SH-with-DC and colors_precomp, fwd + grads
+    against the oracle run with a zero 1x1 cubemap and the equivalent colour offset."""
+    import diff_gauss as dg
+    from oracle import texgs_torch as O
+    scene, cam, deg, bg = _scene(CASES[3])
+    dev = torch.device("cuda:0")
+    N = scene.means3D.shape[0]
+    g = torch.Generator().manual_seed(8)
+    shs_full = torch.cat([torch.randn(N, 1, 3, generator=g), scene.shs[:, :3, :]], 1)      # degree 1: DC + 3
+    target, nhat = synth.make_targets(cam.image_height, cam.image_width, seed=4)
+    st_gpu = Hh.settings_for(cam, 1, bg, device=dev, cls=dg.GaussianRasterizationSettings)
+    for mode in ("shs", "precomp"):
+        leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(True) for n in ["means3D", "opacities", "scales", "rotations"]}
+        col = (shs_full if mode == "shs" else torch.rand(N, 3, generator=g)).to(dev).requires_grad_(True)
+        m2 = torch.zeros(N, 3, device=dev, requires_grad=True)
+        kw = dict(shs=col) if mode == "shs" else dict(colors_precomp=col)
+        out = dg.GaussianRasterizer(st_gpu)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                            scales=leaves["scales"], rotations=leaves["rotations"], cov3Ds_precomp=None,
+                                            extra_attrs=None, **kw)
+        synth.synthetic_loss(out[0], out[3], out[2], target.to(dev), nhat.to(dev)).backward()
+        # oracle
+        d = torch.float64
+        ol = {n: getattr(scene, n).clone().to(d).requires_grad_(True) for n in leaves}
+        ocol = col.detach().cpu().to(d).requires_grad_(True)
+        if mode == "shs":
+            off, rest = O.SH_C0 * ocol[:, 0, :], ocol[:, 1:, :]
+        else:
+            off, rest = ocol - 0.5, None
+        uvs = torch.zeros(N, 3, dtype=d); uvs[:, 2] = 1.0
+        st = Hh.settings_for(cam, 1, bg)
+        ref = O.rasterize(ol["means3D"], None, rest, ol["opacities"], ol["scales"], ol["rotations"], uvs,
+                          torch.zeros(N, 9, dtype=d), torch.zeros(6, 1, 1, 3, dtype=d), st, color_offset=off)
+        synth.synthetic_loss(ref[0], ref[3], ref[2], target.to(d), nhat.to(d)).backward()
+        assert float((out[0].detach().cpu().double() - ref[0]).abs().max()) < 2e-4, mode
+        assert float((out[3].detach().cpu().double() - ref[3]).abs().max()) < 2e-4, mode
+        ok, msg = Hh.grad_close(col.grad.cpu(), ocol.grad)
+        assert ok, (mode, "colour", msg)
+        for n in leaves:
+            ok, msg = Hh.grad_close(leaves[n].grad.cpu(), ol[n].grad)
+            assert ok, (mode, n, msg)

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(TG_BLOCK)
 k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
                  const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ uvs,
-                 const float* __restrict__ juv,
+                 const float* __restrict__ juv, const float* __restrict__ coff,
                  float4* __restrict__ rec, float* __restrict__ depth, int32_t* __restrict__ radii,
                  uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
@@ -275,6 +275,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
             if (k < na) { vd[0] += b[k] * sp[3 * k + 0]; vd[1] += b[k] * sp[3 * k + 1]; vd[2] += b[k] * sp[3 * k + 2]; }
         }
     }
+    if (coff) { vd[0] += coff[3 * i + 0]; vd[1] += coff[3 * i + 1]; vd[2] += coff[3 * i + 2]; }
     radii[i] = g.radius;
     tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
     depth[i] = g.t[2];
@@ -307,7 +308,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  const float* __restrict__ acc,
                  float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
-                 float* __restrict__ d_uvs) {
+                 float* __restrict__ d_uvs, float* __restrict__ d_coff) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K]: SH rows in, dL/dSH rows out
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
     const int K = C.sh_coeffs;
@@ -328,6 +329,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
         d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
         d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
         d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
+        if (d_coff) d_coff[3 * i] = d_coff[3 * i + 1] = d_coff[3 * i + 2] = 0.f;
     }
     if (visible) {
     const Frame F = load_frame(vm, pm, cp);
@@ -352,6 +354,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     // (1,2) pass-through
     d_op[i] = A[R_OP];
     d_uvs[3 * i + 0] = A[R_PHI]; d_uvs[3 * i + 1] = A[R_PHI + 1]; d_uvs[3 * i + 2] = A[R_PHI + 2];
+    if (d_coff) { d_coff[3 * i + 0] = A[R_VD]; d_coff[3 * i + 1] = A[R_VD + 1]; d_coff[3 * i + 2] = A[R_VD + 2]; }
 
     // (3) conic -> cov2D (a,b,c)
     const float dA = A[R_CONIC], dB = A[R_CONIC + 1], dC = A[R_CONIC + 2];
@@ -518,7 +521,7 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
     const size_t lds = (in->shs && c.sh_degree > 0) ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
-                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs,
+                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset,
                        reinterpret_cast<float4*>(g->rec), g->depth, g->radii, reinterpret_cast<uint2*>(g->rect),
                        g->tiles_touched);
 }
@@ -531,7 +534,7 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
-                       gr->dL_drotations, gr->dL_duvs);
+                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset);
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

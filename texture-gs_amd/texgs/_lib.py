@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtexgs.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 TILE = 16
 REC_FLOATS = 32
 ACC_FLOATS = 24
@@ -23,7 +23,7 @@ class Frame(C.Structure):
 
 class Inputs(C.Structure):
     _fields_ = [("means3D", _fp), ("shs", _fp), ("opacities", _fp), ("scales", _fp), ("rotations", _fp),
-                ("uvs", _fp), ("gradient_uvs", _fp), ("texture", _fp)]
+                ("uvs", _fp), ("gradient_uvs", _fp), ("texture", _fp), ("color_offset", _fp)]
 
 
 class Geom(C.Structure):
@@ -46,7 +46,8 @@ class Image(C.Structure):
 class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
-                ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp)]
+                ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
+                ("dL_dcolor_offset", _fp)]
 
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",

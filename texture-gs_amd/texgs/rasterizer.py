@@ -64,7 +64,7 @@ def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
     return f
 
 
-def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture):
+def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None):
     """Run K1..K6.  Returns (outputs, state).  No autograd here."""
     lib = _lib.load()
     device = means3D.device
@@ -98,17 +98,21 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         K = shs.shape[1]
         if K > 15:
             raise ValueError("shs holds at most 15 view-dependent coefficients (degree 3)")
+    if color_offset is not None:
+        color_offset = _f32c(color_offset, "color_offset", device)
+        if color_offset.shape != (N, 3):
+            raise ValueError(f"color_offset must be [N,3], got {tuple(color_offset.shape)}")
     if int(st.sh_degree) < 0 or int(st.sh_degree) > 3:
         raise ValueError("sh_degree must be in [0,3]")
     H, W = int(st.image_height), int(st.image_width)
     tiles = ((W + _lib.TILE - 1) // _lib.TILE) * ((H + _lib.TILE - 1) // _lib.TILE)
     stream = torch.cuda.current_stream(device).cuda_stream
-    keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture]
+    keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset]
 
     with torch.cuda.device(device):
         frame = _make_frame(st, N, K, R, device, keep)
         inputs = _lib.Inputs(_ptr(means3D), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(rotations),
-                             _ptr(uvs), _ptr(gradient_uvs), _ptr(texture))
+                             _ptr(uvs), _ptr(gradient_uvs), _ptr(texture), _ptr(color_offset))
         # per-Gaussian state
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
@@ -188,19 +192,22 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha):
         d_rot = torch.empty(N, 4, **f32)
         d_uvs = torch.empty(N, 3, **f32)
         d_tex = torch.zeros(6, R, R, 3, **f32)
+        d_coff = torch.empty(N, 3, **f32) if s.tensors["keep"][8] is not None else None
         grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(d_means3D), _ptr(d_means2D),
-                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex))
+                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff))
         _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                       C.byref(s.img), C.byref(grads), stream), "texgs_backward")
+    s.tensors["d_color_offset"] = d_coff
     return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, acc
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st):
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None):
         outs, state = forward_raw(st, means3D.detach(), None if shs is None else shs.detach(),
                                   opacities.detach(), scales.detach(), rotations.detach(), uvs.detach(),
-                                  gradient_uvs.detach(), texture.detach())
+                                  gradient_uvs.detach(), texture.detach(),
+                                  None if color_offset is None else color_offset.detach())
         color, depth, norm, alpha, radii = outs
         ctx.state = state
         ctx.op_shape = opacities.shape
@@ -213,8 +220,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.state
         d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, _ = backward_raw(
             s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha)
+        d_coff = s.tensors.get("d_color_offset")
         ctx.state = None
-        return (d_means3D, d_means2D, d_shs, d_op.reshape(ctx.op_shape), d_scales, d_rot, d_uvs, None, d_tex, None)
+        return (d_means3D, d_means2D, d_shs, d_op.reshape(ctx.op_shape), d_scales, d_rot, d_uvs, None, d_tex, None, d_coff)
 
 
 class GaussianRasterizer(nn.Module):
