@@ -63,6 +63,7 @@ def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched)
         "render_fwd": D_eff * 100 + tex + P * 40 + T * 8,
         "render_bwd": D_eff * 100 + P * 40 + tex + 2 * tex + n_touched * 192 + T * 8,
         "preprocess_bwd": N * (96 + 12 * K) + n_vis * 96 + N * (68 + 12 * K),
+        "texgrad_gather": 0,      # an artefact of the scatter layout, no algorithmic traffic of its own
     }
 
 
@@ -189,8 +190,8 @@ def main():
     kinfo = {}
     for name, (ms, cnt) in kern.items():
         if cnt:
-            kinfo[name] = {"avg_us": 1e3 * ms / cnt, "launches": cnt, "alg_MB": ab[name] / 1e6,
-                           "GBps": ab[name] / (ms / cnt * 1e-3) / 1e9}
+            kinfo[name] = {"avg_us": 1e3 * ms / cnt, "launches": cnt, "alg_MB": ab.get(name, 0) / 1e6,
+                           "GBps": ab.get(name, 0) / (ms / cnt * 1e-3) / 1e9}
     dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"] * kinfo[k]["launches"]) if kinfo else None
     roofline = None
     if dom:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 2
+#define TEXGS_ABI_VERSION 3
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
@@ -116,6 +116,13 @@ typedef struct TexGSGrads {
     float* dL_duvs;            /* f32[N,3]                                                             */
     float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
     float* dL_dcolor_offset;   /* f32[N,3] or NULL                                                     */
+    float* tex_quads;          /* f32[texgs_tex_quads_floats(R)] scratch, ALL-ZERO on entry and all-zero again on
+                                  successful return (the gather clears what it read), or NULL.  Four
+                                  phase-shifted arrays of 64-byte-aligned 2x2-texel quads: a bilinear footprint
+                                  anchored at (x0,y0) is one aligned 48-byte run of array (x0&1, y0&1) = ONE
+                                  memory-side atomic request instead of ~2.7.  Summed into dL_dtexture by the
+                                  gather kernel at the end of texgs_backward.  NULL = scatter straight into
+                                  dL_dtexture.                                                              */
 } TexGSGrads;
 
 int         texgs_abi_version(void);
@@ -123,6 +130,7 @@ const char* texgs_last_error(void);
 
 size_t texgs_scan_temp_bytes(int32_t num_gaussians);
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
+size_t texgs_tex_quads_floats(int32_t tex_res);
 
 /* K1 (frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold) + K2
  * (inclusive scan of tiles_touched).  Replaces the first half of _C.rasterize_gaussians. */
@@ -151,7 +159,8 @@ int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGe
  * the caller's host arrays (length TEXGS_NUM_KERNELS) and clears the log. */
 enum {
     TEXGS_K_PREPROCESS_FWD = 0, TEXGS_K_SCAN = 1, TEXGS_K_DUPLICATE = 2, TEXGS_K_SORT = 3, TEXGS_K_RANGES = 4,
-    TEXGS_K_RENDER_FWD = 5, TEXGS_K_RENDER_BWD = 6, TEXGS_K_PREPROCESS_BWD = 7, TEXGS_NUM_KERNELS = 8
+    TEXGS_K_RENDER_FWD = 5, TEXGS_K_RENDER_BWD = 6, TEXGS_K_PREPROCESS_BWD = 7, TEXGS_K_TEXGRAD_GATHER = 8,
+    TEXGS_NUM_KERNELS = 9
 };
 int texgs_profile_enable(int on);
 int texgs_profile_read(float* ms_sum_host, uint32_t* launches_host);

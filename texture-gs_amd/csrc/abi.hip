@@ -82,6 +82,8 @@ size_t texgs_scan_temp_bytes(int32_t num_gaussians) { return scan_temp_bytes(num
 
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles) { return sort_temp_bytes(num_rendered, num_tiles); }
 
+size_t texgs_tex_quads_floats(int32_t tex_res) { return tex_quads_floats(tex_res); }
+
 int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, void* stream) {
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom) return fail_msg("NULL argument");
@@ -150,6 +152,10 @@ int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGe
     if (bin->num_rendered > 0) {
         { ProfScope p(TEXGS_K_RENDER_BWD, s); launch_render_bwd(c, frame, in, geom, bin, img, grads, s); }
         if (int r = check(frame, s, "render_bwd")) return r;
+        if (grads->tex_quads) {
+            { ProfScope p(TEXGS_K_TEXGRAD_GATHER, s); launch_texgrad_gather(c, grads, s); }
+            if (int r = check(frame, s, "texgrad_gather")) return r;
+        }
     }
     { ProfScope p(TEXGS_K_PREPROCESS_BWD, s); launch_preprocess_bwd(c, frame, in, geom, grads, s); }
     return check(frame, s, "preprocess_bwd");

@@ -75,6 +75,7 @@ __device__ unsigned long long g_stats[16];
 
 struct PixArgs {
     int W, H, tiles_x, num_tiles, R;
+    uint32_t quad_dirty_index;      // float index of the dirty-face word inside the quad buffer
     const uint2* ranges;
     const uint32_t* tile_order;
     const uint32_t* point_list;
@@ -260,6 +261,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 // Tile-local texture-gradient cache: direct-mapped, toroidal spatial hash slot = (x mod 64) + 64 * (y mod TC_H), tag =
 // texel offset.  A footprint narrower than 64 x TC_H texels is collision-free wherever it sits; aliasing updates (other
 // face, far side, parallax spread) fall through to the transposed global atomics.  Flushed once per tile, coalesced.
+#ifndef TC_ENABLE
+#define TC_ENABLE 0      // measured: with the quad layout a miss is ONE request; the cache's LDS ops cost more than they save
+#endif
 #define TC_W 64
 #ifndef TC_H
 #define TC_H 32
@@ -278,12 +282,15 @@ __global__ void __launch_bounds__(TG_BLOCK, BWD_WAVES_PER_SIMD)
 k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
-             float* __restrict__ acc, float* __restrict__ dtex) {
+             float* __restrict__ acc, float* __restrict__ dtex, float* __restrict__ quads) {
     __shared__ float4 s_items_all[4][BQ_CAP * 3];             // 3 float4 per item: {T, araw, q, key} {dc, du0} {du1, du2, inv, dden}
-    __shared__ uint2 s_stage_all[4][64 * 7];                  // 14 KB; row stride 7 (56 B): conflict-free ds_write_b64
+    __shared__ float s_sval_all[4][64 * 13];                  // 13 KB: 12 texture-gradient dwords per pair (+1 pad)
+    __shared__ uint32_t s_sbase_all[4][64];                   // 1 KB: their base offset
     __shared__ float s_dpix[TG_BLOCK * 3];                    // 3 KB
+#if TC_ENABLE
     __shared__ uint32_t s_ttag[TC_SLOTS];                     // 8 KB
     __shared__ float s_tval[TC_SLOTS * 3];                    // 24 KB
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= a.num_tiles) return;
     const int tile = (int)a.tile_order[blockIdx.x];      // longest list first
@@ -297,7 +304,8 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     const int HW = a.W * a.H, pix = py * a.W + px;
     const float* __restrict__ tex = a.texture;
     float4* s_items = s_items_all[wave];
-    uint2* s_stage = s_stage_all[wave];
+    float* s_sval = s_sval_all[wave];
+    uint32_t* s_sbase = s_sbase_all[wave];
 
     float Tfin = 1.f; int last = 0;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
@@ -310,13 +318,16 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
     s_dpix[tid * 3 + 0] = dpix[0]; s_dpix[tid * 3 + 1] = dpix[1]; s_dpix[tid * 3 + 2] = dpix[2];
+#if TC_ENABLE
     for (int k = tid; k < TC_SLOTS; k += TG_BLOCK) { s_ttag[k] = TC_EMPTY; s_tval[3 * k] = 0.f; s_tval[3 * k + 1] = 0.f; s_tval[3 * k + 2] = 0.f; }
     __syncthreads();
+#endif
     const int wave_last = min(wave_max_i(last), todo);
     __builtin_amdgcn_wave_barrier();
 
     float T = Tfin;
     float suffix = 0.f, last_alpha = 0.f, last_s = 0.f;
+    uint32_t faces_marked = 0u;                                // wave-uniform: faces already flagged dirty
 
     const int nchunks = (wave_last + 63) >> 6;
     for (int c = nchunks - 1; c >= 0; --c) {
@@ -425,6 +436,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     toff[6] = ct.o10; toff[7] = ct.o10 + 1; toff[8] = ct.o10 + 2; toff[9] = ct.o11; toff[10] = ct.o11 + 1; toff[11] = ct.o11 + 2;
                     tval[0] = w00 * x0; tval[1] = w00 * x1; tval[2] = w00 * x2; tval[3] = w01 * x0; tval[4] = w01 * x1; tval[5] = w01 * x2;
                     tval[6] = w10 * x0; tval[7] = w10 * x1; tval[8] = w10 * x2; tval[9] = w11 * x0; tval[10] = w11 * x1; tval[11] = w11 * x2;
+#if TC_ENABLE
                     if (!(ABL & 4)) {
                         // cache probe per tap: hit -> LDS accumulate and drop the global update.  Tags are read
                         // first (4 independent ds_read in flight); the CAS runs only on a tap's first touch.
@@ -458,6 +470,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                             }
                         }
                     }
+#endif
                     const float dLdcol = x0 * ((1.f - ct.fy) * (t01.x - t00.x) + ct.fy * (t11.x - t10.x))
                                        + x1 * ((1.f - ct.fy) * (t01.y - t00.y) + ct.fy * (t11.y - t10.y))
                                        + x2 * ((1.f - ct.fy) * (t01.z - t00.z) + ct.fy * (t11.z - t10.z));
@@ -476,26 +489,51 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     s_items[e * 3 + 2] = make_float4(du1, du2, inv, dden);
                 }
                 if (!(ABL & 1)) {
-                    // transpose (pair, k) -> lanes so that adjacent lanes carry adjacent dwords of a tap row (6 dwords:
-                    // two x-adjacent texels); one row of taps per half
-                    const int nent = min(64, n_items - r) * 6;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k)
-                            s_stage[lane * 7 + k] = make_uint2(toff[half * 6 + k], __float_as_uint(tval[half * 6 + k]));
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int it2 = 0; it2 < 6; ++it2) {
-                            const int ee = it2 * 64 + lane;
-                            if (ee < nent) {
-                                const uint2 sv = s_stage[(ee / 6) * 7 + (ee % 6)];
-                                const float v = __uint_as_float(sv.y);
-                                if (v != 0.f) unsafeAtomicAdd(dtex + sv.x, v);
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
+                    // Texture-gradient scatter of the cache misses.  Regular footprints (x1 = x0+1, y1 = y0+1) go to the
+                    // quad arrays: the 12 dwords of a pair are ONE aligned 48-byte run, and the (pair, k) -> lane transpose
+                    // below makes 12 adjacent lanes carry it, i.e. one memory-side request per footprint.  Clamped
+                    // footprints at face borders (rare) are scattered straight into dL_dtexture by the owning lane.
+                    uint32_t qbase = 0u;
+                    bool regular = false;
+                    int qface = -1;
+                    if (have && quads != nullptr) {
+                        const uint32_t o00 = toff[0] / 3u;                       // texel index (face*R + y0)*R + x0
+                        const int Rr = a.R;
+                        const int x0 = (int)(o00 % (uint32_t)Rr), yf = (int)(o00 / (uint32_t)Rr);
+                        const int y0 = yf % Rr, face = yf / Rr;
+                        regular = (toff[3] == toff[0] + 3u) && (toff[6] == toff[0] + 3u * (uint32_t)Rr) && (toff[9] == toff[6] + 3u);
+                        const int QW = (Rr >> 1) + 1;
+                        const int phase = (x0 & 1) | ((y0 & 1) << 1);
+                        qbase = (uint32_t)((((phase * 6 + face) * QW + (y0 >> 1)) * QW + (x0 >> 1)) * 16);
+                        if (regular) qface = face;
                     }
+                    if (quads != nullptr) {        // dirty-face word (last slot of the quad buffer): <= 6 atomics per wave overall
+                        uint32_t fm = 0u;
+#pragma unroll
+                        for (int f = 0; f < 6; ++f) fm |= (__ballot(qface == f) != 0ull) ? (1u << f) : 0u;
+                        const uint32_t fresh = fm & ~faces_marked;
+                        if (fresh != 0u && lane == 0) atomicOr(reinterpret_cast<uint32_t*>(quads) + a.quad_dirty_index, fresh);
+                        faces_marked |= fm;
+                    }
+                    if (have && !regular) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) { if (tval[k] != 0.f) unsafeAtomicAdd(dtex + toff[k], tval[k]); tval[k] = 0.f; }
+                    }
+                    s_sbase[lane] = qbase;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) s_sval[lane * 13 + k] = tval[k];
+                    __builtin_amdgcn_wave_barrier();
+                    const int nent = min(64, n_items - r) * 12;
+#pragma unroll
+                    for (int it2 = 0; it2 < 12; ++it2) {
+                        const int ee = it2 * 64 + lane;
+                        if (ee < nent) {
+                            const int pr = ee / 12, k = ee - pr * 12;
+                            const float v = s_sval[pr * 13 + k];
+                            if (v != 0.f) unsafeAtomicAdd(quads + s_sbase[pr] + k, v);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -559,6 +597,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             __builtin_amdgcn_wave_barrier();
         }
     }
+#if TC_ENABLE
     // flush the texel cache: thread -> dword, consecutive slots are consecutive texels of a row (coalesced atomics)
     __syncthreads();
     if (!(ABL & 1)) {
@@ -569,6 +608,45 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             if (tag != TC_EMPTY && v != 0.f) unsafeAtomicAdd(dtex + tag + ch, v);
         }
     }
+#endif
+}
+
+// Sum the four phase-shifted quad arrays into dL_dtexture[6,R,R,3] (+=: the LDS-cache flush and the clamped border
+// footprints are already there) and leave the quad arrays all-zero again, so a persistent scratch needs no memset.  Texel x receives slot px = (x - a) & 1 of quad (x - a) >> 1 of phase array a, a = 0,1.
+__global__ void __launch_bounds__(TG_BLOCK)
+k_texgrad_gather(int R, uint32_t dirty_index, float* __restrict__ quads, float* __restrict__ dtex) {
+    const int QW = (R >> 1) + 1;
+    // one workgroup = one 16x16-texel block of a face: every 64-byte quad line is consumed inside one workgroup
+    const int bpr = (R + 15) >> 4;                              // blocks per row
+    const int face = (int)(blockIdx.x / (uint32_t)(bpr * bpr));
+    const int brem = (int)(blockIdx.x % (uint32_t)(bpr * bpr));
+    const int x = ((brem % bpr) << 4) + (threadIdx.x & 15), y = ((brem / bpr) << 4) + (threadIdx.x >> 4);
+    if (x >= R || y >= R) return;
+    const size_t texel = ((size_t)face * R + y) * R + x;
+    const uint32_t dirty = reinterpret_cast<const uint32_t*>(quads)[dirty_index];
+    if (!((dirty >> face) & 1u)) return;                      // K7 never touched this face: its quads are still all-zero
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int dy = y - b;
+        if (dy < 0) continue;
+#pragma unroll
+        for (int a_ = 0; a_ < 2; ++a_) {
+            const int dx = x - a_;
+            if (dx < 0) continue;
+            const size_t q = ((((size_t)(a_ | (b << 1)) * 6 + face) * QW + (dy >> 1)) * QW + (dx >> 1)) * 16
+                           + (size_t)(((dy & 1) * 2 + (dx & 1)) * 3);
+            const float v0 = quads[q], v1 = quads[q + 1], v2 = quads[q + 2];
+            if (v0 != 0.f || v1 != 0.f || v2 != 0.f) {      // read-and-clear: each slot belongs to exactly one texel thread
+                s0 += v0; s1 += v1; s2 += v2;
+                quads[q] = 0.f; quads[q + 1] = 0.f; quads[q + 2] = 0.f;
+            }
+        }
+    }
+    if (s0 != 0.f || s1 != 0.f || s2 != 0.f) {
+        float* o = dtex + texel * 3;
+        o[0] += s0; o[1] += s1; o[2] += s2;
+    }
 }
 
 inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
@@ -578,6 +656,7 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
     a.ranges = reinterpret_cast<const uint2*>(b->ranges);
     a.point_list = b->point_list;
     a.tile_order = b->tile_order;
+    a.quad_dirty_index = (uint32_t)(tex_quads_floats(c.R) - 16);
     a.rec = reinterpret_cast<const float4*>(g->rec);
     a.texture = in->texture;
     a.bg = f->bg;
@@ -603,7 +682,7 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     const int grid = a.num_tiles;
     static const int abl = getenv("TEXGS_ABLATE") ? atoi(getenv("TEXGS_ABLATE")) : 0;
 #define LAUNCH_BWD(A) hipLaunchKernelGGL(k_render_bwd<A>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->final_T, img->n_contrib, \
-                       gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
+                       gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture, gr->tex_quads)
     switch (abl) {
         case 1: LAUNCH_BWD(1); break;
         case 2: LAUNCH_BWD(2); break;
@@ -623,3 +702,16 @@ extern "C" int texgs_debug_stats(unsigned long long* host16, int reset) {
     return 0;
 }
 #endif
+
+size_t tex_quads_floats(int R) {
+    const size_t QW = (size_t)(R >> 1) + 1;
+    return (size_t)4 * 6 * QW * QW * 16 + 16;      // + one 64-byte slot holding the dirty-face word
+}
+
+void launch_texgrad_gather(const CamConst& c, TexGSGrads* gr, hipStream_t s) {
+    const int bpr = (c.R + 15) >> 4;
+    const int blocks = 6 * bpr * bpr;
+    hipLaunchKernelGGL(k_texgrad_gather, dim3(blocks), dim3(TG_BLOCK), 0, s, c.R, (uint32_t)(tex_quads_floats(c.R) - 16),
+                       gr->tex_quads, gr->dL_dtexture);
+    (void)hipMemsetAsync(gr->tex_quads + (tex_quads_floats(c.R) - 16), 0, 64, s);      // leave the scratch all-zero
+}

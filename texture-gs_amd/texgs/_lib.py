@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtexgs.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 TILE = 16
 REC_FLOATS = 32
 ACC_FLOATS = 24
@@ -47,14 +47,15 @@ class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
                 ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
-                ("dL_dcolor_offset", _fp)]
+                ("dL_dcolor_offset", _fp), ("tex_quads", _fp)]
 
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-           "texgs_render_forward", "texgs_backward", "texgs_mark_visible", "texgs_profile_enable",
+           "texgs_render_forward", "texgs_backward", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_quads_floats",
            "texgs_profile_read"]
-KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd"]
+KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
+                "texgrad_gather"]
 
 _lib = None
 
@@ -76,6 +77,8 @@ def load():
     lib.texgs_scan_temp_bytes.argtypes = [C.c_int32]
     lib.texgs_sort_temp_bytes.restype = C.c_size_t
     lib.texgs_sort_temp_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.texgs_tex_quads_floats.restype = C.c_size_t
+    lib.texgs_tex_quads_floats.argtypes = [C.c_int32]
     lib.texgs_preprocess_forward.argtypes = [P(Frame), P(Inputs), P(Geom), C.c_void_p]
     lib.texgs_read_num_rendered.argtypes = [P(Geom), C.c_int32, P(C.c_uint32), C.c_void_p]
     lib.texgs_bin_sort_render_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), C.c_void_p]

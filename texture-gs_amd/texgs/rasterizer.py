@@ -14,6 +14,10 @@ from torch import nn
 from . import _lib
 
 
+import os as _os
+USE_TEX_QUADS = _os.environ.get("TEXGS_TEX_QUADS", "1") != "0"     # quad-layout texture-gradient scatter
+
+
 class GaussianRasterizationSettings(NamedTuple):
     """Field names and order = keywords at render/uv_tex_render.py:25-38."""
     image_height: int
@@ -42,6 +46,9 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
     return t.contiguous()
+
+
+_QUAD_SCRATCH = {}
 
 
 class _State:
@@ -193,10 +200,19 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha):
         d_uvs = torch.empty(N, 3, **f32)
         d_tex = torch.zeros(6, R, R, 3, **f32)
         d_coff = torch.empty(N, 3, **f32) if s.tensors["keep"][8] is not None else None
+        qkey = (device.index, R, stream)
+        quads = None
+        if USE_TEX_QUADS and R >= 4:
+            # persistent all-zero scratch per (device, R, stream): the library returns it all-zero (read-and-clear)
+            quads = _QUAD_SCRATCH.pop(qkey, None)
+            if quads is None:
+                quads = torch.zeros(lib.texgs_tex_quads_floats(R), **f32)
         grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(d_means3D), _ptr(d_means2D),
-                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff))
+                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff), _ptr(quads))
         _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                       C.byref(s.img), C.byref(grads), stream), "texgs_backward")
+    if quads is not None:
+        _QUAD_SCRATCH[qkey] = quads          # only re-cached after a successful call (an exception drops it)
     s.tensors["d_color_offset"] = d_coff
     return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, acc
 
