@@ -111,7 +111,8 @@ def main():
             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,
             viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev), sh_degree=3,
             campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
-    rasters = {v: GaussianRasterizer(settings(cams[v])) for v in my_views}
+    # fused gradient accumulation: the kernels add into the bucket slices (texgs.multiview), no AccumulateGrad pass
+    rasters = {v: GaussianRasterizer(settings(cams[v]), grad_sink=bucket) for v in my_views}
 
     # fixed upstream gradients of the synthetic loss' shape: image, alpha, norm
     g = torch.Generator().manual_seed(1234)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 3
+#define TEXGS_ABI_VERSION 4
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
@@ -123,6 +123,9 @@ typedef struct TexGSGrads {
                                   memory-side atomic request instead of ~2.7.  Summed into dL_dtexture by the
                                   gather kernel at the end of texgs_backward.  NULL = scatter straight into
                                   dL_dtexture.                                                              */
+    int32_t accumulate;        /* 0: K8 overwrites dL_dmeans3D..dL_duvs (and dL_dcolor_offset); 1: it ADDS into them
+                                  (fused gradient accumulation of a multi-view step; culled Gaussians write
+                                  nothing).  dL_dtexture is always accumulated into.                          */
 } TexGSGrads;
 
 int         texgs_abi_version(void);

@@ -201,3 +201,31 @@ def test_untextured_diff_gauss_surface(lib_built):
         for n in leaves:
             ok, msg = Hh.grad_close(leaves[n].grad.cpu(), ol[n].grad)
             assert ok, (mode, n, msg)
+
+
+def test_fused_grad_sink_equals_autograd_accumulation(lib_built):
+    """texgs.multiview fused accumulation (kernels add into the bucket) == plain autograd accumulation over 3 views."""
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from texgs.multiview import GradBucket
+    scene, _, deg, bg = _scene(CASES[0])
+    cams = synth.fibonacci_cameras(4, 256, 256)[:3]
+    dev = torch.device("cuda:0")
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
+    target, nhat = synth.make_targets(256, 256, seed=6)
+
+    def run(fused):
+        leaves = [getattr(scene, n).clone().to(dev).requires_grad_(True) for n in names]
+        m2 = torch.zeros(scene.means3D.shape[0], 3, device=dev, requires_grad=True)
+        bucket = GradBucket(leaves + [m2])
+        bucket.zero()
+        for cam in cams:
+            st = Hh.settings_for(cam, deg, bg, device=dev, cls=GaussianRasterizationSettings)
+            r = GaussianRasterizer(st, grad_sink=bucket if fused else None)
+            m3, shs, op, sc, rot, uv, tex = leaves
+            out = r(means3D=m3, means2D=m2, shs=shs, opacities=op, scales=sc, rotations=rot, uvs=uv,
+                    gradient_uvs=scene.gradient_uvs.to(dev), texture=tex, extra_attrs=None)
+            synth.synthetic_loss(out[0], out[3], out[2], target.to(dev), nhat.to(dev)).backward()
+        return bucket.flat.clone().cpu()
+    a, b = run(True), run(False)
+    assert float(b.abs().max()) > 0
+    assert Hh.rel_err(a, b) < 1e-4

@@ -308,7 +308,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  const float* __restrict__ acc,
                  float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
-                 float* __restrict__ d_uvs, float* __restrict__ d_coff) {
+                 float* __restrict__ d_uvs, float* __restrict__ d_coff, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K]: SH rows in, dL/dSH rows out
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
     const int K = C.sh_coeffs;
@@ -322,7 +322,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
         __syncthreads();
     }
     const bool visible = live && radii[i] > 0;
-    if (live && !visible) {
+    if (live && !visible && !accumulate) {
         d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
         d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
         d_op[i] = 0.f;
@@ -332,6 +332,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
         if (d_coff) d_coff[3 * i] = d_coff[3 * i + 1] = d_coff[3 * i + 2] = 0.f;
     }
     if (visible) {
+#define OUT(P, V) do { if (accumulate) (P) += (V); else (P) = (V); } while (0)
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     geo_forward(g, F, C, i, means, scales, rots, juv);
@@ -352,9 +353,9 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     for (int k = 0; k < 9; ++k) dR[k] = 0.f;
 
     // (1,2) pass-through
-    d_op[i] = A[R_OP];
-    d_uvs[3 * i + 0] = A[R_PHI]; d_uvs[3 * i + 1] = A[R_PHI + 1]; d_uvs[3 * i + 2] = A[R_PHI + 2];
-    if (d_coff) { d_coff[3 * i + 0] = A[R_VD]; d_coff[3 * i + 1] = A[R_VD + 1]; d_coff[3 * i + 2] = A[R_VD + 2]; }
+    OUT(d_op[i], A[R_OP]);
+    OUT(d_uvs[3 * i + 0], A[R_PHI]); OUT(d_uvs[3 * i + 1], A[R_PHI + 1]); OUT(d_uvs[3 * i + 2], A[R_PHI + 2]);
+    if (d_coff) { OUT(d_coff[3 * i + 0], A[R_VD]); OUT(d_coff[3 * i + 1], A[R_VD + 1]); OUT(d_coff[3 * i + 2], A[R_VD + 2]); }
 
     // (3) conic -> cov2D (a,b,c)
     const float dA = A[R_CONIC], dB = A[R_CONIC + 1], dC = A[R_CONIC + 2];
@@ -411,7 +412,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
 
     // (6) mean2D: record slot is dL/d(pixel xy); operator returns dL/d(ndc xy)
     const float dndx = A[R_XY] * 0.5f * (float)C.W, dndy = A[R_XY + 1] * 0.5f * (float)C.H;
-    d_means2D[3 * i + 0] = dndx; d_means2D[3 * i + 1] = dndy; d_means2D[3 * i + 2] = 0.f;
+    OUT(d_means2D[3 * i + 0], dndx); OUT(d_means2D[3 * i + 1], dndy); if (!accumulate) d_means2D[3 * i + 2] = 0.f;
     {
         const float dhx = dndx * g.pw, dhy = dndy * g.pw;
         const float dhw = -(dndx * g.hx + dndy * g.hy) * g.pw * g.pw;
@@ -486,22 +487,24 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     // (8) t = [m,1] @ V
 #pragma unroll
     for (int k = 0; k < 3; ++k) dm[k] += dt[0] * F.V[k * 4 + 0] + dt[1] * F.V[k * 4 + 1] + dt[2] * F.V[k * 4 + 2];
-    d_means[3 * i + 0] = dm[0]; d_means[3 * i + 1] = dm[1]; d_means[3 * i + 2] = dm[2];
-    d_scales[3 * i + 0] = dscale[0]; d_scales[3 * i + 1] = dscale[1]; d_scales[3 * i + 2] = dscale[2];
+    OUT(d_means[3 * i + 0], dm[0]); OUT(d_means[3 * i + 1], dm[1]); OUT(d_means[3 * i + 2], dm[2]);
+    OUT(d_scales[3 * i + 0], dscale[0]); OUT(d_scales[3 * i + 1], dscale[1]); OUT(d_scales[3 * i + 2], dscale[2]);
 
     // (5) R(q) -> q
     const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
-    d_rots[4 * i + 0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-    d_rots[4 * i + 1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
-    d_rots[4 * i + 2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
-    d_rots[4 * i + 3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    OUT(d_rots[4 * i + 0], 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]));
+    OUT(d_rots[4 * i + 1], 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]));
+    OUT(d_rots[4 * i + 2], 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]));
+    OUT(d_rots[4 * i + 3], 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]));
+#undef OUT
     }   // visible
     if (d_shs) {            // dL/dSH: zero rows for culled Gaussians / inactive degree, then one coalesced block store
         if (na == 0 || (live && !visible)) {
             if (live) for (int k = 0; k < row; ++k) s_sh[threadIdx.x * row + k] = 0.f;
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < count; k += TG_BLOCK) d_shs[first + k] = s_sh[k];
+        if (accumulate) { for (int k = threadIdx.x; k < count; k += TG_BLOCK) { const float v = s_sh[k]; if (v != 0.f) d_shs[first + k] += v; } }
+        else            { for (int k = threadIdx.x; k < count; k += TG_BLOCK) d_shs[first + k] = s_sh[k]; }
     }
 }
 
@@ -534,7 +537,7 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
-                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset);
+                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate);
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

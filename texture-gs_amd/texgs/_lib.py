@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtexgs.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TILE = 16
 REC_FLOATS = 32
 ACC_FLOATS = 24
@@ -47,7 +47,7 @@ class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
                 ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
-                ("dL_dcolor_offset", _fp), ("tex_quads", _fp)]
+                ("dL_dcolor_offset", _fp), ("tex_quads", _fp), ("accumulate", C.c_int32)]
 
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",

@@ -43,6 +43,13 @@ class GradBucket:
             self.slices.append((off, n))
             off += n
 
+    def sink_for(self, tensor):
+        """The bucket slice backing `tensor`'s gradient if `tensor` is one of the registered leaves, else None."""
+        for p, (off, n) in zip(self.params, self.slices):
+            if p is tensor:
+                return self.flat[off:off + n]
+        return None
+
     def zero(self):
         self.flat.zero_()
         for p, (off, n) in zip(self.params, self.slices):   # re-attach if something replaced .grad

@@ -6,6 +6,7 @@ PyTorch is plumbing here (device memory through the caching allocator, the curre
 bookkeeping); all arithmetic runs in the hand-written gfx950 kernels.
 """
 import ctypes as C
+import math
 from typing import NamedTuple, Optional
 
 import torch
@@ -172,8 +173,12 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     return (out_color, out_depth, out_norm, out_alpha, radii), s
 
 
-def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha):
-    """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture)."""
+def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None):
+    """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture, acc).
+
+    `sinks` (optional): dict name -> existing float32 gradient buffer of the input's shape.  If EVERY per-Gaussian
+    output has a sink the kernels ADD into them (fused multi-view accumulation, TexGSGrads.accumulate = 1); a texture
+    sink is used independently (dL_dtexture is always accumulated into).  Outputs written into a sink come back as None."""
     lib = _lib.load()
     means3D = s.tensors["keep"][0]
     device = means3D.device
@@ -191,15 +196,28 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha):
     dc, dd, dn, da = g(dL_dcolor, (3, H, W)), g(dL_ddepth, (1, H, W)), g(dL_dnorm, (3, H, W)), g(dL_dalpha, (1, H, W))
     with torch.cuda.device(device):
         acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
-        d_means3D = torch.empty(N, 3, **f32)
-        d_means2D = torch.empty(N, 3, **f32)
-        d_shs = torch.empty(N, K, 3, **f32) if K > 0 else None
-        d_op = torch.empty(N, 1, **f32)
-        d_scales = torch.empty(N, 3, **f32)
-        d_rot = torch.empty(N, 4, **f32)
-        d_uvs = torch.empty(N, 3, **f32)
-        d_tex = torch.zeros(6, R, R, 3, **f32)
-        d_coff = torch.empty(N, 3, **f32) if s.tensors["keep"][8] is not None else None
+        sinks = sinks or {}
+        has_coff = s.tensors["keep"][8] is not None
+        per_gauss = ["means3D", "means2D", "opacities", "scales", "rotations", "uvs"] + (["shs"] if K > 0 else []) \
+            + (["color_offset"] if has_coff else [])
+        fused = all(n in sinks for n in per_gauss)
+
+        def out(name, *shape):
+            if fused:
+                t = sinks[name]
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == math.prod(shape), name
+                return t
+            return torch.empty(*shape, **f32)
+        d_means3D = out("means3D", N, 3)
+        d_means2D = out("means2D", N, 3)
+        d_shs = out("shs", N, K, 3) if K > 0 else None
+        d_op = out("opacities", N, 1)
+        d_scales = out("scales", N, 3)
+        d_rot = out("rotations", N, 4)
+        d_uvs = out("uvs", N, 3)
+        d_coff = out("color_offset", N, 3) if has_coff else None
+        tex_sink = sinks.get("texture")
+        d_tex = tex_sink if tex_sink is not None else torch.zeros(6, R, R, 3, **f32)
         qkey = (device.index, R, stream)
         quads = None
         if USE_TEX_QUADS and R >= 4:
@@ -208,18 +226,29 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha):
             if quads is None:
                 quads = torch.zeros(lib.texgs_tex_quads_floats(R), **f32)
         grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(d_means3D), _ptr(d_means2D),
-                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff), _ptr(quads))
+                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff), _ptr(quads), 1 if fused else 0)
         _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                       C.byref(s.img), C.byref(grads), stream), "texgs_backward")
     if quads is not None:
         _QUAD_SCRATCH[qkey] = quads          # only re-cached after a successful call (an exception drops it)
+    if fused:
+        d_means3D = d_means2D = d_shs = d_op = d_scales = d_rot = d_uvs = d_coff = None
+    if tex_sink is not None:
+        d_tex = None
     s.tensors["d_color_offset"] = d_coff
     return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, acc
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None):
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None,
+                grad_sink=None):
+        ctx.sinks = None
+        if grad_sink is not None:        # fused accumulation: inputs that ARE registered leaves get their .grad slice
+            named = dict(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales,
+                         rotations=rotations, uvs=uvs, texture=texture, color_offset=color_offset)
+            ctx.sinks = {k: g for k, g in ((k, grad_sink.sink_for(v)) for k, v in named.items() if v is not None)
+                         if g is not None}
         outs, state = forward_raw(st, means3D.detach(), None if shs is None else shs.detach(),
                                   opacities.detach(), scales.detach(), rotations.detach(), uvs.detach(),
                                   gradient_uvs.detach(), texture.detach(),
@@ -235,18 +264,23 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, _dradii):
         s = ctx.state
         d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, _ = backward_raw(
-            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha)
+            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=ctx.sinks)
         d_coff = s.tensors.get("d_color_offset")
         ctx.state = None
-        return (d_means3D, d_means2D, d_shs, d_op.reshape(ctx.op_shape), d_scales, d_rot, d_uvs, None, d_tex, None, d_coff)
+        if d_op is not None:
+            d_op = d_op.reshape(ctx.op_shape)
+        return (d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, None, d_tex, None, d_coff, None)
 
 
 class GaussianRasterizer(nn.Module):
     """Same call surface as the reference's rasterizer (render/uv_tex_render.py:40,56-66)."""
 
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, grad_sink=None):
         super().__init__()
         self.raster_settings = raster_settings
+        # optional texgs.multiview.GradBucket: gradients of inputs that are its registered leaves are accumulated
+        # into the bucket by the kernels themselves (no autograd AccumulateGrad pass); not part of the reference API
+        self.grad_sink = grad_sink
 
     def markVisible(self, positions):
         """Frustum test only (lineage API; unused by the reference)."""
@@ -276,5 +310,5 @@ class GaussianRasterizer(nn.Module):
         if means2D is None:
             means2D = torch.zeros_like(means3D)
         color, depth, norm, alpha, radii = _RasterizeGaussians.apply(
-            means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st)
+            means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, None, self.grad_sink)
         return color, depth, norm, alpha, radii, None
