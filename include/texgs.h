@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 4
+#define TEXGS_ABI_VERSION 5
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
@@ -146,6 +146,15 @@ int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32
  * alpha-blend with cubemap fetch.  Second half of _C.rasterize_gaussians. */
 int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                                   TexGSBinning* bin, TexGSImage* img, void* stream);
+
+/* Whole forward in one call: texgs_preprocess_forward, the num_rendered readback, and -- when D fits `capacity`
+ * (the element count the caller sized keys/vals/point_list for; sort_temp_bytes >= texgs_sort_temp_bytes(capacity, T))
+ * -- texgs_bin_sort_render_forward, with no host work between the sync and the next launches.  Returns
+ * TEXGS_ERR_CAPACITY with *num_rendered_out = D when the buffers are too small: the caller grows them, sets
+ * bin->num_rendered = D and calls texgs_bin_sort_render_forward itself. */
+#define TEXGS_ERR_CAPACITY 1000
+int texgs_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, TexGSBinning* bin, uint32_t capacity,
+                  TexGSImage* img, uint32_t* num_rendered_out, void* stream);
 
 /* K6 alone on existing binning (re-render with a different texture / sh_degree-independent state). */
 int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,

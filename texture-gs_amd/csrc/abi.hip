@@ -142,6 +142,19 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     return texgs_render_forward(frame, in, geom, bin, img, stream);
 }
 
+int texgs_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, TexGSBinning* bin, uint32_t capacity,
+                  TexGSImage* img, uint32_t* num_rendered_out, void* stream) {
+    if (!num_rendered_out || !bin) return fail_msg("NULL argument");
+    if (int r = texgs_preprocess_forward(frame, in, geom, stream)) return r;
+    if (int r = texgs_read_num_rendered(geom, frame->num_gaussians, num_rendered_out, stream)) return r;
+    bin->num_rendered = *num_rendered_out;
+    if (*num_rendered_out > capacity) {
+        snprintf(g_err, sizeof(g_err), "num_rendered %u exceeds binning capacity %u", *num_rendered_out, capacity);
+        return TEXGS_ERR_CAPACITY;
+    }
+    return texgs_bin_sort_render_forward(frame, in, geom, bin, img, stream);
+}
+
 int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                    const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
     if (int r = validate_frame(frame)) return r;

@@ -667,7 +667,9 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
 
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
-    const PixArgs a = make_pix(c, f, in, g, b);
+    PixArgs a = make_pix(c, f, in, g, b);
+    static const int maxt_f = getenv("TEXGS_MAXTILES") ? atoi(getenv("TEXGS_MAXTILES")) : 0;   // timing experiments only
+    if (maxt_f > 0 && maxt_f < a.num_tiles) a.num_tiles = maxt_f;
     const int grid = a.num_tiles;
     static const int fabl = getenv("TEXGS_FWD_ABLATE") ? atoi(getenv("TEXGS_FWD_ABLATE")) : 0;
     if (fabl == 1) { hipLaunchKernelGGL(k_render_fwd<1>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
@@ -678,7 +680,9 @@ void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
 
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
-    const PixArgs a = make_pix(c, f, in, g, b);
+    PixArgs a = make_pix(c, f, in, g, b);
+    static const int maxt_b = getenv("TEXGS_MAXTILES") ? atoi(getenv("TEXGS_MAXTILES")) : 0;   // timing experiments only
+    if (maxt_b > 0 && maxt_b < a.num_tiles) a.num_tiles = maxt_b;
     const int grid = a.num_tiles;
     static const int abl = getenv("TEXGS_ABLATE") ? atoi(getenv("TEXGS_ABLATE")) : 0;
 #define LAUNCH_BWD(A) hipLaunchKernelGGL(k_render_bwd<A>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->final_T, img->n_contrib, \

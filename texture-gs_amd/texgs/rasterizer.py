@@ -50,6 +50,7 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
 
 
 _QUAD_SCRATCH = {}
+_CAPACITY_HINT = {}
 
 
 class _State:
@@ -134,23 +135,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         scan_temp = torch.empty(scan_bytes, dtype=torch.uint8, device=device)
         geom = _lib.Geom(_ptr(rec), _ptr(depth), _ptr(radii), _ptr(rect), _ptr(tiles_touched), _ptr(offsets),
                          _ptr(scan_temp), scan_bytes)
-        _lib.check(lib.texgs_preprocess_forward(C.byref(frame), C.byref(inputs), C.byref(geom), stream),
-                   "texgs_preprocess_forward")
-        d_host = C.c_uint32(0)
-        _lib.check(lib.texgs_read_num_rendered(C.byref(geom), N, C.byref(d_host), stream), "texgs_read_num_rendered")
-        D = int(d_host.value)
-        # binning buffers sized from D
-        keys_u = torch.empty(max(D, 1), dtype=torch.int64, device=device)
-        keys_s = torch.empty(max(D, 1), dtype=torch.int64, device=device)
-        vals_u = torch.empty(max(D, 1), **i32)
-        point_list = torch.empty(max(D, 1), **i32)
-        ranges = torch.zeros(tiles, 2, **i32)
-        tile_order = torch.empty(tiles, **i32)
-        order_keys = torch.empty(3 * tiles, **i32)
-        sort_bytes = lib.texgs_sort_temp_bytes(D, tiles)
-        sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
-        binning = _lib.Binning(D, _ptr(keys_u), _ptr(keys_s), _ptr(vals_u), _ptr(point_list), _ptr(ranges),
-                               _ptr(tile_order), _ptr(order_keys), _ptr(sort_temp), sort_bytes)
+        # everything is allocated BEFORE the one device->host sync, the D-sized buffers from a capacity hint
+        # (largest D seen on this device x 1.25): texgs_forward then runs K1 -> sync -> K3..K6 with no host work between
         out_color = torch.empty(3, H, W, **f32)
         out_depth = torch.empty(1, H, W, **f32)
         out_norm = torch.empty(3, H, W, **f32)
@@ -159,9 +145,37 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         n_contrib = torch.empty(H, W, **i32)
         img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), _ptr(final_T),
                          _ptr(n_contrib))
-        _lib.check(lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom),
-                                                     C.byref(binning), C.byref(img), stream),
-                   "texgs_bin_sort_render_forward")
+        ranges = torch.zeros(tiles, 2, **i32)
+        tile_order = torch.empty(tiles, **i32)
+        order_keys = torch.empty(3 * tiles, **i32)
+
+        def alloc_bin(cap):
+            keys_u = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
+            keys_s = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
+            vals_u = torch.empty(max(cap, 1), **i32)
+            point_list = torch.empty(max(cap, 1), **i32)
+            sort_bytes = lib.texgs_sort_temp_bytes(cap, tiles)
+            sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
+            b = _lib.Binning(0, _ptr(keys_u), _ptr(keys_s), _ptr(vals_u), _ptr(point_list), _ptr(ranges),
+                             _ptr(tile_order), _ptr(order_keys), _ptr(sort_temp), sort_bytes)
+            return b, (keys_u, keys_s, vals_u, point_list, sort_temp)
+        hint_key = (device.index, N, H, W)
+        cap = _CAPACITY_HINT.get(hint_key, max(4 * N, 1024))
+        binning, bin_t = alloc_bin(cap)
+        d_host = C.c_uint32(0)
+        rc = lib.texgs_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning), cap, C.byref(img),
+                               C.byref(d_host), stream)
+        D = int(d_host.value)
+        if rc == _lib.ERR_CAPACITY:             # rare: grow and run the second half
+            cap = int(D * 1.25) + 1024
+            binning, bin_t = alloc_bin(cap)
+            binning.num_rendered = D
+            rc = lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
+                                                   C.byref(img), stream)
+        _lib.check(rc, "texgs_forward")
+        _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
+        keys_u, keys_s, vals_u, point_list, sort_temp = bin_t
+        sort_bytes = binning.sort_temp_bytes
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
