@@ -195,10 +195,18 @@ def main():
                            "GBps": ab.get(name, 0) / (ms / cnt * 1e-3) / 1e9}
     dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"] * kinfo[k]["launches"]) if kinfo else None
     roofline = None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC pass of the same command (scripts/prof.sh)
+    if dom and args.workload == "c3" and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("traffic_bytes")
+        except Exception:
+            traffic = None
     if dom:
         ach = kinfo[dom]["GBps"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)" if traffic else None,
                     "alg_bytes_per_launch": ab[dom], "avg_launch_us": round(kinfo[dom]["avg_us"], 2)}
     view_bytes = sum(ab[k] for k in ab if (with_bwd or k not in ("render_bwd", "preprocess_bwd")))
 

@@ -229,3 +229,23 @@ def test_fused_grad_sink_equals_autograd_accumulation(lib_built):
     a, b = run(True), run(False)
     assert float(b.abs().max()) > 0
     assert Hh.rel_err(a, b) < 1e-4
+
+
+def test_mark_visible_and_capacity_regrow(lib_built):
+    """markVisible = the near-plane test of K1; and the forward's capacity-hint fast path re-grows when D exceeds it."""
+    from texgs import rasterizer as RZ
+    scene, cam, deg, bg = _scene(CASES[0])
+    dev = torch.device("cuda:0")
+    st = Hh.settings_for(cam, deg, bg, device=dev, cls=RZ.GaussianRasterizationSettings)
+    vis = RZ.GaussianRasterizer(st).markVisible(scene.means3D.to(dev)).cpu()
+    hom = torch.cat([scene.means3D, torch.ones(scene.means3D.shape[0], 1)], 1)
+    exp = (hom @ cam.world_view_transform)[:, 2] > 0.2
+    assert torch.equal(vis, exp)
+    outs_a, s_a = Hh.hip_debug_state(scene, cam, deg, bg)
+    key = (dev.index, scene.means3D.shape[0], cam.image_height, cam.image_width)
+    RZ._CAPACITY_HINT[key] = 16                      # force TEXGS_ERR_CAPACITY -> grow -> second half
+    outs_b, s_b = Hh.hip_debug_state(scene, cam, deg, bg)
+    assert s_b.D == s_a.D and RZ._CAPACITY_HINT[key] >= s_a.D
+    for x, y in zip(outs_a[:4], outs_b[:4]):
+        assert torch.equal(x, y)
+    assert torch.equal(s_a.tensors["point_list"][:s_a.D], s_b.tensors["point_list"][:s_b.D])
