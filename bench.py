@@ -17,6 +17,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +66,33 @@ def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched)
         "preprocess_bwd": N * (96 + 12 * K) + n_vis * 96 + N * (68 + 12 * K),
         "texgrad_gather": 0,      # an artefact of the scatter layout, no algorithmic traffic of its own
     }
+
+
+# ---- cpu_baseline leg: the ONLY place bench.py touches oracle/ (a CPU port of the operator, used as the reported
+# baseline; the reference has no CPU rasterizer).  Never on the measured GPU path.
+def cpu_baseline(scene, cam, W, H, with_bwd, budget_s=20.0):
+    from oracle import texgs_ref as CR
+    from oracle import texgs_torch as O
+    st = O.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                    torch.zeros(3), 1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center,
+                    False, False)
+    run = CR.RefRun(scene, st)
+    g = np.random.RandomState(1234)
+    dout = (g.randn(8, H, W) / (H * W)).astype(np.float32)
+    dout[3] = 0.0                                   # the bench's upstream grads: image, norm, alpha
+    views, t0 = 0, time.perf_counter()
+    while True:
+        run.forward()
+        if with_bwd:
+            run.backward(dout)
+        views += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or views >= 8:
+            break
+    return {"value": round(views / el, 4), "unit": "views/s", "cores": run.threads, "kind": "port",
+            "sample": f"{views} whole view(s) fwd{'+bwd' if with_bwd else ''} of the same scene/camera by oracle/texgs_ref.c "
+                      f"(gcc -O2 -fopenmp, fp32, {run.threads} OpenMP threads) in {el:.1f} s; D={run.D}",
+            "seconds_measured": round(el, 2)}
 
 
 def main():
@@ -212,7 +240,6 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from texgs_cpu_baseline import cpu_baseline   # bench-only helper at repo root; uses oracle/ as the checker's port
         cpu = cpu_baseline(scene, cams[my_views[0]], W, H, with_bwd)
 
     if rank == 0:

@@ -249,3 +249,18 @@ def test_mark_visible_and_capacity_regrow(lib_built):
     for x, y in zip(outs_a[:4], outs_b[:4]):
         assert torch.equal(x, y)
     assert torch.equal(s_a.tensors["point_list"][:s_a.D], s_b.tensors["point_list"][:s_b.D])
+
+
+def test_scale_modifier_matches_oracle(lib_built):
+    """scaling_modifier != 1 (utils/viewer_renderer.py:129 passes it through render/uv_tex_render.py:31)."""
+    scene, cam, deg, bg = _scene(CASES[0])
+    target, nhat = synth.make_targets(cam.image_height, cam.image_width, seed=9)
+    ref, dbg, gref = Hh.oracle_run(scene, cam, deg, bg, with_grad=True, target=target, nhat=nhat, scale_modifier=0.6)
+    out, ggot = Hh.hip_run(scene, cam, deg, bg, with_grad=True, target=target, nhat=nhat, scale_modifier=0.6)
+    amb = dbg["ambiguity"] < 1e-4
+    for k in (0, 2, 3):
+        err = (out[k].detach().cpu().double() - ref[k].double()).abs()[:, ~amb]
+        assert float(err.max()) < 1e-4, k
+    for name in ("scales", "means3D", "texture"):
+        ok, msg = Hh.grad_close(ggot[name], gref[name])
+        assert ok, (name, msg)
