@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 5
+#define TEXGS_ABI_VERSION 6
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
@@ -176,6 +176,15 @@ enum {
 };
 int texgs_profile_enable(int on);
 int texgs_profile_read(float* ms_sum_host, uint32_t* launches_host);
+
+/* Fused loss front-end for the operator's outputs -- the always-on terms of TextureGaussian3D.compute_loss
+ * (models/texture_gaussian3d.py:333-345; losses/pixelwise_loss.py l1_loss, losses/ssim_loss.py:16-54):
+ *   loss = (1-l)*mean|I-Igt| + l*(1 - mean SSIM_11x11(I,Igt)) + la*mean|A-Agt|.
+ * image/gt_image f32[3,H,W]; alpha/gt_alpha f32[1,H,W] or NULL (then dL_dalpha is untouched); scratch f32[9*H*W];
+ * sums f32[4] receives {sum|I-Igt|, sum SSIM, sum|A-Agt|, 0}; dL_dimage / dL_dalpha are written for d(loss) = 1. */
+int texgs_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha,
+                         int32_t H, int32_t W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums,
+                         float* dL_dimage, float* dL_dalpha, void* stream);
 
 /* Frustum test only (upstream API `markVisible`; unused by the reference). visible: u8[N]. */
 int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream);

@@ -8,6 +8,8 @@ no source) travel to the GPU box, the reference does not.
                (the module imports nvdiffrast and imageio at top level, absent here; throw-away empty module objects are
                registered under those names for the import only -- cube_to_dir itself is pure torch)
   losses.npz   losses/pixelwise_loss.py l1_loss and losses/ssim_loss.py ssim_loss on small random images
+  loss_frontend.npz  (1-l)*l1 + l*(1-ssim) + la*l1(alpha) with those functions AND their autograd gradients: the
+               fused HIP loss front-end (texgs.losses) is pinned against the reference itself
   op_small.npz the operator itself on a tiny seeded scene, as computed by oracle/texgs_torch.py in float64
                (regression pin of the oracle; the reference holds no vector for the operator: parity unpinned)
 """
@@ -84,6 +86,22 @@ def losses():
     b = torch.rand(3, 24, 20, generator=g)
     np.savez(os.path.join(HERE, "losses.npz"), a=a.numpy(), b=b.numpy(), l1=float(l1_loss(a, b)),
              ssim=float(ssim_loss(a, b)))
+    # the loss front-end of models/texture_gaussian3d.py:333-345 with the reference's own functions and autograd
+    out = {}
+    for tag, (H, W) in {"s": (40, 52), "m": (96, 80)}.items():
+        img = torch.rand(3, H, W, generator=g).requires_grad_(True)
+        gt = (torch.rand(3, H, W, generator=g) * 0.5 + 0.25 * img.detach()).clamp(0, 1)
+        alpha = torch.rand(1, H, W, generator=g).requires_grad_(True)
+        gta = (torch.rand(1, H, W, generator=g) > 0.4).float()
+        lam, la = 0.2, 0.1                              # configs/texture_gaussian3d.yaml lambda_dssim / lambda_alpha
+        Ll1 = l1_loss(img, gt)
+        Lssim = 1.0 - ssim_loss(img, gt)
+        loss = (1.0 - lam) * Ll1 + lam * Lssim + la * l1_loss(alpha, gta)
+        loss.backward()
+        out.update({f"{tag}_img": img.detach().numpy(), f"{tag}_gt": gt.numpy(), f"{tag}_alpha": alpha.detach().numpy(),
+                    f"{tag}_gta": gta.numpy(), f"{tag}_loss": float(loss), f"{tag}_l1": float(Ll1), f"{tag}_ssim": float(1.0 - Lssim),
+                    f"{tag}_dimg": img.grad.numpy(), f"{tag}_dalpha": alpha.grad.numpy(), "lam": lam, "la": la})
+    np.savez_compressed(os.path.join(HERE, "loss_frontend.npz"), **out)
 
 
 def op_small():

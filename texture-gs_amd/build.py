@@ -21,6 +21,7 @@ UNITS = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "render.hip": ["-munsafe-fp-atomics", "-ffp-contract=fast"],
+    "loss.hip": [],
     "abi.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "texgs.h")]

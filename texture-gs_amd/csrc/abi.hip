@@ -200,6 +200,18 @@ int texgs_profile_read(float* ms_sum_host, uint32_t* launches_host) {
     return 0;
 }
 
+int texgs_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha,
+                         int32_t H, int32_t W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums,
+                         float* dL_dimage, float* dL_dalpha, void* stream) {
+    if (!image || !gt_image || !scratch || !sums || !dL_dimage) return fail_msg("NULL argument");
+    if (H <= 0 || W <= 0) return fail_msg("image size must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    launch_rgb_alpha_loss(image, gt_image, alpha, gt_alpha, H, W, lambda_dssim, lambda_alpha, scratch, sums, dL_dimage,
+                          dL_dalpha, s);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("rgb_alpha_loss", e);
+}
+
 int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream) {
     if (int r = validate_frame(frame)) return r;
     if (!means3D || !visible) return fail_msg("NULL argument");

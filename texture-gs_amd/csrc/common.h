@@ -60,3 +60,6 @@ size_t tex_quads_floats(int R);
 void launch_texgrad_gather(const CamConst& c, TexGSGrads* gr, hipStream_t s);
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s);
+int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha, int H,
+                          int W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums, float* d_image,
+                          float* d_alpha, hipStream_t s);

@@ -1,0 +1,153 @@
+// Fused loss front-end for the operator's outputs: the always-on terms of
+// TextureGaussian3D.compute_loss (models/texture_gaussian3d.py:333-345):
+//     loss = (1 - l) * mean|I - I_gt|  +  l * (1 - mean SSIM(I, I_gt))  +  la * mean|A - A_gt|
+// SSIM as losses/ssim_loss.py:16-54: 11x11 Gaussian window (sigma 1.5, separable), zero padding 5, per channel,
+// C1 = 0.01^2, C2 = 0.03^2.  Two HBM-bound kernels, 16x16-pixel tiles with a 5-pixel halo staged in LDS:
+//   k_ssim_fwd   5 windowed moments -> SSIM value and its partials w.r.t. (mu1, E[x^2], E[xy]); block-reduced sums
+//   k_ssim_bwd   the same (symmetric) window applied to the 3 partial maps -> dL/dI; + the L1 sign terms
+// The reference does this with 5 depthwise conv2d calls + ~25 elementwise kernels and their autograd.
+#include "common.h"
+
+namespace {
+
+#define LT 16                   // tile
+#define LH 5                    // halo
+#define LW (LT + 2 * LH)        // 26
+
+struct Win { float w[11]; };
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    const float t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(256)
+k_ssim_fwd(int H, int W, Win win, const float* __restrict__ img, const float* __restrict__ gt,
+           float* __restrict__ part /* [3 maps][3 ch][H][W] */, float* __restrict__ sums) {
+    __shared__ float s_x[LW][LW + 1], s_y[LW][LW + 1];
+    __shared__ float s_h[5][LW][LT + 1];
+    __shared__ float s_red[4];
+    const int c = blockIdx.z, tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT;
+    const float* __restrict__ X = img + (size_t)c * H * W;
+    const float* __restrict__ Y = gt + (size_t)c * H * W;
+    for (int k = threadIdx.x; k < LW * LW; k += 256) {
+        const int r = k / LW, q = k % LW, yy = ty0 + r - LH, xx = tx0 + q - LH;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        s_x[r][q] = in ? X[(size_t)yy * W + xx] : 0.f;
+        s_y[r][q] = in ? Y[(size_t)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < LW * LT; k += 256) {        // horizontal pass
+        const int r = k / LT, q = k % LT;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const float x = s_x[r][q + t], y = s_y[r][q + t], w = win.w[t];
+            a += w * x; b += w * y; aa += w * x * x; bb += w * y * y; ab += w * x * y;
+        }
+        s_h[0][r][q] = a; s_h[1][r][q] = b; s_h[2][r][q] = aa; s_h[3][r][q] = bb; s_h[4][r][q] = ab;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, px = tx0 + lx, py = ty0 + ly;
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const float w = win.w[t];
+        mu1 += w * s_h[0][ly + t][lx]; mu2 += w * s_h[1][ly + t][lx]; e11 += w * s_h[2][ly + t][lx];
+        e22 += w * s_h[3][ly + t][lx]; e12 += w * s_h[4][ly + t][lx];
+    }
+    float ssim = 0.f, l1 = 0.f;
+    if (px < W && py < H) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+        const float inv = 1.f / (B1 * B2);
+        ssim = A1 * A2 * inv;
+        const size_t o = ((size_t)c * H + py) * W + px, plane = (size_t)3 * H * W;
+        part[o]             = 2.f * mu2 * (A2 - A1) * inv - ssim * 2.f * mu1 * (B2 - B1) * inv;   // dS/dmu1
+        part[plane + o]     = -ssim / B2;                                                        // dS/dE[x^2]
+        part[2 * plane + o] = 2.f * A1 * inv;                                                    // dS/dE[xy]
+        l1 = fabsf(s_x[ly + LH][lx + LH] - s_y[ly + LH][lx + LH]);
+    }
+    const float ts = block_sum(ssim, s_red), tl = block_sum(l1, s_red);
+    if (threadIdx.x == 0) { atomicAdd(sums + 0, tl); atomicAdd(sums + 1, ts); }
+}
+
+__global__ void __launch_bounds__(256)
+k_ssim_bwd(int H, int W, Win win, const float* __restrict__ img, const float* __restrict__ gt,
+           const float* __restrict__ part, float g_ssim, float g_l1, float* __restrict__ d_img) {
+    __shared__ float s_p[3][LW][LW + 1];
+    __shared__ float s_h[3][LW][LT + 1];
+    const int c = blockIdx.z, tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT;
+    const size_t plane = (size_t)3 * H * W;
+    for (int k = threadIdx.x; k < LW * LW; k += 256) {
+        const int r = k / LW, q = k % LW, yy = ty0 + r - LH, xx = tx0 + q - LH;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t o = ((size_t)c * H + yy) * W + xx;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) s_p[m][r][q] = in ? part[m * plane + o] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < LW * LT; k += 256) {
+        const int r = k / LT, q = k % LT;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) { const float w = win.w[t]; a0 += w * s_p[0][r][q + t]; a1 += w * s_p[1][r][q + t]; a2 += w * s_p[2][r][q + t]; }
+        s_h[0][r][q] = a0; s_h[1][r][q] = a1; s_h[2][r][q] = a2;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, px = tx0 + lx, py = ty0 + ly;
+    if (px >= W || py >= H) return;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) { const float w = win.w[t]; c0 += w * s_h[0][ly + t][lx]; c1 += w * s_h[1][ly + t][lx]; c2 += w * s_h[2][ly + t][lx]; }
+    const size_t o = ((size_t)c * H + py) * W + px;
+    const float x = img[o], y = gt[o];
+    const float sgn = (x > y) ? 1.f : ((x < y) ? -1.f : 0.f);
+    d_img[o] = g_ssim * (c0 + 2.f * x * c1 + y * c2) + g_l1 * sgn;
+}
+
+__global__ void __launch_bounds__(256)
+k_alpha_l1(int P, const float* __restrict__ a, const float* __restrict__ gt, float g, float* __restrict__ d_a,
+           float* __restrict__ sums) {
+    __shared__ float s_red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (i < P) {
+        const float d = a[i] - gt[i];
+        l = fabsf(d);
+        d_a[i] = g * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+    }
+    const float t = block_sum(l, s_red);
+    if (threadIdx.x == 0) atomicAdd(sums + 2, t);
+}
+
+}  // namespace
+
+// returns 0; sums[0..2] = sum|I-Igt|, sum SSIM, sum|A-Agt| (device); dL/dI and dL/dA are for d(loss) = 1
+int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha, int H,
+                          int W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums, float* d_image,
+                          float* d_alpha, hipStream_t s) {
+    Win win;
+    float tot = 0.f;
+    for (int k = 0; k < 11; ++k) { win.w[k] = expf(-(float)((k - 5) * (k - 5)) / (2.f * 1.5f * 1.5f)); tot += win.w[k]; }
+    for (int k = 0; k < 11; ++k) win.w[k] /= tot;
+    (void)hipMemsetAsync(sums, 0, 4 * sizeof(float), s);
+    const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, 3);
+    const float n = (float)(3 * (size_t)H * W);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, s, H, W, win, image, gt_image, scratch, sums);
+    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, s, H, W, win, image, gt_image, (const float*)scratch,
+                       -lambda_dssim / n, (1.f - lambda_dssim) / n, d_image);
+    if (alpha && gt_alpha && d_alpha) {
+        const int P = H * W;
+        hipLaunchKernelGGL(k_alpha_l1, dim3((P + 255) / 256), dim3(256), 0, s, P, alpha, gt_alpha, lambda_alpha / (float)P,
+                           d_alpha, sums);
+    }
+    return 0;
+}

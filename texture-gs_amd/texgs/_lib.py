@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtexgs.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ERR_CAPACITY = 1000
 TILE = 16
 REC_FLOATS = 32
@@ -53,7 +53,7 @@ class Grads(C.Structure):
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-           "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_quads_floats",
+           "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_quads_floats",
            "texgs_profile_read"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_gather"]
@@ -88,12 +88,15 @@ def load():
     lib.texgs_forward.restype = C.c_int
     lib.texgs_backward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), P(Grads), C.c_void_p]
     lib.texgs_mark_visible.argtypes = [P(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_rgb_alpha_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_rgb_alpha_loss.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]
     lib.texgs_profile_enable.restype = C.c_int
     lib.texgs_profile_read.argtypes = [P(C.c_float), P(C.c_uint32)]
     lib.texgs_profile_read.restype = C.c_int
     for name in ("texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-                 "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_mark_visible"):
+                 "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible"):
         getattr(lib, name).restype = C.c_int
     v = lib.texgs_abi_version()
     if v != ABI_VERSION:

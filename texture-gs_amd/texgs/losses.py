@@ -1,0 +1,58 @@
+"""Fused loss front-end: L1 + SSIM on the image and L1 on alpha, the always-on terms of
+TextureGaussian3D.compute_loss (models/texture_gaussian3d.py:333-345), as two HBM-bound HIP kernels instead of the
+reference's 5 depthwise conv2d + ~25 elementwise kernels and their autograd.  The gradient w.r.t. the rendered image /
+alpha is computed in the same pass and handed to autograd, i.e. straight to the rasterizer's backward."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class _RgbAlphaLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt_image, alpha, gt_alpha, lambda_dssim, lambda_alpha):
+        lib = _lib.load()
+        dev = image.device
+        if dev.type != "cuda":
+            raise RuntimeError("texgs.losses runs on an AMD GPU; there is no CPU fallback")
+        _, H, W = image.shape
+        img = image.detach().to(torch.float32).contiguous()
+        gt = gt_image.detach().to(torch.float32).contiguous()
+        if img.shape != gt.shape or img.shape[0] != 3:
+            raise ValueError("image and gt_image must both be [3,H,W]")
+        use_alpha = alpha is not None and gt_alpha is not None and lambda_alpha != 0.0
+        a = alpha.detach().to(torch.float32).contiguous() if use_alpha else None
+        ga = gt_alpha.detach().to(torch.float32).contiguous() if use_alpha else None
+        scratch = torch.empty(9 * H * W, dtype=torch.float32, device=dev)
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        d_img = torch.empty_like(img)
+        d_a = torch.empty_like(a) if use_alpha else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.texgs_rgb_alpha_loss(p(img), p(gt), p(a), p(ga), H, W, float(lambda_dssim), float(lambda_alpha),
+                                                p(scratch), p(sums), p(d_img), p(d_a),
+                                                torch.cuda.current_stream(dev).cuda_stream), "texgs_rgb_alpha_loss")
+        n = 3.0 * H * W
+        l1 = sums[0] / n
+        ssim = sums[1] / n
+        loss = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim)
+        la = None
+        if use_alpha:
+            la = sums[2] / (H * W)
+            loss = loss + lambda_alpha * la
+        ctx.save_for_backward(d_img, d_a if use_alpha else torch.empty(0, device=dev))
+        ctx.use_alpha = use_alpha
+        ctx.stats = dict(Ll1=l1, Lssim=1.0 - ssim, Lalpha=la)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_img, d_a = ctx.saved_tensors
+        return g * d_img, None, (g * d_a if ctx.use_alpha else None), None, None, None
+
+
+def rgb_alpha_loss(image, gt_image, alpha=None, gt_alpha=None, lambda_dssim=0.2, lambda_alpha=0.0):
+    """(1-l)*l1_loss(image, gt) + l*(1 - ssim_loss(image, gt)) [+ la*l1_loss(alpha, gt_alpha)] with the reference's
+    definitions (losses/pixelwise_loss.py, losses/ssim_loss.py:16-54); differentiable w.r.t. image and alpha."""
+    return _RgbAlphaLoss.apply(image, gt_image, alpha, gt_alpha, float(lambda_dssim), float(lambda_alpha))
