@@ -16,7 +16,7 @@ def window(size=11, sigma=1.5, dtype=torch.float64):
 
 def ssim(img1, img2):
     C = img1.shape[0]
-    w = window(dtype=img1.dtype)[None, None].expand(C, 1, 11, 11).contiguous()
+    w = window(dtype=img1.dtype)[None, None].expand(C, 1, 11, 11).contiguous().to(img1.device)
     x, y = img1[None], img2[None]
     conv = lambda t: F.conv2d(t, w, padding=5, groups=C)
     mu1, mu2 = conv(x), conv(y)
