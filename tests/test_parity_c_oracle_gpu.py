@@ -124,3 +124,52 @@ def test_size_independent_properties_full_size(lib_built):
     lens = (rg[:, 1] - rg[:, 0]).reshape((H + 15) // 16, (W + 15) // 16)
     per_px = lens.repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
     assert bool((nc <= per_px).all())
+
+
+def _stress_scene(N=20000, R=64, seed=3):
+    """Not the benchmark sphere: Gaussians scattered through a box that contains the camera (some behind it, some hugging
+    the near plane), scales over 3 decades (sub-pixel to screen-filling), random rotations / opacities, anisotropic."""
+    g = torch.Generator().manual_seed(seed)
+    means = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([8.0, 6.0, 10.0])
+    scales = torch.exp(torch.rand(N, 3, generator=g) * math.log(500.0) + math.log(0.001))
+    q = torch.randn(N, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    opac = torch.rand(N, 1, generator=g)
+    opac[::7] = 0.001                                          # never reach 1/255
+    uvs = torch.randn(N, 3, generator=g)
+    uvs = uvs / uvs.norm(dim=1, keepdim=True)
+    juv = torch.randn(N, 9, generator=g) * 0.5
+    return synth.Scene(means, scales, q, opac, 0.2 * torch.randn(N, 15, 3, generator=g), uvs, juv,
+                       torch.randn(6, R, R, 3, generator=g))
+
+
+def test_stress_scene_vs_c_oracle(lib_built):
+    from texgs.rasterizer import backward_raw
+    scene = _stress_scene()
+    cam = synth.look_at_camera((0.3, -0.2, -3.0), 640, 360, fovx=1.2)
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    ref = CR.RefRun(scene, Hh.settings_for(cam, 3, bg))
+    ref.forward()
+    outs, s = Hh.hip_debug_state(scene, cam, 3, bg)
+    N, D, t = ref.N, ref.D, s.tensors
+    assert D > 100000 and int((ref.radii[:N] == 0).sum()) > N // 10         # big lists AND many culled
+    assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
+    assert s.D == D
+    assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
+    assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
+    got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
+    err = (got - torch.tensor(ref.out)).abs()
+    scale = torch.ones(8, 1, 1); scale[3] = 10.0
+    assert float(((err > 1e-4 * scale).any(dim=0)).float().mean()) < 5e-3
+    assert float((err / scale).max()) < 5e-2
+    H, W = cam.image_height, cam.image_width
+    gen = torch.Generator().manual_seed(11)
+    dout = torch.randn(8, H, W, generator=gen) / (H * W)
+    dev = outs[0].device
+    res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(), dout[4:7].to(dev).contiguous(),
+                       dout[7:8].to(dev).contiguous())
+    gref = ref.backward(dout.numpy())
+    for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
+        assert bool(torch.isfinite(got_g).all()), name_
+        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.01, global_rel=5e-2)
+        assert ok, (name_, msg)
