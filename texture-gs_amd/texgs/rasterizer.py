@@ -175,13 +175,13 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         _lib.check(rc, "texgs_forward")
         _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
         keys_u, keys_s, vals_u, point_list, sort_temp = bin_t
-        sort_bytes = binning.sort_temp_bytes
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
     s.tensors = dict(keep=keep, rec=rec, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
                      offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s, vals_unsorted=vals_u,
-                     point_list=point_list, ranges=ranges, tile_order=tile_order, order_keys=order_keys, final_T=final_T, n_contrib=n_contrib,
+                     point_list=point_list, ranges=ranges, tile_order=tile_order, order_keys=order_keys,
+                     final_T=final_T, n_contrib=n_contrib,
                      scan_temp=scan_temp, sort_temp=sort_temp,
                      out=(out_color, out_depth, out_norm, out_alpha))
     return (out_color, out_depth, out_norm, out_alpha, radii), s
