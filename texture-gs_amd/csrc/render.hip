@@ -287,6 +287,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     __shared__ float s_sval_all[4][64 * 13];                  // 13 KB: 12 texture-gradient dwords per pair (+1 pad)
     __shared__ uint32_t s_sbase_all[4][64];                   // 1 KB: their base offset
     __shared__ float s_dpix[TG_BLOCK * 3];                    // 3 KB
+    __shared__ float4 s_recs_all[4][6 * 64];                  // 24 KB: the chunk's records, plane-major [k][lane]
 #if TC_ENABLE
     __shared__ uint32_t s_ttag[TC_SLOTS];                     // 8 KB
     __shared__ float s_tval[TC_SLOTS * 3];                    // 24 KB
@@ -305,6 +306,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
     const float* __restrict__ tex = a.texture;
     float4* s_items = s_items_all[wave];
     float* s_sval = s_sval_all[wave];
+    float4* s_recs = s_recs_all[wave];
     uint32_t* s_sbase = s_sbase_all[wave];
 
     float Tfin = 1.f; int last = 0;
@@ -341,6 +343,13 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
             const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
             r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5]; r6 = r[6];
         }
+        // stage A broadcasts from registers (v_readlane: no LDS latency in its dependent chain); stages B and C fetch the
+        // per-Gaussian fields from this LDS copy (stage C: 6 broadcast ds_read_b128 instead of ~29 v_readlane whose SGPR
+        // results collide with gfx9's one-SGPR-per-VALU constant-bus limit; stage B: per-lane gather instead of 16 ds_bpermute)
+        __builtin_amdgcn_wave_barrier();
+        s_recs[0 * 64 + lane] = r0; s_recs[1 * 64 + lane] = r1; s_recs[2 * 64 + lane] = r2v;
+        s_recs[3 * 64 + lane] = r3v; s_recs[4 * 64 + lane] = r4v; s_recs[5 * 64 + lane] = r5;
+        __builtin_amdgcn_wave_barrier();
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
         if (lane == 0) STAT(8, 1);                                      /* wave-chunks */
         const unsigned long long cull_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
@@ -397,14 +406,8 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 if (have) it = s_items[e * 3];
                 const uint32_t key = __float_as_uint(it.w);
                 const int pl = (int)(key >> 8) & 63, jj = (int)(key & 63u);
-                // the instance's record lives in lane jj's registers: cross-lane fetch through the LDS crossbar
-#define BP(V) __int_as_float(__builtin_amdgcn_ds_bpermute(jj << 2, __float_as_int(V)))
-                float4 q0, q1, r2, r3, r4;
-                q0.x = BP(r0.x); q0.y = BP(r0.y); q1.z = BP(r1.z); q1.w = BP(r1.w);
-                r2.x = BP(r2v.x); r2.y = BP(r2v.y); r2.z = BP(r2v.z); r2.w = BP(r2v.w);
-                r3.x = BP(r3v.x); r3.y = BP(r3v.y); r3.z = BP(r3v.z); r3.w = BP(r3v.w);
-                r4.x = BP(r4v.x); r4.y = BP(r4v.y); r4.z = BP(r4v.z); r4.w = BP(r4v.w);
-#undef BP
+                const float4 q0 = s_recs[0 * 64 + jj], q1 = s_recs[1 * 64 + jj], r2 = s_recs[2 * 64 + jj],
+                             r3 = s_recs[3 * 64 + jj], r4 = s_recs[4 * 64 + jj];
                 if (have) {
                     const float alpha = fminf(TG_ALPHA_MAX, it.y);
                     const float w = alpha * it.x;
@@ -549,14 +552,15 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 float part[32];
 #pragma unroll
                 for (int k = 0; k < 32; ++k) part[k] = 0.f;
-#define RL(V) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), jj))
+                const float4 c0 = s_recs[0 * 64 + jj], c1 = s_recs[1 * 64 + jj], c2 = s_recs[2 * 64 + jj],
+                             c3 = s_recs[3 * 64 + jj], c5 = s_recs[5 * 64 + jj];             // uniform address: LDS broadcast
                 if (ok) {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
                     const float4 i0 = s_items[(it0 + rank) * 3], i1 = s_items[(it0 + rank) * 3 + 1], i2 = s_items[(it0 + rank) * 3 + 2];
                     const float Ti = i0.x, araw = i0.y, qv = i0.z;
                     const float alpha = fminf(TG_ALPHA_MAX, araw);
-                    const float gx_ = RL(r0.x), gy_ = RL(r0.y), ca = RL(r0.z), cb = RL(r0.w), cc = RL(r1.x), op = RL(r1.y);
-                    const float dep = RL(r5.x), n0 = RL(r5.y), n1 = RL(r5.z), n2 = RL(r5.w);
+                    const float gx_ = c0.x, gy_ = c0.y, ca = c0.z, cb = c0.w, cc = c1.x, op = c1.y;
+                    const float dep = c5.x, n0 = c5.y, n1 = c5.z, n2 = c5.w;
                     const float dx = gx_ - pxf, dy = gy_ - pyf;
                     const float w = alpha * Ti;
                     const float s_i = qv + dep * dpix[3] + n0 * dpix[4] + n1 * dpix[5] + n2 * dpix[6] + dpix[7];
@@ -569,8 +573,8 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
                     const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
                     const float dpx = -dx, dpy = -dy;
-                    const float ggx = RL(r1.z), ggy = RL(r1.w);
-                    const float G00 = RL(r2v.x), G01 = RL(r2v.y), G10 = RL(r2v.z), G11 = RL(r2v.w), G20 = RL(r3v.x), G21 = RL(r3v.y);
+                    const float ggx = c1.z, ggy = c1.w;
+                    const float G00 = c2.x, G01 = c2.y, G10 = c2.z, G11 = c2.w, G20 = c3.x, G21 = c3.y;
                     part[R_XY]        = dL_dpower * gdx - ((G00 * dn0 + G10 * dn1 + G20 * dn2) + ggx * dden);
                     part[R_XY + 1]    = dL_dpower * gdy - ((G01 * dn0 + G11 * dn1 + G21 * dn2) + ggy * dden);
                     part[R_CONIC]     = -0.5f * dx * dx * dL_dpower;
