@@ -127,7 +127,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         f32 = dict(dtype=torch.float32, device=device)
         rec = torch.empty(max(N, 1), _lib.REC_FLOATS, **f32)
         depth = torch.empty(max(N, 1), **f32)
-        radii = torch.zeros(N, **i32)
+        radii = torch.empty(N, **i32)          # K1 writes every entry (0 for culled)
         rect = torch.empty(max(N, 1), 2, **i32)
         tiles_touched = torch.empty(max(N, 1), **i32)
         offsets = torch.empty(max(N, 1), **i32)
