@@ -21,13 +21,17 @@ __global__ void k(float* out) {
     }
     out[320 + l] = reduce_transposed<16>(a16, l) - ref16;
     out[384 + l] = reduce_transposed<32>(a32, l) - ref32;
+    {   float t32[32]; for (int i = 0; i < 32; ++i) t32[i] = a32[i];
+        float refb = 0; const int want = transposed_index(l);
+        for (int i = 0; i < 32; ++i) { float t = a32[i]; for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64); if (i == want) refb = t; }
+        out[448 + l] = reduce32_bankfirst(t32, l) - refb; }
 }
 int main() {
-    float* d; hipMalloc(&d, 448 * 4); hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
-    float h[448]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-    const char* names[7] = {"xor4", "xor8", "sum_xor16", "sum_xor32", "wave_sum", "reduce16T", "reduce32T"};
+    float* d; hipMalloc(&d, 512 * 4); hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
+    float h[512]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    const char* names[8] = {"xor4", "xor8", "sum_xor16", "sum_xor32", "wave_sum", "reduce16T", "reduce32T", "reduce32BF"};
     int bad = 0;
-    for (int t = 0; t < 7; ++t) { float m = 0; for (int l = 0; l < 64; ++l) m = fmaxf(m, fabsf(h[t * 64 + l])); printf("%-10s max|diff| %g\n", names[t], m); bad += m != 0.f; }
+    for (int t = 0; t < 8; ++t) { float m = 0; for (int l = 0; l < 64; ++l) m = fmaxf(m, fabsf(h[t * 64 + l])); printf("%-10s max|diff| %g\n", names[t], m); bad += m != 0.f; }
     printf(bad ? "FAIL\n" : "ALL OK\n");
     return bad;
 }

@@ -593,10 +593,12 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
 #undef RL
                 if (lane == 0) STAT(7, 1);                              /* stage C heavy iterations */
                 it0 += __popcll(bal);
-                const float tot = (ABL & 2) ? part[lane & 31] : reduce_transposed<32>(part, lane);
-                // accumulator slot k lives in lane k: 24 consecutive dwords of one row -> one coalesced request
+                // bank-first transposing butterfly (wave_ops.h): lane l < 32 ends with the wave total of slot transposed_index(l);
+                // the 24 slots are 24 consecutive dwords of one accumulator row -> one coalesced memory-side request
+                const int slot = transposed_index(lane);
+                const float tot = (ABL & 2) ? part[slot] : reduce32_bankfirst(part, lane);
                 const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)id, jj);
-                if (lane < TEXGS_ACC_FLOATS && tot != 0.f) unsafeAtomicAdd(acc + (size_t)idj * TEXGS_ACC_FLOATS + lane, tot);
+                if (lane < 32 && slot < TEXGS_ACC_FLOATS && tot != 0.f) unsafeAtomicAdd(acc + (size_t)idj * TEXGS_ACC_FLOATS + slot, tot);
             }
             __builtin_amdgcn_wave_barrier();
         }

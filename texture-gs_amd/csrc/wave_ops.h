@@ -94,3 +94,53 @@ __device__ __forceinline__ float reduce_transposed(float (&v)[NV], int lane) {
     }
     return sum_xor32(r);
 }
+
+
+// ---- bank-first variant ------------------------------------------------------------------------------------------
+// Same reduction, steps reordered so that the two widest ones (16 and 8 pairs) are the lane^4 and lane^8 exchanges:
+// their keep/send split coincides with DPP *banks* (groups of 4 lanes), so one pair costs two bank-masked
+// v_add_f32_dpp (banks {0,2} <- a + a[l+4], banks {1,3} <- b + b[l-4]) instead of 2 selects + 2 DPP moves + 1 add.
+// On return lane l (< 32; lanes 32..63 mirror them) holds the wave total of v[transposed_index(l)].
+__device__ __forceinline__ int transposed_index(int lane) {
+    return ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2) | (((lane >> 1) & 1) << 3) | (((lane >> 4) & 1) << 4);
+}
+
+__device__ __forceinline__ float pair_xor4(float a, float b) {
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float pair_xor8(float a, float b) {
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float reduce32_bankfirst(float (&v)[32], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b4 = lane & 16;
+    float a[16], b[8], c[4], d[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = pair_xor4(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = pair_xor8(a[2 * i], a[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b0 ? b[2 * i + 1] : b[2 * i], send = b0 ? b[2 * i] : b[2 * i + 1];
+        c[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b1 ? c[2 * i + 1] : c[2 * i], send = b1 ? c[2 * i] : c[2 * i + 1];
+        d[i] = keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    }
+    const float keep = b4 ? d[1] : d[0], send = b4 ? d[0] : d[1];
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_int(send), __float_as_int(send), false, false);
+    const float r = keep + (b4 ? __int_as_float(sw[0]) : __int_as_float(sw[1]));
+    return sum_xor32(r);
+}
