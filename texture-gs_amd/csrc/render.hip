@@ -99,8 +99,11 @@ struct PixArgs {
 //  ran at ~12 % lane efficiency; with LDS-staged records the LDS was 50 % busy and 22 % of wave time was LDS issue stall.)
 #define FQ_CAP 128
 
+#ifndef FWD_WAVES_PER_SIMD
+#define FWD_WAVES_PER_SIMD 8
+#endif
 template <int FABL>     // timing experiments only (0 = product): 1 skip the dense phase, 2 dense phase without loads
-__global__ void __launch_bounds__(TG_BLOCK)
+__global__ void __launch_bounds__(TG_BLOCK, FWD_WAVES_PER_SIMD)
 k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_norm,
              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     __shared__ uint2 s_qall[4][FQ_CAP];
