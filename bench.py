@@ -107,7 +107,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("TEXGS_FORCE_DIST") == "1" and "RANK" in os.environ   # 1-rank RCCL smoke of the N>1 code path
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -166,7 +167,7 @@ def main():
         for _ in range(args.views_per_step):
             one_view(my_views[cursor[0] % len(my_views)])
             cursor[0] += 1
-        if with_bwd and world > 1:
+        if with_bwd and dist is not None:
             bucket.all_reduce(dist)
 
     def fence():
