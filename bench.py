@@ -239,6 +239,25 @@ def main():
                     "alg_bytes_per_launch": ab[dom], "avg_launch_us": round(kinfo[dom]["avg_us"], 2)}
     view_bytes = sum(ab[k] for k in ab if (with_bwd or k not in ("render_bwd", "preprocess_bwd")))
 
+    # same-run measured HBM ceiling: device-to-device copy of 1 GiB, read + write bytes
+    hbm_measured = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            dst = torch.empty_like(src)
+            for _ in range(2):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            hbm_measured = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception:
+            hbm_measured = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(scene, cams[my_views[0]], W, H, with_bwd)
@@ -258,6 +277,7 @@ def main():
             "alg_bytes_per_view": view_bytes,
             "pipeline_GBps": round(view_bytes * value / world / 1e9, 2),
             "pipeline_frac_of_hbm_peak": round(view_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
+            "hbm_copy_ceiling_GBps_measured": hbm_measured,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in kinfo.items()},

@@ -677,12 +677,16 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
     PixArgs a = make_pix(c, f, in, g, b);
-    static const int maxt_f = getenv("TEXGS_MAXTILES") ? atoi(getenv("TEXGS_MAXTILES")) : 0;   // timing experiments only
+#ifdef TEXGS_EXPERIMENTS     // timing experiments (ablations, heaviest-K-tiles runs); never in the product build
+    static const int maxt_f = getenv("TEXGS_MAXTILES") ? atoi(getenv("TEXGS_MAXTILES")) : 0;
     if (maxt_f > 0 && maxt_f < a.num_tiles) a.num_tiles = maxt_f;
+#endif
     const int grid = a.num_tiles;
+#ifdef TEXGS_EXPERIMENTS
     static const int fabl = getenv("TEXGS_FWD_ABLATE") ? atoi(getenv("TEXGS_FWD_ABLATE")) : 0;
     if (fabl == 1) { hipLaunchKernelGGL(k_render_fwd<1>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
     if (fabl == 2) { hipLaunchKernelGGL(k_render_fwd<2>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm, img->out_alpha, img->final_T, img->n_contrib); return; }
+#endif
     hipLaunchKernelGGL(k_render_fwd<0>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->out_color, img->out_depth, img->out_norm,
                        img->out_alpha, img->final_T, img->n_contrib);
 }
@@ -690,12 +694,15 @@ void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     PixArgs a = make_pix(c, f, in, g, b);
-    static const int maxt_b = getenv("TEXGS_MAXTILES") ? atoi(getenv("TEXGS_MAXTILES")) : 0;   // timing experiments only
+#ifdef TEXGS_EXPERIMENTS
+    static const int maxt_b = getenv("TEXGS_MAXTILES") ? atoi(getenv("TEXGS_MAXTILES")) : 0;
     if (maxt_b > 0 && maxt_b < a.num_tiles) a.num_tiles = maxt_b;
+#endif
     const int grid = a.num_tiles;
-    static const int abl = getenv("TEXGS_ABLATE") ? atoi(getenv("TEXGS_ABLATE")) : 0;
 #define LAUNCH_BWD(A) hipLaunchKernelGGL(k_render_bwd<A>, dim3(grid), dim3(TG_BLOCK), 0, s, a, img->final_T, img->n_contrib, \
                        gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture, gr->tex_quads)
+#ifdef TEXGS_EXPERIMENTS
+    static const int abl = getenv("TEXGS_ABLATE") ? atoi(getenv("TEXGS_ABLATE")) : 0;
     switch (abl) {
         case 1: LAUNCH_BWD(1); break;
         case 2: LAUNCH_BWD(2); break;
@@ -705,6 +712,9 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
         case 11: LAUNCH_BWD(11); break;
         default: LAUNCH_BWD(0); break;
     }
+#else
+    LAUNCH_BWD(0);
+#endif
 #undef LAUNCH_BWD
 }
 
