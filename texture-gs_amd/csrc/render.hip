@@ -389,7 +389,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                 seg_mask |= jbit;
                 if (lane == j) { touched_lo = (uint32_t)bal; touched_hi = (uint32_t)(bal >> 32); }
                 if (ok) {
-                    T = T / (1.0f - alpha);
+                    T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     s_items[(n_items + rank) * 3] = make_float4(T, araw, 0.f, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
@@ -569,7 +569,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     const float s_i = qv + dep * dpix[3] + n0 * dpix[4] + n1 * dpix[5] + n2 * dpix[6] + dpix[7];
                     suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
                     last_s = s_i; last_alpha = alpha;
-                    const float dL_dalpha_ = (s_i - suffix) * Ti + (-Tfin / (1.0f - alpha)) * bgdot;
+                    const float dL_dalpha_ = (s_i - suffix) * Ti - Tfin * __builtin_amdgcn_rcpf(1.0f - alpha) * bgdot;
                     const float dL_dpower = araw * dL_dalpha_;        // straight through the 0.99 clamp (lineage)
                     const float gdx = -(ca * dx + cb * dy), gdy = -(cc * dy + cb * dx);
                     // uv path (stage B results): dn = du * inv, dp = pix - xy
@@ -583,7 +583,7 @@ k_render_bwd(PixArgs a, const float* __restrict__ final_T, const uint32_t* __res
                     part[R_CONIC]     = -0.5f * dx * dx * dL_dpower;
                     part[R_CONIC + 1] = -dx * dy * dL_dpower;
                     part[R_CONIC + 2] = -0.5f * dy * dy * dL_dpower;
-                    part[R_OP]        = (araw / op) * dL_dalpha_;
+                    part[R_OP]        = araw * __builtin_amdgcn_rcpf(op) * dL_dalpha_;
                     part[R_G2] = dden * dpx; part[R_G2 + 1] = dden * dpy;
                     part[R_GM + 0] = dn0 * dpx; part[R_GM + 1] = dn0 * dpy;
                     part[R_GM + 2] = dn1 * dpx; part[R_GM + 3] = dn1 * dpy;
