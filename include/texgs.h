@@ -186,6 +186,11 @@ int texgs_rgb_alpha_loss(const float* image, const float* gt_image, const float*
                          int32_t H, int32_t W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums,
                          float* dL_dimage, float* dL_dalpha, void* stream);
 
+/* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
+ * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,
+ * nine blocks of 64 differences against the __shfl_xor formulation -- all exactly 0 on gfx950. */
+int texgs_selftest_waveops(const float* seed128, float* out576, void* stream);
+
 /* Frustum test only (upstream API `markVisible`; unused by the reference). visible: u8[N]. */
 int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream);
 

@@ -1,5 +1,7 @@
 """Shared helpers for the parity tests: build identical inputs for the HIP operator and the oracle."""
+import json
 import math
+import os
 
 import torch
 
@@ -75,13 +77,42 @@ def hip_debug_state(scene, cam, sh_degree, bg):
     return outs, s
 
 
+_REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+
+
+def report(label, **metrics):
+    """Print (visible with `pytest -rA`) and append to gpurun_out/parity_report.jsonl the MEASURED error of a parity
+    check, so that the slack inside the tolerances is on record (copied to profiles/ per round)."""
+    line = dict(check=label, **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in metrics.items()})
+    print("PARITY", json.dumps(line))
+    try:
+        os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+        with open(_REPORT, "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+
+
+def forward_errors(label, got, exp, amb=None, names=("image", "depth", "norm", "alpha")):
+    """Per-output max abs error on unambiguous / all pixels; reported, returned as {name: (clean_max, all_max)}."""
+    res = {}
+    for k, name in enumerate(names):
+        err = (got[k].detach().cpu().double() - exp[k].double()).abs()
+        clean = err if amb is None else err[:, ~amb]
+        res[name] = (float(clean.max()) if clean.numel() else 0.0, float(err.max()))
+    report(label, **{f"{n}_max_err_unambiguous": v[0] for n, v in res.items()},
+           **{f"{n}_max_err_all": v[1] for n, v in res.items()},
+           ambiguous_pixel_frac=(0.0 if amb is None else float(amb.float().mean())))
+    return res
+
+
 def rel_err(a, b):
     a = a.double().reshape(-1)
     b = b.double().reshape(-1)
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=0.005, global_rel=2e-2):
+def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=0.005, global_rel=2e-2, label=None):
     """Robust gradient comparison.  fp32 (HIP) vs fp64 (oracle) differ by isolated discrete events -- a
     bilinear cell chosen differently for one (pixel, Gaussian) pair changes that pair's dL/duv by O(1), a
     1/255 or clamp threshold decided differently adds or removes one pair -- so a handful of rows may be off
@@ -103,4 +134,9 @@ def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=0.0
     budget = max(int(max_outlier_frac * g.shape[0]), 20)    # ~13 cell flips per 256x256 image are expected
     rel = float((g - e).norm() / e.norm())
     ok = (nbad <= budget) and (rel <= global_rel)
+    good = err <= tol
+    rel_clean = float((g[good] - e[good]).norm() / e[good].norm().clamp_min(1e-300)) if bool(good.any()) else 0.0
+    if label is not None:
+        report(label, rows=g.shape[0], outlier_rows=nbad, outlier_budget=budget, global_rel_l2=rel,
+               rel_l2_without_outliers=rel_clean, max_row_err_over_gmax=float(err.max()) / gmax, ok=bool(ok))
     return ok, f"outlier rows {nbad} (budget {budget} of {g.shape[0]}), global rel L2 {rel:.3e} (max {global_rel})"

@@ -7,12 +7,13 @@ from texgs import synth
 from oracle import texgs_ref as CR
 import helpers as Hh
 
-CASES = [(600, 32, 96, 80, 0.05, 3, 1, (0.1, 0.2, 0.3)), (300, 16, 64, 48, 0.08, 1, 3, (0.0, 0.5, 0.0))]
+CASES = [(600, 32, 96, 80, 0.05, 3, 1, (0.1, 0.2, 0.3)), (300, 16, 64, 48, 0.08, 1, 3, (0.0, 0.5, 0.0)),
+         (500, 32, 96, 80, 0.05, 2, 2, (0.0, 0.1, 0.2), True)]       # last: non-symmetric UV Jacobians
 
 
 def _scene(case):
-    N, R, W, H, sm, deg, view, bg = case
-    return synth.make_scene(N, R, seed=N + R, scale_mean=sm), synth.fibonacci_cameras(4, W, H)[view], deg, torch.tensor(bg)
+    N, R, W, H, sm, deg, view, bg = case[:8]
+    return synth.make_scene(N, R, seed=N + R, scale_mean=sm, random_jacobian=len(case) > 8 and case[8]), synth.fibonacci_cameras(4, W, H)[view], deg, torch.tensor(bg)
 
 
 def test_c_forward_matches_torch_oracle():

@@ -75,9 +75,12 @@ def test_forward_full_size_vs_c_oracle(lib_built, name):
     err = (got - exp).abs()
     scale = torch.ones(8, 1, 1); scale[3] = 4.0
     bad = (err > 1e-4 * scale).any(dim=0)
+    nc = s.tensors["n_contrib"].cpu().numpy().astype(np.uint32)
+    Hh.report(f"hip_vs_c32/{name}/fwd", pixels_over_1e4th_frac=float(bad.float().mean()), worst_pixel=float((err / scale).max()),
+              median_err=float(err.median()), p999_err=float(err.flatten().kthvalue(int(0.999 * err.numel())).values),
+              n_contrib_agree_frac=float((nc == ref.n_contrib).mean()))
     assert float(bad.float().mean()) < 2e-3, float(bad.float().mean())
     assert float((err / scale).max()) < 2e-2
-    nc = s.tensors["n_contrib"].cpu().numpy().astype(np.uint32)
     assert float((nc == ref.n_contrib).mean()) > 0.998
 
 
@@ -94,7 +97,7 @@ def test_backward_full_size_vs_c_oracle(lib_built, name):
     gref = ref.backward(dout.numpy())
     names = ["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
     for name_, got in zip(names, res[:8]):
-        ok, msg = Hh.grad_close(got.cpu(), torch.tensor(gref[name_]))
+        ok, msg = Hh.grad_close(got.cpu(), torch.tensor(gref[name_]), label=f"hip_vs_c32/{name}/bwd/{name_}")
         assert ok, (name_, msg)
 
 
@@ -171,5 +174,6 @@ def test_stress_scene_vs_c_oracle(lib_built):
     gref = ref.backward(dout.numpy())
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
         assert bool(torch.isfinite(got_g).all()), name_
-        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.01, global_rel=5e-2)
+        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.01, global_rel=5e-2,
+                                label=f"hip_vs_c32/stress/bwd/{name_}")
         assert ok, (name_, msg)

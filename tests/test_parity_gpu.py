@@ -20,12 +20,15 @@ CASES = [
     (1000, 64, 256, 256, 0.03, 0, 2, (0.0, 0.0, 0.0)),
     (4000, 128, 200, 136, 0.02, 2, 0, (1.0, 1.0, 1.0)),     # W, H not multiples of 16
     (300, 16, 64, 48, 0.08, 1, 3, (0.0, 0.5, 0.0)),         # large splats, tiny texture
+    # non-symmetric UV Jacobians (a trained UVNet's): a transposed [3*i+j] layout cannot hide behind J = J^T
+    (1500, 64, 256, 192, 0.03, 3, 2, (0.2, 0.1, 0.0), True),
+    (4000, 128, 200, 136, 0.02, 1, 1, (0.0, 0.0, 0.0), True),
 ]
 
 
 def _scene(case):
-    N, R, W, H, sm, deg, view, bg = case
-    scene = synth.make_scene(N, R, seed=N + R, scale_mean=sm)
+    N, R, W, H, sm, deg, view, bg = case[:8]
+    scene = synth.make_scene(N, R, seed=N + R, scale_mean=sm, random_jacobian=len(case) > 8 and case[8])
     cam = synth.fibonacci_cameras(4, W, H)[view]
     return scene, cam, deg, torch.tensor(bg, dtype=torch.float32)
 
@@ -39,6 +42,7 @@ def test_forward_matches_oracle(lib_built, case):
     frac = float(amb.float().mean())
     assert frac < 0.01, f"too many ambiguous pixels: {frac}"
     names = ["image", "depth", "norm", "alpha"]
+    Hh.forward_errors(f"hip_vs_torch64/fwd/{case[:4]}{'/randJ' if len(case) > 8 else ''}", out, ref, amb)
     for k, name in enumerate(names):
         got = out[k].detach().cpu().double()
         exp = ref[k].double()
@@ -54,7 +58,7 @@ def test_forward_matches_oracle(lib_built, case):
     assert out[5] is None
 
 
-@pytest.mark.parametrize("case", CASES[:3])
+@pytest.mark.parametrize("case", CASES[:3] + CASES[4:])
 def test_backward_matches_oracle_autograd(lib_built, case):
     scene, cam, deg, bg = _scene(case)
     target, nhat = synth.make_targets(cam.image_height, cam.image_width, seed=5)
@@ -63,29 +67,52 @@ def test_backward_matches_oracle_autograd(lib_built, case):
     for name, exp in gref.items():
         if exp is None:
             continue
-        ok, msg = Hh.grad_close(ggot[name], exp)
+        ok, msg = Hh.grad_close(ggot[name], exp, label=f"hip_vs_torch64/bwd/{case[:4]}{'/randJ' if len(case) > 8 else ''}/{name}")
         assert ok, (name, msg)
+
+
+def _tile_lists(point_list, ranges, drop):
+    """{tile: [Gaussian ids in list order]} without the ids in `drop`."""
+    pl = point_list.tolist()
+    out = {}
+    for t, (a, b) in enumerate(ranges.tolist()):
+        if b > a:
+            out[t] = [i for i in pl[a:b] if i not in drop]
+    return out
 
 
 def test_integer_stages_vs_oracle(lib_built):
     """tiles_touched / offsets / sorted point list / ranges / n_contrib against the float64 oracle.  (The
-    bit-exact check against the fp32 C oracle lives in test_parity_c_oracle_gpu.py.)"""
+    bit-exact check against the fp32 C oracle lives in test_parity_c_oracle_gpu.py.)  fp32 vs fp64 may round the
+    radius of a Gaussian differently (ceil(3 sqrt(lambda)) at an integer): such Gaussians are REMOVED from both
+    sides and every assertion still runs on the rest -- nothing is skipped."""
     scene, cam, deg, bg = _scene(CASES[0])
     ref, dbg, _ = Hh.oracle_run(scene, cam, deg, bg)
     outs, s = Hh.hip_debug_state(scene, cam, deg, bg)
     pre, binning = dbg["pre"], dbg["binning"]
     tt = s.tensors["tiles_touched"].cpu().to(torch.int64)
-    bad = int((tt != pre["tiles"]).sum())
-    assert bad <= 2, bad
-    if bad == 0:
-        assert s.D == binning["D"]
+    mism = torch.nonzero(tt != pre["tiles"]).reshape(-1).tolist()
+    assert len(mism) <= 2, mism
+    drop = set(mism)
+    D = s.D
+    assert D - int(tt[mism].sum()) == binning["D"] - int(pre["tiles"][mism].sum())
+    got = _tile_lists(s.tensors["point_list"][:D].cpu(), s.tensors["ranges"].cpu(), drop)
+    exp = _tile_lists(binning["point_list"], binning["ranges"], drop)
+    assert got.keys() == exp.keys()
+    same_order = 0
+    for t in exp:
+        assert sorted(got[t]) == sorted(exp[t]), t                  # same Gaussians in every tile
+        same_order += got[t] == exp[t]
+    # depth ties / fp32-vs-fp64 depth rounding can swap neighbours inside a tile: order identical in >= 98 % of tiles
+    assert same_order >= 0.98 * len(exp), (same_order, len(exp))
+    if not mism:
         assert torch.equal(s.tensors["offsets"].cpu().to(torch.int64), binning["offsets"])
-        pl = s.tensors["point_list"][:s.D].cpu().to(torch.int64)
-        # depth ties / fp32-vs-fp64 depth rounding can swap neighbours: compare as per-tile multisets + mostly equal
-        assert float((pl == binning["point_list"]).float().mean()) > 0.99
         assert torch.equal(s.tensors["ranges"].cpu().to(torch.int64), binning["ranges"])
-        nc = s.tensors["n_contrib"].cpu().to(torch.int64)
-        assert float((nc == dbg["n_contrib"]).float().mean()) > 0.995
+    nc = s.tensors["n_contrib"].cpu().to(torch.int64)
+    agree = float((nc == dbg["n_contrib"]).float().mean())
+    Hh.report("hip_vs_torch64/integer_stages", radius_mismatches=len(mism), tiles=len(exp),
+              tiles_with_identical_order=same_order, n_contrib_agree_frac=agree)
+    assert agree > 0.995 - 0.02 * len(mism)
 
 
 def test_empty_and_culled_inputs(lib_built):
@@ -156,7 +183,7 @@ def test_matches_committed_golden_fixture(lib_built):
         assert float(err.max()) < (4e-4 if name == "depth" else 1e-4), (name, float(err.max()))
     assert np.array_equal(out[4].cpu().numpy(), d["radii"])
     for name in ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture", "means2D"]:
-        ok, msg = Hh.grad_close(g[name], torch.tensor(d["grad_" + name]))
+        ok, msg = Hh.grad_close(g[name], torch.tensor(d["grad_" + name]), label=f"hip_vs_golden_op_small/bwd/{name}")
         assert ok, (name, msg)
 
 
@@ -262,5 +289,5 @@ def test_scale_modifier_matches_oracle(lib_built):
         err = (out[k].detach().cpu().double() - ref[k].double()).abs()[:, ~amb]
         assert float(err.max()) < 1e-4, k
     for name in ("scales", "means3D", "texture"):
-        ok, msg = Hh.grad_close(ggot[name], gref[name])
+        ok, msg = Hh.grad_close(ggot[name], gref[name], label=f"hip_vs_torch64/scale_modifier0.6/bwd/{name}")
         assert ok, (name, msg)

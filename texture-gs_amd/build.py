@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libtexgs.so")
+LIB = os.path.join(HERE, os.environ.get("TEXGS_LIB_NAME", "libtexgs.so"))     # TEXGS_LIB_NAME: experiment builds
+OBJ = os.path.join(HERE, os.environ.get("TEXGS_OBJ_DIR", "build"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
@@ -22,6 +23,7 @@ UNITS = {
     "binning.hip": [],
     "render.hip": ["-munsafe-fp-atomics", "-ffp-contract=fast"],
     "loss.hip": [],
+    "selftest.hip": [],
     "abi.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "texgs.h")]

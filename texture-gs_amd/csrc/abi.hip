@@ -212,6 +212,13 @@ int texgs_rgb_alpha_loss(const float* image, const float* gt_image, const float*
     return e == hipSuccess ? 0 : fail("rgb_alpha_loss", e);
 }
 
+int texgs_selftest_waveops(const float* seed128, float* out576, void* stream) {
+    if (!seed128 || !out576) return fail_msg("NULL argument");
+    launch_selftest_waveops(seed128, out576, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("selftest_waveops", e);
+}
+
 int texgs_mark_visible(const TexGSFrame* frame, const float* means3D, uint8_t* visible, void* stream) {
     if (int r = validate_frame(frame)) return r;
     if (!means3D || !visible) return fail_msg("NULL argument");

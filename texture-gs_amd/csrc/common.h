@@ -63,3 +63,4 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
 int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha, int H,
                           int W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums, float* d_image,
                           float* d_alpha, hipStream_t s);
+void launch_selftest_waveops(const float* seed128, float* out576, hipStream_t s);

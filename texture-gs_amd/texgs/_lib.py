@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libtexgs.so")
+LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
 ABI_VERSION = 6
 ERR_CAPACITY = 1000
@@ -54,7 +54,7 @@ class Grads(C.Structure):
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_quads_floats",
-           "texgs_profile_read"]
+           "texgs_profile_read", "texgs_selftest_waveops"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_gather"]
 
@@ -91,6 +91,8 @@ def load():
     lib.texgs_rgb_alpha_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                          C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_rgb_alpha_loss.restype = C.c_int
+    lib.texgs_selftest_waveops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_selftest_waveops.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]
     lib.texgs_profile_enable.restype = C.c_int
     lib.texgs_profile_read.argtypes = [P(C.c_float), P(C.c_uint32)]

@@ -44,10 +44,22 @@ class GradBucket:
             off += n
 
     def sink_for(self, tensor):
-        """The bucket slice backing `tensor`'s gradient if `tensor` is one of the registered leaves, else None."""
+        """The bucket slice backing `tensor`'s gradient if `tensor` is one of the registered leaves AND its .grad still
+        aliases that slice, else None (autograd then delivers the gradient the normal way).
+
+        `optimizer.zero_grad(set_to_none=True)` -- the PyTorch default and what the reference's optimize_step does
+        (models/texture_gaussian3d.py:442-444) -- sets p.grad = None: the slice is then zeroed and re-attached (the
+        semantics of "no gradient yet"), so kernels that accumulate into it are never writing into a buffer the
+        optimizer no longer sees.  A .grad replaced by some other tensor is left alone (returns None)."""
         for p, (off, n) in zip(self.params, self.slices):
             if p is tensor:
-                return self.flat[off:off + n]
+                sl = self.flat[off:off + n]
+                if p.grad is None:
+                    sl.zero_()
+                    p.grad = sl.view_as(p)
+                elif p.grad.data_ptr() != self.flat.data_ptr() + 4 * off or not p.grad.is_contiguous():
+                    return None
+                return sl
         return None
 
     def zero(self):

@@ -269,6 +269,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                                   None if color_offset is None else color_offset.detach())
         color, depth, norm, alpha, radii = outs
         ctx.state = state
+        # the backward re-reads the inputs through raw pointers (K8 recomputes geometry, K7 re-fetches texels): remember
+        # their autograd version counters so an in-place update in between (optimizer.step, change_texture) is an error,
+        # not a silently wrong gradient
+        ctx.versions = [(t, t._version) for t in state.tensors["keep"] if t is not None]
         ctx.op_shape = opacities.shape
         ctx.juv_shape = gradient_uvs.shape
         ctx.mark_non_differentiable(radii)
@@ -277,10 +281,18 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, _dradii):
         s = ctx.state
+        if s is None:
+            raise RuntimeError("the rasterizer's backward ran a second time: its per-call state was released after the "
+                               "first backward (retain_graph=True is not supported); run the forward again")
+        for t, v in ctx.versions:
+            if t._version != v:
+                raise RuntimeError("an input of the rasterizer was modified in place between its forward and backward "
+                                   "(the backward re-reads inputs through saved pointers); clone it before modifying")
         d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, _ = backward_raw(
             s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=ctx.sinks)
         d_coff = s.tensors.get("d_color_offset")
         ctx.state = None
+        ctx.versions = None
         if d_op is not None:
             d_op = d_op.reshape(ctx.op_shape)
         return (d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, None, d_tex, None, d_coff, None)

@@ -43,7 +43,10 @@ def _quat_mul(a, b):
                         w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
 
 
-def make_scene(N, R, seed=0, scale_mean=0.006, sh_coeffs=15):
+def make_scene(N, R, seed=0, scale_mean=0.006, sh_coeffs=15, random_jacobian=False):
+    """random_jacobian=True replaces the analytic (symmetric) Jacobian of `normalize` by a general non-symmetric 3x3 per
+    Gaussian -- what a trained UVNet produces (models/texture_gaussian3d.py:216-227) -- so that a transposed [3*i+j]
+    layout cannot hide behind J = J^T."""
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
     d = rn(N, 3)
@@ -73,6 +76,9 @@ def make_scene(N, R, seed=0, scale_mean=0.006, sh_coeffs=15):
     Jm = (eye[None] - d[:, :, None] * d[:, None, :]) / r[:, :, None]   # analytic Jacobian of normalize at mu
     shs = 0.1 * rn(N, sh_coeffs, 3)
     tex = torch.randn(6, R, R, 3, generator=g, dtype=torch.float32)
+    if random_jacobian:                      # drawn last: every other tensor is identical to the symmetric-J scene
+        g2 = torch.Generator().manual_seed(seed + 7919)
+        Jm = Jm + 0.6 * torch.randn(N, 3, 3, generator=g2, dtype=torch.float64) / r[:, :, None]
     f = lambda t: t.to(torch.float32).contiguous()
     return Scene(f(means), f(scales), f(q), f(opac), f(shs), f(uvs), f(Jm.reshape(N, 9)), tex)
 
