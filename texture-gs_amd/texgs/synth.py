@@ -78,7 +78,7 @@ def make_scene(N, R, seed=0, scale_mean=0.006, sh_coeffs=15, random_jacobian=Fal
     tex = torch.randn(6, R, R, 3, generator=g, dtype=torch.float32)
     if random_jacobian:                      # drawn last: every other tensor is identical to the symmetric-J scene
         g2 = torch.Generator().manual_seed(seed + 7919)
-        Jm = Jm + 0.6 * torch.randn(N, 3, 3, generator=g2, dtype=torch.float64) / r[:, :, None]
+        Jm = Jm + 0.3 * torch.randn(N, 3, 3, generator=g2, dtype=torch.float64) / r[:, :, None]
     f = lambda t: t.to(torch.float32).contiguous()
     return Scene(f(means), f(scales), f(q), f(opac), f(shs), f(uvs), f(Jm.reshape(N, 9)), tex)
 
