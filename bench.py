@@ -64,7 +64,7 @@ def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched)
         "render_fwd": D_eff * 100 + tex + P * 40 + T * 8,
         "render_bwd": D_eff * 100 + P * 40 + tex + 2 * tex + n_touched * 192 + T * 8,
         "preprocess_bwd": N * (96 + 12 * K) + n_vis * 96 + N * (68 + 12 * K),
-        "texgrad_gather": 0,      # an artefact of the scatter layout, no algorithmic traffic of its own
+        "texgrad_reduce": 0,      # an artefact of the gradient scatter, no algorithmic traffic of its own
     }
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 6
+#define TEXGS_ABI_VERSION 7
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
@@ -116,13 +116,19 @@ typedef struct TexGSGrads {
     float* dL_duvs;            /* f32[N,3]                                                             */
     float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
     float* dL_dcolor_offset;   /* f32[N,3] or NULL                                                     */
-    float* tex_quads;          /* f32[texgs_tex_quads_floats(R)] scratch, ALL-ZERO on entry and all-zero again on
-                                  successful return (the gather clears what it read), or NULL.  Four
-                                  phase-shifted arrays of 64-byte-aligned 2x2-texel quads: a bilinear footprint
-                                  anchored at (x0,y0) is one aligned 48-byte run of array (x0&1, y0&1) = ONE
-                                  memory-side atomic request instead of ~2.7.  Summed into dL_dtexture by the
-                                  gather kernel at the end of texgs_backward.  NULL = scatter straight into
-                                  dL_dtexture.                                                              */
+    float*    tex_bins;        /* texture-gradient record lists, f32[texgs_tex_bin_count(R) * 6 * tex_bin_cap], or NULL.
+                                  The texture is cut into 32x32-texel blocks ("bins", 6 * ceil(R/32)^2 of them).  K7 appends
+                                  one 24-byte record {cell, fx, fy, dL/dtexel-colour rgb} per bilinear footprint to the
+                                  list of the bin the footprint is anchored in (plain coalesced stores, plane-major
+                                  [bin][field][slot]); the reduce kernel at the end of texgs_backward sums each list in
+                                  LDS and adds every texel to dL_dtexture once.  NULL (or cap 0) = fp32 atomics straight
+                                  into dL_dtexture (~20 G requests/s memory-side: 0.7 ms per C3 view).  Contents need no
+                                  initialisation.                                                                  */
+    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: list lengths, ALL-ZERO on entry and all-zero again on
+                                  return (the reduce clears what it read).  Word [count] receives atomicMax(list length)
+                                  of every list that overflowed tex_bin_cap (never cleared by the library: the caller
+                                  sizes tex_bin_cap from it); word [count+1] is per-call scratch (zero on entry/return). */
+    uint32_t  tex_bin_cap;     /* slots per bin.  A full bin is not an error: the excess footprints fall back to atomics. */
     int32_t accumulate;        /* 0: K8 overwrites dL_dmeans3D..dL_duvs (and dL_dcolor_offset); 1: it ADDS into them
                                   (fused gradient accumulation of a multi-view step; culled Gaussians write
                                   nothing).  dL_dtexture is always accumulated into.                          */
@@ -133,7 +139,7 @@ const char* texgs_last_error(void);
 
 size_t texgs_scan_temp_bytes(int32_t num_gaussians);
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
-size_t texgs_tex_quads_floats(int32_t tex_res);
+size_t texgs_tex_bin_count(int32_t tex_res);
 
 /* K1 (frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold) + K2
  * (inclusive scan of tiles_touched).  Replaces the first half of _C.rasterize_gaussians. */
@@ -160,7 +166,7 @@ int texgs_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geo
 int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                          const TexGSBinning* bin, TexGSImage* img, void* stream);
 
-/* K7 (back-to-front replay, per-Gaussian partials + texture-grad scatter) + K8 (chain to the operator's
+/* K7 (back-to-front replay, per-Gaussian partials + texture-gradient records) + bin reduce + K8 (chain to the operator's
  * inputs).  Replaces _C.rasterize_gaussians_backward. */
 int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                    const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream);
@@ -171,7 +177,7 @@ int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGe
  * the caller's host arrays (length TEXGS_NUM_KERNELS) and clears the log. */
 enum {
     TEXGS_K_PREPROCESS_FWD = 0, TEXGS_K_SCAN = 1, TEXGS_K_DUPLICATE = 2, TEXGS_K_SORT = 3, TEXGS_K_RANGES = 4,
-    TEXGS_K_RENDER_FWD = 5, TEXGS_K_RENDER_BWD = 6, TEXGS_K_PREPROCESS_BWD = 7, TEXGS_K_TEXGRAD_GATHER = 8,
+    TEXGS_K_RENDER_FWD = 5, TEXGS_K_RENDER_BWD = 6, TEXGS_K_PREPROCESS_BWD = 7, TEXGS_K_TEXGRAD_REDUCE = 8,
     TEXGS_NUM_KERNELS = 9
 };
 int texgs_profile_enable(int on);

@@ -239,6 +239,35 @@ def test_c5_full_size_vs_c_oracle(lib_built):
         assert ok, (name_, msg)
 
 
+def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
+    """The binned two-pass texture gradient (records -> per-bin LDS reduce) against its own fallbacks: bins too small
+    (most footprints overflow to atomics) and bins disabled (every footprint through atomics).  Same sums."""
+    from texgs import rasterizer as RZ
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(3000, 96, seed=12, scale_mean=0.03)       # R = 96: 3x3 bins per face, last column partial? no: 96 = 3*32
+    scene2 = synth.make_scene(3000, 80, seed=12, scale_mean=0.03)      # R = 80: partial bins at the right / bottom edge
+    cam = synth.fibonacci_cameras(4, 240, 176)[3]
+    target, nhat = synth.make_targets(176, 240, seed=4)
+    for sc in (scene, scene2):
+        res = {}
+        for mode, (use, cap) in dict(bins=(True, 0), tiny=(True, 5), off=(False, 0)).items():
+            RZ.USE_TEX_BINS, RZ.TEX_BIN_CAP = use, cap
+            RZ._TEX_BINS.clear()
+            try:
+                _, g = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)
+                _, g2 = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)   # cursors were left clean
+            finally:
+                RZ.USE_TEX_BINS, RZ.TEX_BIN_CAP = True, 0
+                RZ._TEX_BINS.clear()
+            assert Hh.rel_err(g2["texture"], g["texture"]) < 1e-5, mode
+            res[mode] = g
+        for mode in ("tiny", "off"):
+            for name in ("texture", "uvs", "means3D"):
+                r = Hh.rel_err(res[mode][name], res["bins"][name])
+                Hh.report(f"texture_bins/{mode}_vs_bins/R{sc.texture.shape[1]}/{name}", rel_l2=r)
+                assert r < 1e-5, (mode, name, r)
+
+
 def test_wave_ops_primitives_on_hardware(lib_built):
     """csrc/wave_ops.h (DPP row_shl/shr exchanges, permlane16/32 swaps, transposing butterflies incl. the inline-asm
     bank-first one): every primitive equals the __shfl_xor formulation, exactly, for several random seeds."""

@@ -3,6 +3,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -82,7 +83,7 @@ size_t texgs_scan_temp_bytes(int32_t num_gaussians) { return scan_temp_bytes(num
 
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles) { return sort_temp_bytes(num_rendered, num_tiles); }
 
-size_t texgs_tex_quads_floats(int32_t tex_res) { return tex_quads_floats(tex_res); }
+size_t texgs_tex_bin_count(int32_t tex_res) { return tex_bin_count(tex_res); }
 
 int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, void* stream) {
     if (int r = validate_frame(frame)) return r;
@@ -165,9 +166,13 @@ int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGe
     if (bin->num_rendered > 0) {
         { ProfScope p(TEXGS_K_RENDER_BWD, s); launch_render_bwd(c, frame, in, geom, bin, img, grads, s); }
         if (int r = check(frame, s, "render_bwd")) return r;
-        if (grads->tex_quads) {
-            { ProfScope p(TEXGS_K_TEXGRAD_GATHER, s); launch_texgrad_gather(c, grads, s); }
-            if (int r = check(frame, s, "texgrad_gather")) return r;
+        bool reduce = grads->tex_bins && grads->tex_bin_cursor && grads->tex_bin_cap;
+#ifdef TEXGS_EXPERIMENTS
+        if (getenv("TEXGS_SKIP_REDUCE")) reduce = false;       // diagnostics: leave the cursors for inspection
+#endif
+        if (reduce) {
+            { ProfScope p(TEXGS_K_TEXGRAD_REDUCE, s); launch_texgrad_reduce(c, grads, s); }
+            if (int r = check(frame, s, "texgrad_reduce")) return r;
         }
     }
     { ProfScope p(TEXGS_K_PREPROCESS_BWD, s); launch_preprocess_bwd(c, frame, in, geom, grads, s); }

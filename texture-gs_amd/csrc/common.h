@@ -56,8 +56,8 @@ int  launch_sort(const CamConst& c, TexGSBinning* b, hipStream_t s);
 void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s);
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s);
-size_t tex_quads_floats(int R);
-void launch_texgrad_gather(const CamConst& c, TexGSGrads* gr, hipStream_t s);
+size_t tex_bin_count(int R);
+void launch_texgrad_reduce(const CamConst& c, TexGSGrads* gr, hipStream_t s);
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s);
 int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha, int H,

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ERR_CAPACITY = 1000
 TILE = 16
 REC_FLOATS = 32
@@ -48,15 +48,16 @@ class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
                 ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
-                ("dL_dcolor_offset", _fp), ("tex_quads", _fp), ("accumulate", C.c_int32)]
+                ("dL_dcolor_offset", _fp), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_cap", C.c_uint32),
+                ("accumulate", C.c_int32)]
 
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-           "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_quads_floats",
+           "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
            "texgs_profile_read", "texgs_selftest_waveops"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
-                "texgrad_gather"]
+                "texgrad_reduce"]
 
 _lib = None
 
@@ -78,8 +79,8 @@ def load():
     lib.texgs_scan_temp_bytes.argtypes = [C.c_int32]
     lib.texgs_sort_temp_bytes.restype = C.c_size_t
     lib.texgs_sort_temp_bytes.argtypes = [C.c_uint32, C.c_uint32]
-    lib.texgs_tex_quads_floats.restype = C.c_size_t
-    lib.texgs_tex_quads_floats.argtypes = [C.c_int32]
+    lib.texgs_tex_bin_count.restype = C.c_size_t
+    lib.texgs_tex_bin_count.argtypes = [C.c_int32]
     lib.texgs_preprocess_forward.argtypes = [P(Frame), P(Inputs), P(Geom), C.c_void_p]
     lib.texgs_read_num_rendered.argtypes = [P(Geom), C.c_int32, P(C.c_uint32), C.c_void_p]
     lib.texgs_bin_sort_render_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), C.c_void_p]

@@ -16,7 +16,9 @@ from . import _lib
 
 
 import os as _os
-USE_TEX_QUADS = _os.environ.get("TEXGS_TEX_QUADS", "1") != "0"     # quad-layout texture-gradient scatter
+USE_TEX_BINS = _os.environ.get("TEXGS_TEX_BINS", "1") != "0"       # binned two-pass texture gradient
+TEX_BIN_CAP = int(_os.environ.get("TEXGS_BIN_CAP", "0"))           # fixed slots per bin (tests); 0 = adaptive
+TEX_BIN_BYTES_MAX = int(float(_os.environ.get("TEXGS_BIN_GB_MAX", "16")) * (1 << 30))
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -49,8 +51,49 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
     return t.contiguous()
 
 
-_QUAD_SCRATCH = {}
 _CAPACITY_HINT = {}
+_TEX_BINS = {}
+
+
+class _TexBins:
+    """Persistent scratch of the binned texture gradient for one (device, R, stream): record lists + cursors
+    (TexGSGrads.tex_bins / tex_bin_cursor).  The cursors are all-zero between calls (the reduce kernel clears them), the
+    records need no initialisation.  `cap` (slots per bin) adapts: a list that overflowed leaves its wanted length in
+    the word after the cursors (atomicMax); it is copied to pinned host memory asynchronously every few calls and
+    looked at only when that copy has completed -- the backward never waits for it.  A full bin is not an error (the
+    excess goes through atomics), so a stale `cap` costs speed, never correctness."""
+
+    def __init__(self, lib, device, R):
+        self.device, self.R = device, R
+        self.nbins = int(lib.texgs_tex_bin_count(R))
+        self.cursor = torch.zeros(self.nbins + 2, dtype=torch.int32, device=device)
+        self.cap = 0
+        self.rec = None
+        self._resize(TEX_BIN_CAP or 8192)
+        self.host_max = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.calls = 0
+
+    def _resize(self, cap):
+        cap = max(4, min(int(cap), TEX_BIN_BYTES_MAX // (24 * self.nbins)))
+        if cap != self.cap:
+            self.rec = None
+            self.rec = torch.empty(self.nbins * 6 * cap, dtype=torch.float32, device=self.device)
+            self.cap = cap
+
+    def before_call(self):
+        if self.event is not None and self.event.query():
+            self.event = None
+            longest = int(self.host_max[0])
+            if not TEX_BIN_CAP and longest > self.cap:
+                self._resize(1 << int(math.ceil(math.log2(longest * 1.25))))
+
+    def after_call(self):
+        self.calls += 1
+        if self.event is None and not TEX_BIN_CAP and (self.calls <= 4 or self.calls % 16 == 0):
+            self.host_max.copy_(self.cursor[self.nbins:self.nbins + 1], non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(self.device))
 
 
 class _State:
@@ -232,19 +275,20 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
         d_coff = out("color_offset", N, 3) if has_coff else None
         tex_sink = sinks.get("texture")
         d_tex = tex_sink if tex_sink is not None else torch.zeros(6, R, R, 3, **f32)
-        qkey = (device.index, R, stream)
-        quads = None
-        if USE_TEX_QUADS and R >= 4:
-            # persistent all-zero scratch per (device, R, stream): the library returns it all-zero (read-and-clear)
-            quads = _QUAD_SCRATCH.pop(qkey, None)
-            if quads is None:
-                quads = torch.zeros(lib.texgs_tex_quads_floats(R), **f32)
+        bkey = (device.index, R, stream)
+        bins = None
+        if USE_TEX_BINS:
+            bins = _TEX_BINS.pop(bkey, None) or _TexBins(lib, device, R)
+            bins.before_call()
         grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(d_means3D), _ptr(d_means2D),
-                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff), _ptr(quads), 1 if fused else 0)
+                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff),
+                           _ptr(bins.rec) if bins else None, _ptr(bins.cursor) if bins else None, bins.cap if bins else 0,
+                           1 if fused else 0)
         _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                       C.byref(s.img), C.byref(grads), stream), "texgs_backward")
-    if quads is not None:
-        _QUAD_SCRATCH[qkey] = quads          # only re-cached after a successful call (an exception drops it)
+    if bins is not None:
+        bins.after_call()
+        _TEX_BINS[bkey] = bins               # only re-cached after a successful call (an exception drops it)
     if fused:
         d_means3D = d_means2D = d_shs = d_op = d_scales = d_rot = d_uvs = d_coff = None
     if tex_sink is not None:
