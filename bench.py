@@ -62,7 +62,7 @@ def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched)
         "sort": D * 8 + passes * D * 24,
         "ranges": D * 8 + T * 8,
         "render_fwd": D_eff * 100 + tex + P * 40 + T * 8,
-        "render_bwd": D_eff * 100 + P * 40 + tex + 2 * tex + n_touched * 192 + T * 8,
+        "render_bwd": D_eff * 100 + P * 40 + tex + 2 * tex + n_touched * 256 + T * 8,
         "preprocess_bwd": N * (96 + 12 * K) + n_vis * 96 + N * (68 + 12 * K),
         "texgrad_reduce": 0,      # an artefact of the gradient scatter, no algorithmic traffic of its own
     }
@@ -212,7 +212,7 @@ def main():
         n_touched, texels = n_vis, 0
         if with_bwd:
             res = backward_raw(s, g_img, None, g_norm, g_alpha)
-            n_touched = int((res[-1].abs().sum(1) > 0).sum())
+            n_touched = int((res[3].reshape(N, -1).abs().sum(1) > 0).sum())     # Gaussians that received a gradient
             texels = int((res[7].abs().sum(-1) > 0).sum())
         else:
             texels = 0

@@ -29,7 +29,7 @@ extern "C" {
 #define TEXGS_ABI_VERSION 7
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
-#define TEXGS_ACC_FLOATS 24    /* per-Gaussian gradient accumulators, same order as record[0..23]     */
+#define TEXGS_ACC_FLOATS 32    /* per-Gaussian moment accumulators of the backward: one 128-byte line  */
 
 /* Per-call configuration = GaussianRasterizationSettings (render/uv_tex_render.py:25-38). */
 typedef struct TexGSFrame {
@@ -66,7 +66,7 @@ typedef struct TexGSInputs {
 
 /* Per-Gaussian state written by texgs_preprocess_forward. */
 typedef struct TexGSGeom {
-    float*    rec;             /* f32[N,32]: xy(2) conic(3) opacity g(2) | G(6) phi(3) viewdep(3) depth normal(3) | pad */
+    float*    rec;             /* f32[N,32]: xy(2) conic(-a/2,-b,-c/2) opacity g(2) | G(6) phi(3) viewdep(3) depth normal(3) | rcull thr */
     float*    depth;           /* f32[N] view-space z (sort key)                                       */
     int32_t*  radii;           /* i32[N] screen radius in px; 0 = culled (operator output `radii`)     */
     uint32_t* rect;            /* u32[N,2]: (minx | miny<<16), (maxx | maxy<<16) tile rectangle        */
@@ -106,7 +106,8 @@ typedef struct TexGSGrads {
     const float* dL_ddepth;    /* f32[1,H,W] or NULL */
     const float* dL_dnorm;     /* f32[3,H,W] or NULL */
     const float* dL_dalpha;    /* f32[1,H,W] or NULL */
-    float* acc;                /* f32[N,24] caller zero-filled; scratch between the two backward kernels */
+    float* acc;                /* f32[N,32] ALL-ZERO on entry and all-zero again on return (K8 clears the rows it read):
+                                  per-Gaussian raw moment sums, scratch between the two backward kernels              */
     float* dL_dmeans3D;        /* f32[N,3]                                                             */
     float* dL_dmeans2D;        /* f32[N,3] dL/d(ndc xy), z = 0 (lineage convention)                    */
     float* dL_dshs;            /* f32[N,K,3] or NULL                                                   */

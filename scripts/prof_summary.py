@@ -2,7 +2,7 @@
 import csv, glob, os, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 def short(n):
-    for k in ("k_render_fwd", "k_render_bwd", "k_preprocess_fwd", "k_preprocess_bwd", "k_duplicate", "k_ranges"):
+    for k in ("k_render_fwd", "k_render_bwd", "k_preprocess_fwd", "k_preprocess_bwd", "k_duplicate", "k_ranges", "k_texgrad_reduce"):
         if k in n: return k
     if "onesweep" in n or "radix" in n or "sort" in n.lower(): return "radix_sort:" + n.split("(")[0][-40:]
     if "scan" in n.lower(): return "scan:" + n.split("(")[0][-30:]
@@ -20,5 +20,5 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print("== pmc", f)
         for k, cs in agg.items():
-            if not k.startswith("k_render") and not k.startswith("k_pre"): continue
+            if not k.startswith("k_"): continue
             print("  ", k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n", len(next(iter(cs.values()))))

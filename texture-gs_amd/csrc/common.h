@@ -16,9 +16,18 @@
 #define TG_MA_MIN        1e-20f
 #define TG_SH_C0         0.28209479177387814f
 
-// record / accumulator slots (float index)
+// record slots (float index)
 enum {
     R_XY = 0, R_CONIC = 2, R_OP = 5, R_G2 = 6, R_GM = 8, R_PHI = 14, R_VD = 17, R_DEPTH = 20, R_N = 21
+};
+// accumulator-row slots (TexGSGrads.acc, 32 floats = one 128-byte line per Gaussian): raw moments about the splat centre,
+// summed by K7 over the Gaussian's contributing pixels.  dx = xy - pixel, dp = pixel - xy.
+//   M_P   : sum P {1, dx, dy, dx^2, dx dy, dy^2}          P = dL/dpower
+//   M_DEN : sum dden {1, dpx, dpy}                         dden = dL/d(1 + g.dp)
+//   M_DN  : for c = 0..2: sum dn_c {1, dpx, dpy}           dn = dL/duv / den
+//   M_PHI : sum dL/duv (3)   M_VD: sum dL/dcolour (3)   M_DEPTH: sum w dL/ddepth   M_N: sum w dL/dnormal (3)
+enum {
+    M_P = 0, M_DEN = 6, M_DN = 9, M_PHI = 18, M_VD = 21, M_DEPTH = 24, M_N = 25
 };
 
 #define TG_BLOCK 256

@@ -281,8 +281,9 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     depth[i] = g.t[2];
     rect[i] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
     float4* r = rec + (size_t)i * (TEXGS_REC_FLOATS / 4);
-    r[0] = make_float4(g.xy[0], g.xy[1], g.conic[0], g.conic[1]);
-    r[1] = make_float4(g.conic[2], opac[i], g.gx, g.gy);
+    // conic pre-scaled for the blend kernels' falloff exponent: power = ah dx^2 + bh dx dy + ch dy^2 (render.hip gauss_power)
+    r[0] = make_float4(g.xy[0], g.xy[1], -0.5f * g.conic[0], -g.conic[1]);
+    r[1] = make_float4(-0.5f * g.conic[2], opac[i], g.gx, g.gy);
     r[2] = make_float4(g.G[0], g.G[1], g.G[2], g.G[3]);
     r[3] = make_float4(g.G[4], g.G[5], uvs[3 * i + 0], uvs[3 * i + 1]);
     r[4] = make_float4(uvs[3 * i + 2], vd[0], vd[1], vd[2]);
@@ -303,9 +304,10 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
 // ------------------------------------------------------------------------------------------------ K8
 __global__ void __launch_bounds__(TG_BLOCK)
 k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
-                 const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ scales,
+                 const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
+                 const float* __restrict__ scales,
                  const float* __restrict__ rots, const float* __restrict__ juv, const int32_t* __restrict__ radii,
-                 const float* __restrict__ acc,
+                 float* __restrict__ acc,
                  float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
                  float* __restrict__ d_uvs, float* __restrict__ d_coff, int accumulate, uint32_t* __restrict__ clear_word) {
@@ -337,14 +339,34 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     geo_forward(g, F, C, i, means, scales, rots, juv);
-    float A[TEXGS_ACC_FLOATS];
+    // K7 left raw moment sums (common.h M_*) in this Gaussian's accumulator row; turn them into the gradients of the
+    // record fields (R_* slots) here, where conic / opacity / G / g are in registers anyway, and hand the row back zeroed
+    // (the scratch is all-zero between calls: no 38 MB memset per backward).
+    float A[24];
     {
-        const float4* ap = reinterpret_cast<const float4*>(acc + (size_t)i * TEXGS_ACC_FLOATS);
+        float Mo[TEXGS_ACC_FLOATS];
+        float4* ap = reinterpret_cast<float4*>(acc + (size_t)i * TEXGS_ACC_FLOATS);
 #pragma unroll
         for (int k = 0; k < TEXGS_ACC_FLOATS / 4; ++k) {
             const float4 v = ap[k];
-            A[4 * k] = v.x; A[4 * k + 1] = v.y; A[4 * k + 2] = v.z; A[4 * k + 3] = v.w;
+            Mo[4 * k] = v.x; Mo[4 * k + 1] = v.y; Mo[4 * k + 2] = v.z; Mo[4 * k + 3] = v.w;
+            ap[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const float ca = g.conic[0], cb = g.conic[1], cc = g.conic[2];
+        const float m00 = Mo[M_P], m10 = Mo[M_P + 1], m01 = Mo[M_P + 2];
+        const float N00 = Mo[M_DN], N10 = Mo[M_DN + 3], N20 = Mo[M_DN + 6], D0 = Mo[M_DEN];
+        A[R_XY]     = -(ca * m10 + cb * m01) - ((g.G[0] * N00 + g.G[2] * N10 + g.G[4] * N20) + g.gx * D0);
+        A[R_XY + 1] = -(cc * m01 + cb * m10) - ((g.G[1] * N00 + g.G[3] * N10 + g.G[5] * N20) + g.gy * D0);
+        A[R_CONIC] = -0.5f * Mo[M_P + 3]; A[R_CONIC + 1] = -Mo[M_P + 4]; A[R_CONIC + 2] = -0.5f * Mo[M_P + 5];
+        const float op = opac[i];
+        A[R_OP] = (op > 0.0f) ? m00 / op : 0.0f;                 // d alpha_raw / d opacity = alpha_raw / opacity
+        A[R_G2] = Mo[M_DEN + 1]; A[R_G2 + 1] = Mo[M_DEN + 2];
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) {
+            A[R_GM + 2 * cidx] = Mo[M_DN + 3 * cidx + 1]; A[R_GM + 2 * cidx + 1] = Mo[M_DN + 3 * cidx + 2];
+            A[R_PHI + cidx] = Mo[M_PHI + cidx]; A[R_VD + cidx] = Mo[M_VD + cidx]; A[R_N + cidx] = Mo[M_N + cidx];
+        }
+        A[R_DEPTH] = Mo[M_DEPTH];
     }
     const float tx = g.t[0], ty = g.t[1], tz = g.t[2];
     float dt[3] = {0.f, 0.f, 0.f};      // dL/d t (view-space mean)
@@ -536,7 +558,7 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
     const size_t lds = gr->dL_dshs ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
-                       in->means3D, in->shs, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
+                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
                        gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate,
                        (gr->tex_bins && gr->tex_bin_cursor && gr->tex_bin_cap) ? gr->tex_bin_cursor + tex_bin_count(c.R) + 1 : nullptr);

@@ -67,10 +67,10 @@ __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, in
 }
 
 // The falloff exponent, shared by K6 and K7: K7 must reproduce K6's contributor decisions (power <= 0, alpha >= 1/255)
-// bit for bit, so both evaluate this one fixed sequence of fp32 operations (no FMA contraction here).
-__device__ __forceinline__ float gauss_power(float ca, float cb, float cc, float dx, float dy) {
-#pragma clang fp contract(off)
-    return -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+// bit for bit, so both evaluate this one explicitly ordered sequence of fp32 operations.  K1 stores the conic pre-scaled,
+// (ah, bh, ch) = (-a/2, -b, -c/2), so power = ah dx^2 + bh dx dy + ch dy^2 is 3 mul + 1 mul + 2 fma.
+__device__ __forceinline__ float gauss_power(float ah, float bh, float ch, float dx, float dy) {
+    return __fmaf_rn(bh, __fmul_rn(dx, dy), __fmaf_rn(ch, __fmul_rn(dy, dy), __fmul_rn(ah, __fmul_rn(dx, dx))));
 }
 __device__ __forceinline__ float gauss_alpha_raw(float op, float power) { return op * __expf(power); }
 
@@ -269,9 +269,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //            q = colour . dL/dpixel (for the suffix recurrence) and dL/dcolour (3), dL/duv (3), 1/den, dL/dden; appends
 //            the item's texture-gradient record to its texture bin (see the file header).
 //   stage C  sequential, scalar suffix recurrence dL/dalpha = T (s - suffix) + bg term with s = q + geometry
-//            channels; all 24 per-Gaussian partials are formed by the owning pixel lane, reduced over the wave with
-//            ONE transposing butterfly (value k ends in lane k, DPP + permlane swaps only, wave_ops.h) and lanes 0..23
-//            add 24 consecutive dwords of the accumulator row: one coalesced memory-side request.
+//            channels; the 28 per-Gaussian moment sums are formed by the owning pixel lane, reduced over the wave with
+//            ONE transposing butterfly (value k ends in one lane, DPP + permlane swaps only, wave_ops.h) and 28 lanes add
+//            28 dwords of the 128-byte accumulator row: one coalesced memory-side request.
 #ifndef BQ_CAP
 #define BQ_CAP 128
 #endif
@@ -509,47 +509,39 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 float part[32];
 #pragma unroll
                 for (int k = 0; k < 32; ++k) part[k] = 0.f;
-                const float4 c0 = s_recs[0 * 64 + jj], c1 = s_recs[1 * 64 + jj], c2 = s_recs[2 * 64 + jj],
-                             c3 = s_recs[3 * 64 + jj], c5 = s_recs[5 * 64 + jj];             // uniform address: LDS broadcast
+                const float4 c0 = s_recs[0 * 64 + jj], c5 = s_recs[5 * 64 + jj];             // uniform address: LDS broadcast
                 if (ok) {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
                     const float4 i0 = s_items[(it0 + rank) * 3], i1 = s_items[(it0 + rank) * 3 + 1], i2 = s_items[(it0 + rank) * 3 + 2];
                     const float Ti = i0.x, araw = i0.y, qv = i0.z;
                     const float alpha = fminf(TG_ALPHA_MAX, araw);
-                    const float gx_ = c0.x, gy_ = c0.y, ca = c0.z, cb = c0.w, cc = c1.x, op = c1.y;
-                    const float dep = c5.x, n0 = c5.y, n1 = c5.z, n2 = c5.w;
-                    const float dx = gx_ - pxf, dy = gy_ - pyf;
+                    const float dx = c0.x - pxf, dy = c0.y - pyf;               // xy - pixel
                     const float w = alpha * Ti;
-                    const float s_i = qv + dep * dpix[3] + n0 * dpix[4] + n1 * dpix[5] + n2 * dpix[6] + dpix[7];
+                    const float s_i = qv + c5.x * dpix[3] + c5.y * dpix[4] + c5.z * dpix[5] + c5.w * dpix[6] + dpix[7];
                     suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
                     last_s = s_i; last_alpha = alpha;
                     const float dL_dalpha_ = (s_i - suffix) * Ti - Tfin * __builtin_amdgcn_rcpf(1.0f - alpha) * bgdot;
-                    const float dL_dpower = araw * dL_dalpha_;        // straight through the 0.99 clamp (lineage)
-                    const float gdx = -(ca * dx + cb * dy), gdy = -(cc * dy + cb * dx);
-                    // uv path (stage B results): dn = du * inv, dp = pix - xy
+                    const float P = araw * dL_dalpha_;                // dL/dpower, straight through the 0.99 clamp (lineage)
+                    // The per-Gaussian sums are RAW MOMENTS about the splat centre (TexGSGrads.acc layout, texgs.h); K8, which
+                    // has conic / opacity / G / g in registers anyway, turns them into dL/d(xy, conic, opacity, G, g, ...).
                     const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
                     const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
-                    const float dpx = -dx, dpy = -dy;
-                    const float ggx = c1.z, ggy = c1.w;
-                    const float G00 = c2.x, G01 = c2.y, G10 = c2.z, G11 = c2.w, G20 = c3.x, G21 = c3.y;
-                    part[R_XY]        = dL_dpower * gdx - ((G00 * dn0 + G10 * dn1 + G20 * dn2) + ggx * dden);
-                    part[R_XY + 1]    = dL_dpower * gdy - ((G01 * dn0 + G11 * dn1 + G21 * dn2) + ggy * dden);
-                    part[R_CONIC]     = -0.5f * dx * dx * dL_dpower;
-                    part[R_CONIC + 1] = -dx * dy * dL_dpower;
-                    part[R_CONIC + 2] = -0.5f * dy * dy * dL_dpower;
-                    part[R_OP]        = araw * __builtin_amdgcn_rcpf(op) * dL_dalpha_;
-                    part[R_G2] = dden * dpx; part[R_G2 + 1] = dden * dpy;
-                    part[R_GM + 0] = dn0 * dpx; part[R_GM + 1] = dn0 * dpy;
-                    part[R_GM + 2] = dn1 * dpx; part[R_GM + 3] = dn1 * dpy;
-                    part[R_GM + 4] = dn2 * dpx; part[R_GM + 5] = dn2 * dpy;
-                    part[R_PHI] = du0; part[R_PHI + 1] = du1; part[R_PHI + 2] = du2;
-                    part[R_VD] = i1.x; part[R_VD + 1] = i1.y; part[R_VD + 2] = i1.z;
-                    part[R_DEPTH] = w * dpix[3];
-                    part[R_N] = w * dpix[4]; part[R_N + 1] = w * dpix[5]; part[R_N + 2] = w * dpix[6];
+                    const float dpx = -dx, dpy = -dy;                           // pixel - xy
+                    const float Pdx = P * dx, Pdy = P * dy;
+                    part[M_P] = P; part[M_P + 1] = Pdx; part[M_P + 2] = Pdy;
+                    part[M_P + 3] = Pdx * dx; part[M_P + 4] = Pdx * dy; part[M_P + 5] = Pdy * dy;
+                    part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
+                    part[M_DN + 0] = dn0; part[M_DN + 1] = dn0 * dpx; part[M_DN + 2] = dn0 * dpy;
+                    part[M_DN + 3] = dn1; part[M_DN + 4] = dn1 * dpx; part[M_DN + 5] = dn1 * dpy;
+                    part[M_DN + 6] = dn2; part[M_DN + 7] = dn2 * dpx; part[M_DN + 8] = dn2 * dpy;
+                    part[M_PHI] = du0; part[M_PHI + 1] = du1; part[M_PHI + 2] = du2;
+                    part[M_VD] = i1.x; part[M_VD + 1] = i1.y; part[M_VD + 2] = i1.z;
+                    part[M_DEPTH] = w * dpix[3];
+                    part[M_N] = w * dpix[4]; part[M_N + 1] = w * dpix[5]; part[M_N + 2] = w * dpix[6];
                 }
                 it0 += __popcll(bal);
                 // bank-first transposing butterfly (wave_ops.h): lane l < 32 ends with the wave total of slot transposed_index(l);
-                // the 24 slots are 24 consecutive dwords of one accumulator row -> one coalesced memory-side request
+                // the slots are the 32 dwords of one 128-byte accumulator row -> one coalesced memory-side request
                 const int slot = transposed_index(lane);
                 const float tot = reduce32_bankfirst(part, lane);
                 const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)id, jj);
@@ -571,42 +563,70 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 // < 2^42, so 2^20 records per bin cannot overflow; resolution 2^-42 of the image-wide bound, sums exact and
 // order-independent (the texture gradient of the binned path is bit-reproducible run to run).
 #define TB_EDGE 33
+#ifndef TB_COPIES
+#define TB_COPIES 1
+#endif
+#ifndef TB_PLAIN_RMW
+#define TB_PLAIN_RMW 0
+#endif
 __global__ void __launch_bounds__(256)
 k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
-    __shared__ long long s_tile[TB_EDGE * TB_EDGE * 3];
-    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    __shared__ long long s_tile[TB_COPIES * TB_EDGE * TB_EDGE * 3];      // two copies, even / odd lanes: halves the conflicts of
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;      // lanes that hit the same texel (66 % conflict cycles with one)
     const uint32_t filled = tb.cursor[b];
     if (filled == 0u) return;                                  // uniform per workgroup
-    for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) s_tile[k] = 0ll;
+    for (int k = tid; k < TB_COPIES * TB_EDGE * TB_EDGE * 3; k += 256) s_tile[k] = 0ll;
     __syncthreads();
     const float bound = TG_SH_C0 * __uint_as_float(tb.stats[1]);
     int e = 0;
     (void)frexpf(bound, &e);                                   // bound < 2^e
-    const float up = ldexpf(1.0f, 42 - e), down = ldexpf(1.0f, e - 42);
+    const double up = (double)ldexpf(1.0f, 42 - e);
+    const float down = ldexpf(1.0f, e - 42);
     const uint32_t cnt = min(filled, tb.cap);
     const float* __restrict__ rp = tb.rec + (size_t)b * tb.cap * 6;
     const size_t cap = tb.cap;
-    for (uint32_t i = (uint32_t)tid; i < cnt; i += 256u) {
-        const uint32_t cell = __float_as_uint(rp[i]);
-        const float fx = rp[cap + i], fy = rp[2 * cap + i];
-        const float x0 = rp[3 * cap + i] * up, x1 = rp[4 * cap + i] * up, x2 = rp[5 * cap + i] * up;
-        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + ((cell >> 8) * TB_EDGE + (cell & 0xFFu)) * 3;
-#define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(long long)(V))
-        TB_ADD(t + 0, w00 * x0); TB_ADD(t + 1, w00 * x1); TB_ADD(t + 2, w00 * x2);
-        TB_ADD(t + 3, w01 * x0); TB_ADD(t + 4, w01 * x1); TB_ADD(t + 5, w01 * x2);
-        TB_ADD(t + TB_EDGE * 3 + 0, w10 * x0); TB_ADD(t + TB_EDGE * 3 + 1, w10 * x1); TB_ADD(t + TB_EDGE * 3 + 2, w10 * x2);
-        TB_ADD(t + TB_EDGE * 3 + 3, w11 * x0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * x1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * x2);
+    // float -> int64 without the 11-instruction generic conversion: |v| < 2^42, so v + 1.5 * 2^52 (exact in double) carries
+    // round(v) in its mantissa; subtracting the bias as integers leaves the two's-complement value
+    const double magic = 6755399441055744.0;
+    const long long magic_bits = __double_as_longlong(magic);
+    auto add_record = [&](uint32_t cell, float fx, float fy, float x0, float x1, float x2) {
+        const double dx0 = (double)x0 * up, dx1 = (double)x1 * up, dx2 = (double)x2 * up;
+        const double w00 = (double)((1.f - fx) * (1.f - fy)), w01 = (double)(fx * (1.f - fy));
+        const double w10 = (double)((1.f - fx) * fy), w11 = (double)(fx * fy);
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + (tid & (TB_COPIES - 1)) * (TB_EDGE * TB_EDGE * 3)
+                              + ((cell >> 8) * TB_EDGE + (cell & 0xFFu)) * 3;
+#define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(__double_as_longlong((V) + magic) - magic_bits))
+        TB_ADD(t + 0, w00 * dx0); TB_ADD(t + 1, w00 * dx1); TB_ADD(t + 2, w00 * dx2);
+        TB_ADD(t + 3, w01 * dx0); TB_ADD(t + 4, w01 * dx1); TB_ADD(t + 5, w01 * dx2);
+        TB_ADD(t + TB_EDGE * 3 + 0, w10 * dx0); TB_ADD(t + TB_EDGE * 3 + 1, w10 * dx1); TB_ADD(t + TB_EDGE * 3 + 2, w10 * dx2);
+        TB_ADD(t + TB_EDGE * 3 + 3, w11 * dx0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * dx1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * dx2);
 #undef TB_ADD
+    };
+    uint32_t i = (uint32_t)tid;
+    for (; i + 256u < cnt; i += 512u) {                          // two records per thread in flight (12 loads)
+        const uint32_t i2 = i + 256u;
+        const uint32_t ca = __float_as_uint(rp[i]), cb = __float_as_uint(rp[i2]);
+        const float fxa = rp[cap + i], fya = rp[2 * cap + i], xa0 = rp[3 * cap + i], xa1 = rp[4 * cap + i], xa2 = rp[5 * cap + i];
+        const float fxb = rp[cap + i2], fyb = rp[2 * cap + i2], xb0 = rp[3 * cap + i2], xb1 = rp[4 * cap + i2], xb2 = rp[5 * cap + i2];
+        add_record(ca, fxa, fya, xa0, xa1, xa2);
+        add_record(cb, fxb, fyb, xb0, xb1, xb2);
     }
+    if (i < cnt) add_record(__float_as_uint(rp[i]), rp[cap + i], rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i], rp[5 * cap + i]);
     __syncthreads();
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
-        const long long q = s_tile[k];
+        long long q = s_tile[k];
+#pragma unroll
+        for (int cp = 1; cp < TB_COPIES; ++cp) q += s_tile[cp * TB_EDGE * TB_EDGE * 3 + k];
         if (q == 0ll) continue;
         const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
         const int y = by * 32 + row, xq = bx * 96 + c;
-        if (y < R && xq < R * 3) unsafeAtomicAdd(dtex + ((size_t)(face * R + y) * R) * 3 + xq, (float)q * down);
+        if (y >= R || xq >= R * 3) continue;
+        float* o = dtex + ((size_t)(face * R + y) * R) * 3 + xq;
+        // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles; the 31x31 interior is this
+        // workgroup's alone (K7's direct atomics finished before this kernel started): plain read-modify-write
+        if (TB_PLAIN_RMW && row >= 1 && row <= 31 && c >= 3 && c < 96) *o += (float)q * down;
+        else unsafeAtomicAdd(o, (float)q * down);
     }
     if (tid == 0) {
         tb.cursor[b] = 0u;

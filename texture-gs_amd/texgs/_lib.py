@@ -10,7 +10,7 @@ ABI_VERSION = 7
 ERR_CAPACITY = 1000
 TILE = 16
 REC_FLOATS = 32
-ACC_FLOATS = 24
+ACC_FLOATS = 32
 
 _fp = C.c_void_p  # device pointers travel as integers
 

@@ -53,6 +53,7 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
 
 _CAPACITY_HINT = {}
 _TEX_BINS = {}
+_ACC_SCRATCH = {}       # (device, N, stream) -> f32[N,32] moment accumulators, all-zero between calls (K8 clears what it read)
 
 
 class _TexBins:
@@ -231,7 +232,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
 
 
 def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None):
-    """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture, acc).
+    """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture).
 
     `sinks` (optional): dict name -> existing float32 gradient buffer of the input's shape.  If EVERY per-Gaussian
     output has a sink the kernels ADD into them (fused multi-view accumulation, TexGSGrads.accumulate = 1); a texture
@@ -252,7 +253,10 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     H, W = s.H, s.W
     dc, dd, dn, da = g(dL_dcolor, (3, H, W)), g(dL_ddepth, (1, H, W)), g(dL_dnorm, (3, H, W)), g(dL_dalpha, (1, H, W))
     with torch.cuda.device(device):
-        acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
+        akey = (device.index, N, stream)
+        acc = _ACC_SCRATCH.pop(akey, None)
+        if acc is None:
+            acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
         sinks = sinks or {}
         has_coff = s.tensors["keep"][8] is not None
         per_gauss = ["means3D", "means2D", "opacities", "scales", "rotations", "uvs"] + (["shs"] if K > 0 else []) \
@@ -286,6 +290,7 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
                            1 if fused else 0)
         _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                       C.byref(s.img), C.byref(grads), stream), "texgs_backward")
+    _ACC_SCRATCH[akey] = acc                 # only re-cached after a successful call (an exception drops it)
     if bins is not None:
         bins.after_call()
         _TEX_BINS[bkey] = bins               # only re-cached after a successful call (an exception drops it)
@@ -294,7 +299,7 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     if tex_sink is not None:
         d_tex = None
     s.tensors["d_color_offset"] = d_coff
-    return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, acc
+    return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -332,7 +337,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if t._version != v:
                 raise RuntimeError("an input of the rasterizer was modified in place between its forward and backward "
                                    "(the backward re-reads inputs through saved pointers); clone it before modifying")
-        d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex, _ = backward_raw(
+        d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex = backward_raw(
             s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=ctx.sinks)
         d_coff = s.tensors.get("d_color_offset")
         ctx.state = None
