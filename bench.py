@@ -52,15 +52,16 @@ def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched)
     """Per-launch algorithmic HBM bytes of every kernel (DESIGN.md section 5 states each term).  D_eff = sum over
     tiles of the last contributor's position (the replay never needs the rest of the list); texels_touched =
     distinct texels with a non-zero gradient in this view."""
-    bits = max(1, math.ceil(math.log2(max(T, 2))))
-    passes = math.ceil((32 + bits) / 8)
     tex = 12 * texels_touched
     return {
         "preprocess_fwd": N * (92 + 12 * K) + n_vis * 96 + N * 20,
-        "scan": N * 8,
-        "duplicate": N * 20 + D * 12,
-        "sort": D * 8 + passes * D * 24,
-        "ranges": D * 8 + T * 8,
+        # K2: 4 stable radix passes over the N (depth key, index) pairs (count: 4N read; scatter: 8N read + 8N write) +
+        # exclusive scan of tiles_touched in rank order (2 x (8N read) + 4N write)
+        "scan": 4 * N * (4 + 8 + 8) + N * 20,
+        "duplicate": N * 20 + D * 8 + T * 8,
+        # K4: 2 stable passes over the D 8-byte (tile | rank) elements; the last writes 12 B / element and gathers 8 B
+        "sort": 2 * D * (8 + 8) + D * 8 + D * (12 + 8),
+        "ranges": D * 8 + T * 8 + T * 12,
         "render_fwd": D_eff * 100 + tex + P * 40 + T * 8,
         "render_bwd": D_eff * 100 + P * 40 + tex + 2 * tex + n_touched * 256 + T * 8,
         "preprocess_bwd": N * (96 + 12 * K) + n_vis * 96 + N * (68 + 12 * K),
@@ -179,15 +180,29 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    _lib.profile_enable(True)
+    # HIP events inside the timed region bracket ONLY the dominant kernel (an event pair costs ~5 us of stream time; all
+    # nine kernel groups bracketed cost ~90 us / view).  The full per-kernel table comes from two extra steps afterwards.
+    DOMINANT = "render_bwd" if with_bwd else "render_fwd"
+    _lib.profile_enable(True, only=[DOMINANT])
     _lib.profile_read()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for k in range(args.steps):
         step()
+        step_ev[k + 1].record()
     fence()
     t1 = time.perf_counter()
+    kern_timed = _lib.profile_read()
+    _lib.profile_enable(True)
+    for _ in range(2):
+        step()
+    fence()
     kern = _lib.profile_read()
     _lib.profile_enable(False)
+    kern[DOMINANT] = kern_timed[DOMINANT]
+    step_ms = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
     elapsed = t1 - t0
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -222,7 +237,7 @@ def main():
         if cnt:
             kinfo[name] = {"avg_us": 1e3 * ms / cnt, "launches": cnt, "alg_MB": ab.get(name, 0) / 1e6,
                            "GBps": ab.get(name, 0) / (ms / cnt * 1e-3) / 1e9}
-    dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"] * kinfo[k]["launches"]) if kinfo else None
+    dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"]) if kinfo else None        # every group launches once per view
     roofline = None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC pass of the same command (scripts/prof.sh)
@@ -258,6 +273,36 @@ def main():
         except Exception:
             hbm_measured = None
 
+    # ---- the same workload through the reference-compatible call pattern: activation OUTPUTS as operator
+    # inputs, a fresh non-leaf means2D per view, plain autograd (no grad_sink) -- what render/uv_tex_render.py does.
+    compat = None
+    if rank == 0 and with_bwd:
+        raw = {n: leaves[n].detach().clone().requires_grad_(True) for n in names}
+        raw["scales"] = leaves["scales"].detach().log().requires_grad_(True)
+        op = leaves["opacities"].detach().clamp(1e-6, 1 - 1e-6)
+        raw["opacities"] = torch.log(op / (1 - op)).requires_grad_(True)
+
+        def compat_view(v):
+            m2 = torch.zeros_like(raw["means3D"], requires_grad=True) + 0
+            m2.retain_grad()
+            out = GaussianRasterizer(settings(cams[v]))(
+                means3D=raw["means3D"], means2D=m2, shs=raw["shs"], opacities=torch.sigmoid(raw["opacities"]),
+                scales=torch.exp(raw["scales"]), rotations=torch.nn.functional.normalize(raw["rotations"]),
+                uvs=raw["uvs"], gradient_uvs=juv, texture=raw["texture"], extra_attrs=None)
+            torch.autograd.backward([out[0], out[3], out[2]], [g_img, g_alpha, g_norm])
+        nv = min(16, len(my_views))
+        for v in my_views[:4]:
+            compat_view(v)
+        torch.cuda.synchronize(dev)
+        c0 = time.perf_counter()
+        for v in my_views[:nv]:
+            compat_view(v)
+        torch.cuda.synchronize(dev)
+        compat = {"views_per_s": round(nv / (time.perf_counter() - c0), 2), "views": nv,
+                  "note": "one view per call through autograd: sigmoid/exp/normalize activations + their backward, fresh "
+                          "means2D, AccumulateGrad of every gradient (no fused sink); measured after the timed region"}
+        del raw
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(scene, cams[my_views[0]], W, H, with_bwd)
@@ -274,6 +319,9 @@ def main():
                        "num_rendered_D": s.D, "D_eff": D_eff, "parallelism": f"views sharded dp{world}",
                        "grad_allreduce": "RCCL SUM of one flat f32 bucket per step" if world > 1 else "none (1 GPU)"},
             "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
+            "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4),
+                                        "source": "torch.cuda.Event per step on the op's stream, this rank"},
+            "reference_call_pattern": compat,
             "alg_bytes_per_view": view_bytes,
             "pipeline_GBps": round(view_bytes * value / world / 1e9, 2),
             "pipeline_frac_of_hbm_peak": round(view_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
@@ -281,6 +329,7 @@ def main():
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in kinfo.items()},
+            "kernels_note": f"{DOMINANT}: HIP events inside the timed region; the others: two extra fully bracketed steps after it",
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 7
+#define TEXGS_ABI_VERSION 8
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
 #define TEXGS_ACC_FLOATS 32    /* per-Gaussian moment accumulators of the backward: one 128-byte line  */
@@ -64,29 +64,28 @@ typedef struct TexGSInputs {
                                   colors_precomp - 0.5                                                    */
 } TexGSInputs;
 
-/* Per-Gaussian state written by texgs_preprocess_forward. */
+/* Per-Gaussian state written by texgs_preprocess_forward (K1) and texgs_read_num_rendered (K2). */
 typedef struct TexGSGeom {
     float*    rec;             /* f32[N,32]: xy(2) conic(-a/2,-b,-c/2) opacity g(2) | G(6) phi(3) viewdep(3) depth normal(3) | rcull thr */
-    float*    depth;           /* f32[N] view-space z (sort key)                                       */
+    float*    depth;           /* f32[N] view-space z = the depth sort key (its bit pattern); 0xFFFFFFFF for culled Gaussians */
     int32_t*  radii;           /* i32[N] screen radius in px; 0 = culled (operator output `radii`)     */
     uint32_t* rect;            /* u32[N,2]: (minx | miny<<16), (maxx | maxy<<16) tile rectangle        */
     uint32_t* tiles_touched;   /* u32[N]                                                               */
-    uint32_t* offsets;         /* u32[N] inclusive prefix sum of tiles_touched                         */
-    void*     scan_temp;       /* >= texgs_scan_temp_bytes(N)                                          */
+    uint32_t* offsets;         /* u32[N] EXCLUSIVE prefix sum of tiles_touched in depth-rank order: offsets[r] = first
+                                  instance slot of the r-th Gaussian of the (depth bits, index) order (K2)              */
+    void*     scan_temp;       /* >= texgs_scan_temp_bytes(N): count tables, D total, depth-sorted (key, index) pairs */
     size_t    scan_temp_bytes;
 } TexGSGeom;
 
 /* Tile binning buffers, sized from num_rendered (D). */
 typedef struct TexGSBinning {
-    uint32_t  num_rendered;    /* D = offsets[N-1] (host value)                                        */
-    uint64_t* keys_unsorted;   /* u64[D]  (tile_id << 32) | float_bits(depth)                          */
-    uint64_t* keys_sorted;     /* u64[D]                                                               */
-    uint32_t* vals_unsorted;   /* u32[D]  Gaussian index                                               */
-    uint32_t* point_list;      /* u32[D]  Gaussian index, sorted by (tile, depth), stable              */
-    uint32_t* ranges;          /* u32[T,2] [first,last) into point_list per tile; caller zero-fills    */
+    uint32_t  num_rendered;    /* D = sum of tiles_touched (host value)                                */
+    uint64_t* keys_unsorted;   /* u64[D]  (tile_id << 32) | depth rank, emitted in depth-rank order (K3) */
+    uint64_t* keys_sorted;     /* u64[D]  (tile_id << 32) | float_bits(depth), sorted: the lineage's sorted key list */
+    uint32_t* point_list;      /* u32[D]  Gaussian index, sorted by (tile, depth, index)               */
+    uint32_t* ranges;          /* u32[T,2] [first,last) into point_list per tile (K3 zero-fills it)    */
     uint32_t* tile_order;      /* u32[T] tile ids, longest list first (launch order of the blend kernels) */
-    uint32_t* order_keys;      /* u32[3*T] scratch for the ordering sort                               */
-    void*     sort_temp;       /* >= texgs_sort_temp_bytes(D, T)                                       */
+    void*     sort_temp;       /* >= texgs_sort_temp_bytes(D, T): tile-pass count tables + u64[D] ping-pong buffer */
     size_t    sort_temp_bytes;
 } TexGSBinning;
 
@@ -142,15 +141,18 @@ size_t texgs_scan_temp_bytes(int32_t num_gaussians);
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
 size_t texgs_tex_bin_count(int32_t tex_res);
 
-/* K1 (frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold) + K2
- * (inclusive scan of tiles_touched).  Replaces the first half of _C.rasterize_gaussians. */
+/* K1: frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold, depth sort key, and
+ * D = sum of tiles_touched (device word).  Replaces the first half of _C.rasterize_gaussians. */
 int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, void* stream);
 
-/* The one device->host sync of the forward: D = offsets[N-1].  (Same sync exists in the lineage.) */
+/* The one device->host sync of the forward (the lineage has the same one): starts the asynchronous readback of D,
+ * launches K2 -- the stable 4-pass radix sort of the N Gaussians by depth bits and the exclusive scan of tiles_touched in
+ * that order, neither of which depends on D -- and only then waits for D, so the device is busy during the sync. */
 int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream);
 
-/* K3 duplicate-with-keys, K4 radix sort of 32+ceil(log2 T) key bits, K5 tile ranges, K6 16x16-tile
- * alpha-blend with cubemap fetch.  Second half of _C.rasterize_gaussians. */
+/* K3 duplicate-with-keys (in depth-rank order), K4 stable 2-pass radix sort of the D instances by tile id (the list is then
+ * ordered by (tile, depth bits, index) exactly like the lineage's one 32+ceil(log2 T)-bit sort), K5 tile ranges + tile
+ * launch order, K6 16x16-tile alpha-blend with cubemap fetch.  Second half of _C.rasterize_gaussians. */
 int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                                   TexGSBinning* bin, TexGSImage* img, void* stream);
 
@@ -182,6 +184,7 @@ enum {
     TEXGS_NUM_KERNELS = 9
 };
 int texgs_profile_enable(int on);
+int texgs_profile_select(uint32_t kernel_mask);      /* bit k = bracket kernel id k (default: all) */
 int texgs_profile_read(float* ms_sum_host, uint32_t* launches_host);
 
 /* Fused loss front-end for the operator's outputs -- the always-on terms of TextureGaussian3D.compute_loss

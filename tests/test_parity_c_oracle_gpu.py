@@ -48,7 +48,6 @@ def test_integer_stages_bit_exact(lib_built, name):
     t = s.tensors
     assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
     assert np.array_equal(t["tiles_touched"][:N].cpu().numpy().astype(np.uint32), ref.tiles[:N])
-    assert np.array_equal(t["offsets"][:N].cpu().numpy().astype(np.uint32), ref.offsets[:N])
     assert s.D == ref.D
     vis = ref.radii[:N] > 0
     rect = t["rect"][:N].cpu().numpy().astype(np.uint32)
@@ -56,9 +55,19 @@ def test_integer_stages_bit_exact(lib_built, name):
     assert np.array_equal(got[vis], ref.rect[:N][vis])
     depth = t["depth"][:N].cpu().numpy()
     assert np.array_equal(depth[vis].view(np.uint32), ref.depth[:N][vis].view(np.uint32))     # sort-key bits
+    assert np.all(depth[~vis].view(np.uint32) == 0xFFFFFFFF)                                  # culled: after every visible one
     D = ref.D
-    assert np.array_equal(t["keys_unsorted"][:D].cpu().numpy().view(np.uint64), ref.keys_unsorted[:D])
-    assert np.array_equal(t["vals_unsorted"][:D].cpu().numpy().astype(np.uint32), ref.vals_unsorted[:D])
+    # K2 / K3 contract (include/texgs.h): Gaussians ranked by (depth bits, index) with culled ones last; offsets = exclusive
+    # scan of tiles_touched in rank order; instance k of the r-th ranked Gaussian = (tile << 32) | r at offsets[r] + k
+    key = np.where(vis, ref.depth[:N].view(np.uint32), np.uint32(0xFFFFFFFF)).astype(np.uint64)
+    order = np.argsort(key, kind="stable")
+    tt_rank = ref.tiles[:N][order].astype(np.int64)
+    offs_rank = np.cumsum(tt_rank) - tt_rank
+    assert np.array_equal(t["offsets"][:N].cpu().numpy().astype(np.uint32).astype(np.int64), offs_rank)
+    offs_idx = ref.offsets[:N].astype(np.int64) - ref.tiles[:N].astype(np.int64)               # lineage: exclusive, index order
+    src = np.repeat(offs_idx[order], tt_rank) + (np.arange(D) - np.repeat(offs_rank, tt_rank))
+    exp_unsorted = (ref.keys_unsorted[:D][src] & np.uint64(0xFFFFFFFF00000000)) | np.repeat(np.arange(N, dtype=np.uint64), tt_rank)
+    assert np.array_equal(t["keys_unsorted"][:D].cpu().numpy().view(np.uint64), exp_unsorted)
     assert np.array_equal(t["keys_sorted"][:D].cpu().numpy().view(np.uint64), ref.keys_sorted[:D])
     assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
     assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)

@@ -106,7 +106,6 @@ def test_integer_stages_vs_oracle(lib_built):
     # depth ties / fp32-vs-fp64 depth rounding can swap neighbours inside a tile: order identical in >= 98 % of tiles
     assert same_order >= 0.98 * len(exp), (same_order, len(exp))
     if not mism:
-        assert torch.equal(s.tensors["offsets"].cpu().to(torch.int64), binning["offsets"])
         assert torch.equal(s.tensors["ranges"].cpu().to(torch.int64), binning["ranges"])
     nc = s.tensors["n_contrib"].cpu().to(torch.int64)
     agree = float((nc == dbg["n_contrib"]).float().mean())

@@ -16,6 +16,8 @@ thread_local char g_err[512] = "";
 struct EvRec { int kid; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+uint32_t g_prof_mask = 0xFFFFFFFFu;       // kernel ids to bracket (an event pair costs ~5 us of stream time: bench.py brackets
+                                          // only the dominant kernel inside its timed region)
 std::vector<EvRec> g_prof_log;
 std::vector<hipEvent_t> g_prof_free;
 
@@ -28,7 +30,7 @@ struct ProfScope {          // brackets the launches issued inside its lifetime
     int kid; hipStream_t s; hipEvent_t a; bool on;
     ProfScope(int k, hipStream_t st) : kid(k), s(st), a(nullptr), on(false) {
         std::lock_guard<std::mutex> l(g_prof_mu);
-        if (g_prof_on) { on = true; a = prof_event(); (void)hipEventRecord(a, s); }
+        if (g_prof_on && ((g_prof_mask >> k) & 1u)) { on = true; a = prof_event(); (void)hipEventRecord(a, s); }
     }
     ~ProfScope() {
         if (!on) return;
@@ -94,22 +96,45 @@ int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, Tex
     if (geom->scan_temp_bytes < scan_temp_bytes(frame->num_gaussians)) return fail_msg("scan_temp too small");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
+    if (int r = launch_bin_header(geom, frame->num_gaussians, s)) return fail("bin header memset", (hipError_t)r);
     { ProfScope p(TEXGS_K_PREPROCESS_FWD, s); launch_preprocess_fwd(c, frame, in, geom, s); }
     if (int r = check(frame, s, "preprocess_fwd")) return r;
-    { ProfScope p(TEXGS_K_SCAN, s);
-      if (int r = launch_scan(geom, frame->num_gaussians, s)) return fail("inclusive_scan", (hipError_t)r); }
-    return check(frame, s, "inclusive_scan");
+    return 0;
 }
 
+// K2: depth sort of the Gaussians + exclusive scan of tiles_touched in depth-rank order (independent of D)
+static int depth_sort_scan(const TexGSFrame* frame, TexGSGeom* geom, hipStream_t s) {
+    if (frame->num_gaussians == 0) return 0;
+    { ProfScope p(TEXGS_K_SCAN, s);
+      if (int r = launch_depth_sort_scan(geom, frame->num_gaussians, s)) return fail("depth sort / scan", (hipError_t)r); }
+    return check(frame, s, "depth sort / scan");
+}
+
+namespace {
+struct Readback { uint32_t* host = nullptr; hipEvent_t ev = nullptr; };
+thread_local Readback g_rb;       // one pinned word + event per host thread (the D readback), created on first use
+}
+
+// D = sum of tiles_touched (K1 accumulates it): asynchronous copy into pinned memory, then depth sort + scan are
+// launched, and only then the host waits -- the device stays busy during the one unavoidable device->host sync.
 int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream) {
     if (!geom || !host_out) return fail_msg("NULL argument");
     *host_out = 0;
     if (num_gaussians <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemcpyAsync(host_out, geom->offsets + (num_gaussians - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (!g_rb.host) {
+        if (hipHostMalloc((void**)&g_rb.host, 64, hipHostMallocDefault) != hipSuccess) return fail_msg("hipHostMalloc failed");
+        if (hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming) != hipSuccess) return fail_msg("hipEventCreate failed");
+    }
+    hipError_t e = hipMemcpyAsync(g_rb.host, bin_total_ptr(geom, num_gaussians), sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return fail("num_rendered readback", e);
-    e = hipStreamSynchronize(s);
+    e = hipEventRecord(g_rb.ev, s);
+    if (e != hipSuccess) return fail("num_rendered event", e);
+    TexGSFrame f0; memset(&f0, 0, sizeof(f0)); f0.num_gaussians = num_gaussians;
+    if (int r = depth_sort_scan(&f0, const_cast<TexGSGeom*>(geom), s)) return r;
+    e = hipEventSynchronize(g_rb.ev);
     if (e != hipSuccess) return fail("num_rendered sync", e);
+    *host_out = *g_rb.host;
     return 0;
 }
 
@@ -131,12 +156,13 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     if (bin->num_rendered > 0) {
-
+        if (bin->sort_temp_bytes < sort_temp_bytes(bin->num_rendered, (uint32_t)(c.tiles_x * c.tiles_y))) return fail_msg("sort_temp too small");
+        if (int r = launch_sort_header(bin->sort_temp, s)) return fail("sort header memset", (hipError_t)r);
         { ProfScope p(TEXGS_K_DUPLICATE, s); launch_duplicate(c, geom, bin, s); }
         if (int r = check(frame, s, "duplicate_with_keys")) return r;
         { ProfScope p(TEXGS_K_SORT, s);
-          if (int r = launch_sort(c, bin, s)) return fail("radix_sort_pairs", (hipError_t)r); }
-        if (int r = check(frame, s, "radix_sort_pairs")) return r;
+          if (int r = launch_sort(c, geom, bin, s)) return fail("tile sort", (hipError_t)r); }
+        if (int r = check(frame, s, "tile sort")) return r;
     }
     { ProfScope p(TEXGS_K_RANGES, s); launch_ranges(c, bin, s); }
     if (int r = check(frame, s, "tile_ranges")) return r;
@@ -186,6 +212,12 @@ int texgs_profile_enable(int on) {
         for (auto& r : g_prof_log) { g_prof_free.push_back(r.a); g_prof_free.push_back(r.b); }
         g_prof_log.clear();
     }
+    return 0;
+}
+
+int texgs_profile_select(uint32_t kernel_mask) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof_mask = kernel_mask;
     return 0;
 }
 

@@ -235,8 +235,9 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ uvs,
                  const float* __restrict__ juv, const float* __restrict__ coff,
                  float4* __restrict__ rec, float* __restrict__ depth, int32_t* __restrict__ radii,
-                 uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched) {
+                 uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ total_D) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
+    __shared__ uint32_t s_tt[TG_BLOCK / 64];
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
     const bool live = i < C.N;
     const Frame F = load_frame(vm, pm, cp);
@@ -257,9 +258,21 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
         for (int k = threadIdx.x; k < count; k += TG_BLOCK) s_sh[k] = shs[first + k];
         __syncthreads();
     }
+    {   // D = sum of tiles_touched: one atomic per workgroup (the host reads it back while the depth sort runs)
+        uint32_t tt = (live && g.valid) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+        for (int d = 32; d >= 1; d >>= 1) tt += __shfl_xor(tt, d, 64);
+        if ((threadIdx.x & 63) == 0) s_tt[threadIdx.x >> 6] = tt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0u;
+            for (int w = 0; w < TG_BLOCK / 64; ++w) sum += s_tt[w];
+            if (sum != 0u) atomicAdd(total_D, sum);
+        }
+    }
     if (!live) return;
     if (!g.valid) {
-        radii[i] = 0; tiles_touched[i] = 0; depth[i] = 0.0f; rect[i] = make_uint2(0u, 0u);
+        radii[i] = 0; tiles_touched[i] = 0; rect[i] = make_uint2(0u, 0u);
+        depth[i] = __uint_as_float(0xFFFFFFFFu);   // sort key of a culled Gaussian: after every visible one
         return;                                   // record left unwritten: never gathered (no instances)
     }
     // view-dependent colour: SH bands 1..deg at the (unit) view direction
@@ -549,7 +562,7 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset,
                        reinterpret_cast<float4*>(g->rec), g->depth, g->radii, reinterpret_cast<uint2*>(g->rect),
-                       g->tiles_touched);
+                       g->tiles_touched, bin_total_ptr(g, c.N));
 }
 
 void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 ERR_CAPACITY = 1000
 TILE = 16
 REC_FLOATS = 32
@@ -33,10 +33,8 @@ class Geom(C.Structure):
 
 
 class Binning(C.Structure):
-    _fields_ = [("num_rendered", C.c_uint32), ("keys_unsorted", _fp), ("keys_sorted", _fp),
-                ("vals_unsorted", _fp), ("point_list", _fp), ("ranges", _fp), ("tile_order", _fp), ("order_keys", _fp),
-                ("sort_temp", _fp),
-                ("sort_temp_bytes", C.c_size_t)]
+    _fields_ = [("num_rendered", C.c_uint32), ("keys_unsorted", _fp), ("keys_sorted", _fp), ("point_list", _fp),
+                ("ranges", _fp), ("tile_order", _fp), ("sort_temp", _fp), ("sort_temp_bytes", C.c_size_t)]
 
 
 class Image(C.Structure):
@@ -55,7 +53,7 @@ class Grads(C.Structure):
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
-           "texgs_profile_read", "texgs_selftest_waveops"]
+           "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
 
@@ -96,6 +94,8 @@ def load():
     lib.texgs_selftest_waveops.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]
     lib.texgs_profile_enable.restype = C.c_int
+    lib.texgs_profile_select.argtypes = [C.c_uint32]
+    lib.texgs_profile_select.restype = C.c_int
     lib.texgs_profile_read.argtypes = [P(C.c_float), P(C.c_uint32)]
     lib.texgs_profile_read.restype = C.c_int
     for name in ("texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
@@ -114,7 +114,11 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
-def profile_enable(on: bool):
+def profile_enable(on: bool, only=None):
+    """Bracket kernel launches with HIP events.  `only`: iterable of KERNEL_NAMES to restrict to (an event pair costs a few
+    microseconds of stream time, so a timed region should bracket as little as it needs)."""
+    mask = 0xFFFFFFFF if only is None else sum(1 << KERNEL_NAMES.index(n) for n in only)
+    check(load().texgs_profile_select(mask), "texgs_profile_select")
     check(load().texgs_profile_enable(1 if on else 0), "texgs_profile_enable")
 
 

@@ -189,20 +189,18 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         n_contrib = torch.empty(H, W, **i32)
         img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), _ptr(final_T),
                          _ptr(n_contrib))
-        ranges = torch.zeros(tiles, 2, **i32)
+        ranges = torch.empty(tiles, 2, **i32)          # zero-filled by K3
         tile_order = torch.empty(tiles, **i32)
-        order_keys = torch.empty(3 * tiles, **i32)
 
         def alloc_bin(cap):
             keys_u = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
             keys_s = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
-            vals_u = torch.empty(max(cap, 1), **i32)
             point_list = torch.empty(max(cap, 1), **i32)
             sort_bytes = lib.texgs_sort_temp_bytes(cap, tiles)
             sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
-            b = _lib.Binning(0, _ptr(keys_u), _ptr(keys_s), _ptr(vals_u), _ptr(point_list), _ptr(ranges),
-                             _ptr(tile_order), _ptr(order_keys), _ptr(sort_temp), sort_bytes)
-            return b, (keys_u, keys_s, vals_u, point_list, sort_temp)
+            b = _lib.Binning(0, _ptr(keys_u), _ptr(keys_s), _ptr(point_list), _ptr(ranges), _ptr(tile_order), _ptr(sort_temp),
+                             sort_bytes)
+            return b, (keys_u, keys_s, point_list, sort_temp)
         hint_key = (device.index, N, H, W)
         cap = _CAPACITY_HINT.get(hint_key, max(4 * N, 1024))
         binning, bin_t = alloc_bin(cap)
@@ -218,13 +216,13 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
                                                    C.byref(img), stream)
         _lib.check(rc, "texgs_forward")
         _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
-        keys_u, keys_s, vals_u, point_list, sort_temp = bin_t
+        keys_u, keys_s, point_list, sort_temp = bin_t
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
     s.tensors = dict(keep=keep, rec=rec, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
-                     offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s, vals_unsorted=vals_u,
-                     point_list=point_list, ranges=ranges, tile_order=tile_order, order_keys=order_keys,
+                     offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s,
+                     point_list=point_list, ranges=ranges, tile_order=tile_order,
                      final_T=final_T, n_contrib=n_contrib,
                      scan_temp=scan_temp, sort_temp=sort_temp,
                      out=(out_color, out_depth, out_norm, out_alpha))
@@ -307,6 +305,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None,
                 grad_sink=None):
         ctx.sinks = None
+        ctx.set_materialize_grads(False)     # outputs without an upstream gradient arrive as None, not as zero-filled tensors
         if grad_sink is not None:        # fused accumulation: inputs that ARE registered leaves get their .grad slice
             named = dict(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales,
                          rotations=rotations, uvs=uvs, texture=texture, color_offset=color_offset)
