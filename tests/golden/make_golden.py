@@ -10,6 +10,10 @@ no source) travel to the GPU box, the reference does not.
   losses.npz   losses/pixelwise_loss.py l1_loss and losses/ssim_loss.py ssim_loss on small random images
   loss_frontend.npz  (1-l)*l1 + l*(1-ssim) + la*l1(alpha) with those functions AND their autograd gradients: the
                fused HIP loss front-end (texgs.losses) is pinned against the reference itself
+  texture_io.npz  models/texture_gaussian3d.py rgb2sh0 / sh02rgb / cube_map / change_texture(modes -1..3): the module
+               itself cannot be imported here (cv2, tinycudann, nvdiffrast), so the four function definitions are taken
+               from its source with `ast` at generation time and RUN (nothing of them is stored); input = a 12-px-per-face
+               downsample of assets/textures/mosaic.png and a random SH-DC texture
   op_small.npz the operator itself on a tiny seeded scene, as computed by oracle/texgs_torch.py in float64
                (regression pin of the oracle; the reference holds no vector for the operator: parity unpinned)
 """
@@ -104,6 +108,42 @@ def losses():
     np.savez_compressed(os.path.join(HERE, "loss_frontend.npz"), **out)
 
 
+def texture_io():
+    import ast
+    from PIL import Image
+    src = open(os.path.join(REF, "models", "texture_gaussian3d.py")).read()
+    tree = ast.parse(src)
+    want_top = {"rgb2sh0", "sh02rgb"}
+    want_methods = {"cube_map", "change_texture"}
+    funcs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want_top]
+    for cls in (n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TextureGaussian3D"):
+        funcs += [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want_methods]
+    assert {f.name for f in funcs} == want_top | want_methods
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), "<reference functions>", "exec"), ns)
+
+    class Holder:                       # the two methods only touch self._texture
+        pass
+    g = torch.Generator().manual_seed(5)
+    r = 12
+    mosaic = np.asarray(Image.open(os.path.join(REF, "assets", "textures", "mosaic.png")).convert("RGB"))
+    ys = (np.arange(3 * r) * mosaic.shape[0]) // (3 * r)
+    xs = (np.arange(4 * r) * mosaic.shape[1]) // (4 * r)
+    cross_u8 = mosaic[ys][:, xs]                                  # nearest-neighbour decimation: just a small data sample
+    cross = torch.tensor(cross_u8.astype(np.float32) / 255.0)
+    tex0 = torch.randn(6, r, r, 3, generator=g) * 1.5
+    out = {"cross_u8": cross_u8, "texture0": tex0.numpy()}
+    out["sh02rgb"] = ns["sh02rgb"](tex0).numpy()
+    out["rgb2sh0"] = ns["rgb2sh0"](cross).numpy()
+    h = Holder(); h._texture = tex0.clone()
+    out["cube_map"] = ns["cube_map"](h).numpy()
+    for mode in (-1, 0, 1, 2, 3):
+        h = Holder(); h._texture = tex0.clone()
+        ns["change_texture"](h, cross.clone(), mode=mode)
+        out[f"change_texture_m{mode + 1}"] = h._texture.numpy()
+    np.savez_compressed(os.path.join(HERE, "texture_io.npz"), **out)
+
+
 def op_small():
     from texgs import synth
     import helpers as Hh
@@ -122,5 +162,7 @@ def op_small():
 
 
 if __name__ == "__main__":
-    cameras(); sh(); cube(); losses(); op_small()
+    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "texture_io", "op_small"]
+    for name in which:
+        globals()[name]()
     print("golden fixtures written to", HERE)
