@@ -196,6 +196,18 @@ int texgs_rgb_alpha_loss(const float* image, const float* gt_image, const float*
                          int32_t H, int32_t W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums,
                          float* dL_dimage, float* dL_dalpha, void* stream);
 
+/* Geometric regularisers of TextureGaussian3D.compute_loss on the operator's normal / depth outputs
+ * (models/texture_gaussian3d.py:347-368), the producers of dL/dnorm and dL/ddepth for texgs_backward:
+ *   lambda_norm   * norm_loss(norm, gt_norm, mask)        losses/norm_reg_loss.py:66-71
+ *   lambda_smooth * smooth_loss(gt_image, norm, mask)     losses/smooth_loss.py:4-27 (bilateral weight exp(-|d rgb|_1 / gamma))
+ *   lambda_depth  * l1_loss(depth, gt_depth)              losses/pixelwise_loss.py
+ * norm, gt_norm, gt_image f32[3,H,W]; mask f32[1,H,W] or NULL (= ones); depth, gt_depth f32[1,H,W]; a term with lambda 0
+ * is skipped and its pointers may be NULL.  sums f32[12] receives {sum m, sum (1-<n,g>) m, sum w_k (4), sum w_k|dn| (4),
+ * sum |d-d_gt|, 0}; dL_dnorm / dL_ddepth are written for d(loss) = 1. */
+int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_image, const float* mask, const float* depth,
+                      const float* gt_depth, int32_t H, int32_t W, float lambda_norm, float lambda_smooth, float gamma,
+                      float lambda_depth, float* sums, float* dL_dnorm, float* dL_ddepth, void* stream);
+
 /* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
  * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,
  * nine blocks of 64 differences against the __shfl_xor formulation -- all exactly 0 on gfx950. */

@@ -32,3 +32,29 @@ def rgb_alpha_loss(image, gt_image, alpha, gt_alpha, lam, la):
     if alpha is not None:
         loss = loss + la * (alpha - gt_alpha).abs().mean()
     return loss
+
+
+def norm_loss(pred, gt, mask=None):
+    """losses/norm_reg_loss.py:66-71."""
+    if mask is None:
+        return torch.mean(1.0 - torch.sum(pred * gt, dim=0))
+    return torch.sum((1.0 - torch.sum(pred * gt, dim=0, keepdim=True)) * mask) / (mask.sum() + 1e-6)
+
+
+def smooth_loss(rgb, value, mask, gamma=0.1):
+    """losses/smooth_loss.py:4-27: bilateral first-order smoothness over right / down / down-right / anti-diagonal
+    neighbours, weight exp(-|d rgb|_1 / gamma) * mask_a * mask_b, each direction normalised by its weight sum."""
+    pairs = [(lambda t: t[:, :, :-1], lambda t: t[:, :, 1:]), (lambda t: t[:, :-1, :], lambda t: t[:, 1:, :]),
+             (lambda t: t[:, :-1, :-1], lambda t: t[:, 1:, 1:]), (lambda t: t[:, 1:, :-1], lambda t: t[:, :-1, 1:])]
+    total = 0.0
+    for a, b in pairs:
+        w = torch.exp(-(a(rgb) - b(rgb)).abs().sum(0, keepdim=True) / gamma) * a(mask) * b(mask)
+        total = total + (w * (a(value) - b(value))).abs().sum() / (w.sum() + 1e-6)
+    return total / 4
+
+
+def geom_losses(norm, gt_norm, gt_image, mask, depth, gt_depth, ln, ls, ld, gamma=0.1):
+    loss = ln * norm_loss(norm, gt_norm, mask) + ls * smooth_loss(gt_image, norm, mask, gamma)
+    if depth is not None:
+        loss = loss + ld * (depth - gt_depth).abs().mean()
+    return loss

@@ -10,6 +10,9 @@ no source) travel to the GPU box, the reference does not.
   losses.npz   losses/pixelwise_loss.py l1_loss and losses/ssim_loss.py ssim_loss on small random images
   loss_frontend.npz  (1-l)*l1 + l*(1-ssim) + la*l1(alpha) with those functions AND their autograd gradients: the
                fused HIP loss front-end (texgs.losses) is pinned against the reference itself
+  geom_losses.npz  losses/norm_reg_loss.py norm_loss, losses/smooth_loss.py smooth_loss and losses/pixelwise_loss.py l1_loss
+               combined as models/texture_gaussian3d.py:347-368 combines them (lambda_norm 0.1, lambda_norm_smooth 0.5 of
+               configs/texture_gaussian3d.yaml, plus a depth term), values AND autograd gradients w.r.t. norm / depth
   texture_io.npz  models/texture_gaussian3d.py rgb2sh0 / sh02rgb / cube_map / change_texture(modes -1..3): the module
                itself cannot be imported here (cv2, tinycudann, nvdiffrast), so the four function definitions are taken
                from its source with `ast` at generation time and RUN (nothing of them is stored); input = a 12-px-per-face
@@ -108,6 +111,39 @@ def losses():
     np.savez_compressed(os.path.join(HERE, "loss_frontend.npz"), **out)
 
 
+def geom_losses():
+    sys.path.insert(0, REF)
+    from losses.pixelwise_loss import l1_loss
+    from losses.norm_reg_loss import norm_loss
+    from losses.smooth_loss import smooth_loss
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for tag, (H, W) in {"s": (21, 27), "m": (48, 40)}.items():
+        norm = torch.randn(3, H, W, generator=g)
+        norm = (norm / norm.norm(dim=0, keepdim=True) * (0.3 + 0.7 * torch.rand(1, H, W, generator=g))).requires_grad_(True)
+        gtn = torch.randn(3, H, W, generator=g)
+        gtn = gtn / gtn.norm(dim=0, keepdim=True)
+        # piecewise-smooth image so the bilateral weights span (0, 1]
+        gti = (torch.rand(3, H // 6 + 1, W // 6 + 1, generator=g).repeat_interleave(6, 1).repeat_interleave(6, 2)[:, :H, :W]
+               + 0.05 * torch.rand(3, H, W, generator=g)).clamp(0, 1)
+        mask = (torch.rand(1, H, W, generator=g) > 0.25).float()
+        depth = (3.0 + torch.rand(1, H, W, generator=g)).requires_grad_(True)
+        gtd = 3.0 + torch.rand(1, H, W, generator=g)
+        ln, ls, ld = 0.1, 0.5, 0.3
+        Lnorm = norm_loss(norm, gtn, mask)
+        Lnsm = smooth_loss(gti, norm, mask)
+        Ld = l1_loss(depth, gtd)
+        loss = ln * Lnorm + ls * Lnsm + ld * Ld
+        loss.backward()
+        out.update({f"{tag}_norm": norm.detach().numpy(), f"{tag}_gtn": gtn.numpy(), f"{tag}_gti": gti.numpy(),
+                    f"{tag}_mask": mask.numpy(), f"{tag}_depth": depth.detach().numpy(), f"{tag}_gtd": gtd.numpy(),
+                    f"{tag}_loss": float(loss), f"{tag}_Lnorm": float(Lnorm), f"{tag}_Lnsm": float(Lnsm), f"{tag}_Ld": float(Ld),
+                    f"{tag}_dnorm": norm.grad.numpy(), f"{tag}_ddepth": depth.grad.numpy()})
+        # mask = None variant of the smoothness term is not reachable in the reference (mask.float() on None): skipped
+    out.update(ln=0.1, ls=0.5, ld=0.3, gamma=0.1)
+    np.savez_compressed(os.path.join(HERE, "geom_losses.npz"), **out)
+
+
 def texture_io():
     import ast
     from PIL import Image
@@ -162,7 +198,7 @@ def op_small():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "texture_io", "op_small"]
+    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "texture_io", "op_small"]
     for name in which:
         globals()[name]()
     print("golden fixtures written to", HERE)

@@ -268,6 +268,31 @@ def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
                 assert r < 1e-5, (mode, name, r)
 
 
+def test_retexture_path_from_cross_image(lib_built):
+    """retexture.py's path with texgs.texture_io: cross image (fixture: a 12-px-per-face sample of the reference's
+    assets/textures/mosaic.png) -> resize -> change_texture -> forward-only renders at full SH degree and degree 0
+    (models/texture_gaussian3d.py:499-511), against the oracle rendering the same texture."""
+    from texgs import texture_io as TIO
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "texture_io.npz"))
+    R = 48
+    cross = torch.tensor(TIO.resize_bilinear_u8(G["cross_u8"], 3 * R, 4 * R).astype(np.float32) / 255.0)
+    scene = synth.make_scene(2500, R, seed=17, scale_mean=0.03)
+    tex = TIO.change_texture(scene.texture, cross, mode=0)
+    assert tuple(tex.shape) == (6, R, R, 3)
+    scene = scene._replace(texture=tex.contiguous())
+    cam = synth.fibonacci_cameras(4, 208, 160)[0]
+    bg = torch.zeros(3)
+    for deg in (3, 0):
+        ref, dbg, _ = Hh.oracle_run(scene, cam, deg, bg)
+        out, _ = Hh.hip_run(scene, cam, deg, bg)
+        amb = dbg["ambiguity"] < 1e-4
+        res = Hh.forward_errors(f"retexture/mosaic/sh{deg}", out, ref, amb)
+        assert res["image"][0] < 1e-4 and res["alpha"][0] < 1e-4
+    # and back out: the cross image of the new texture is the (clamped) input modulated by mode 0
+    back = TIO.cross_to_cube(TIO.texture_to_cross(tex))
+    assert torch.allclose(back, TIO.sh02rgb(tex))
+
+
 def test_wave_ops_primitives_on_hardware(lib_built):
     """csrc/wave_ops.h (DPP row_shl/shr exchanges, permlane16/32 swaps, transposing butterflies incl. the inline-asm
     bank-first one): every primitive equals the __shfl_xor formulation, exactly, for several random seeds."""

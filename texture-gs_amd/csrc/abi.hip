@@ -249,6 +249,20 @@ int texgs_rgb_alpha_loss(const float* image, const float* gt_image, const float*
     return e == hipSuccess ? 0 : fail("rgb_alpha_loss", e);
 }
 
+int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_image, const float* mask, const float* depth,
+                      const float* gt_depth, int32_t H, int32_t W, float lambda_norm, float lambda_smooth, float gamma,
+                      float lambda_depth, float* sums, float* dL_dnorm, float* dL_ddepth, void* stream) {
+    if (!sums) return fail_msg("NULL argument");
+    if (H <= 0 || W <= 0 || !(gamma > 0.f)) return fail_msg("image size and gamma must be positive");
+    if (lambda_norm != 0.f && (!norm || !gt_norm || !dL_dnorm)) return fail_msg("norm term needs norm, gt_norm, dL_dnorm");
+    if (lambda_smooth != 0.f && (!norm || !gt_image || !dL_dnorm)) return fail_msg("smoothness term needs norm, gt_image, dL_dnorm");
+    if (lambda_depth != 0.f && (!depth || !gt_depth || !dL_ddepth)) return fail_msg("depth term needs depth, gt_depth, dL_ddepth");
+    launch_geom_losses(norm, gt_norm, gt_image, mask, depth, gt_depth, H, W, lambda_norm, lambda_smooth, gamma, lambda_depth, sums,
+                       dL_dnorm, dL_ddepth, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("geom_losses", e);
+}
+
 int texgs_selftest_waveops(const float* seed128, float* out576, void* stream) {
     if (!seed128 || !out576) return fail_msg("NULL argument");
     launch_selftest_waveops(seed128, out576, (hipStream_t)stream);

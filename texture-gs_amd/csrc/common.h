@@ -76,3 +76,6 @@ int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float
                           int W, float lambda_dssim, float lambda_alpha, float* scratch, float* sums, float* d_image,
                           float* d_alpha, hipStream_t s);
 void launch_selftest_waveops(const float* seed128, float* out576, hipStream_t s);
+int launch_geom_losses(const float* norm, const float* gt_norm, const float* gt_image, const float* mask, const float* depth,
+                       const float* gt_depth, int H, int W, float lambda_norm, float lambda_smooth, float gamma,
+                       float lambda_depth, float* sums, float* d_norm, float* d_depth, hipStream_t s);

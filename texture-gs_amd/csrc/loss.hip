@@ -128,7 +128,132 @@ k_alpha_l1(int P, const float* __restrict__ a, const float* __restrict__ gt, flo
     if (threadIdx.x == 0) atomicAdd(sums + 2, t);
 }
 
+// ---- geometric regularisers of TextureGaussian3D.compute_loss (models/texture_gaussian3d.py:347-368) on the operator's
+// normal / depth outputs -- the terms that feed dL/dnorm and dL/ddepth into K7:
+//   norm_loss(norm, gt_norm, mask)   losses/norm_reg_loss.py:66-71   sum((1 - <n, g>) m) / (sum m + 1e-6)
+//   smooth_loss(gt_image, norm, mask) losses/smooth_loss.py:4-27     bilateral first-order smoothness over the 4 neighbour
+//        directions k (right, down, down-right, anti-diagonal): w_k = exp(-sum_c |d rgb| / gamma) m_a m_b,
+//        L = 1/4 sum_k  sum(w_k sum_c |d n_c|) / (sum w_k + 1e-6)
+//   l1_loss(depth, gt_depth)         losses/pixelwise_loss.py        mean |d - d_gt|
+// Two HBM-bound kernels: the normalisers sum m and sum w_k depend only on the ground truth, so k_geom_sums reduces them
+// (and the loss numerators) and k_geom_grad then writes dL/dnorm, dL/ddepth in one pass.
+// sums: [0] sum m  [1] sum (1-<n,g>) m  [2..5] sum w_k  [6..9] sum w_k |dn|  [10] sum |d - d_gt|
+struct GeomArgs {
+    int H, W;
+    const float *norm, *gt_norm, *gt_image, *mask, *depth, *gt_depth;
+    float inv_gamma;
+};
+
+__device__ __forceinline__ float pair_weight(const GeomArgs& a, int ya, int xa, int yb, int xb) {
+    const size_t P = (size_t)a.H * a.W, ia = (size_t)ya * a.W + xa, ib = (size_t)yb * a.W + xb;
+    const float d = fabsf(a.gt_image[ia] - a.gt_image[ib]) + fabsf(a.gt_image[P + ia] - a.gt_image[P + ib])
+                  + fabsf(a.gt_image[2 * P + ia] - a.gt_image[2 * P + ib]);
+    float w = __expf(-d * a.inv_gamma);
+    if (a.mask) w *= a.mask[ia] * a.mask[ib];
+    return w;
+}
+// pair k anchored at (y, x): (ya, xa) - (yb, xb); false when it leaves the image
+__device__ __forceinline__ bool pair_ends(int k, int y, int x, int H, int W, int& ya, int& xa, int& yb, int& xb) {
+    ya = y; xa = x;
+    if (k == 0) { yb = y; xb = x + 1; }
+    else if (k == 1) { yb = y + 1; xb = x; }
+    else if (k == 2) { yb = y + 1; xb = x + 1; }
+    else { ya = y + 1; xa = x; yb = y; xb = x + 1; }
+    return ya >= 0 && yb >= 0 && xa >= 0 && xb >= 0 && ya < H && yb < H && xa < W && xb < W;
+}
+
+__global__ void __launch_bounds__(256)
+k_geom_sums(GeomArgs a, int do_norm, int do_smooth, int do_depth, float* __restrict__ sums) {
+    __shared__ float s_red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x, P = a.H * a.W;
+    const bool in = i < P;
+    const int y = in ? i / a.W : 0, x = in ? i % a.W : 0;
+    float v[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = 0.f;
+    if (in) {
+        const float n0 = a.norm ? a.norm[i] : 0.f, n1 = a.norm ? a.norm[P + i] : 0.f, n2 = a.norm ? a.norm[2 * P + i] : 0.f;
+        if (do_norm) {
+            const float m = a.mask ? a.mask[i] : 1.f;
+            v[0] = m;
+            v[1] = (1.f - (n0 * a.gt_norm[i] + n1 * a.gt_norm[P + i] + n2 * a.gt_norm[2 * P + i])) * m;
+        }
+        if (do_smooth) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int ya, xa, yb, xb;
+                if (!pair_ends(k, y, x, a.H, a.W, ya, xa, yb, xb)) continue;
+                const float w = pair_weight(a, ya, xa, yb, xb);
+                const size_t ia = (size_t)ya * a.W + xa, ib = (size_t)yb * a.W + xb;
+                v[2 + k] = w;
+                v[6 + k] = fabsf(w * (a.norm[ia] - a.norm[ib])) + fabsf(w * (a.norm[P + ia] - a.norm[P + ib]))
+                         + fabsf(w * (a.norm[2 * P + ia] - a.norm[2 * P + ib]));
+            }
+        }
+        if (do_depth) v[10] = fabsf(a.depth[i] - a.gt_depth[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float t = block_sum(v[k], s_red);
+        if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + k, t);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_geom_grad(GeomArgs a, float l_norm, float l_smooth, float l_depth, const float* __restrict__ sums,
+            float* __restrict__ d_norm, float* __restrict__ d_depth) {
+    const int i = blockIdx.x * 256 + threadIdx.x, P = a.H * a.W;
+    if (i >= P) return;
+    const int y = i / a.W, x = i % a.W;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (l_norm != 0.f) {
+        const float c = -l_norm * (a.mask ? a.mask[i] : 1.f) / (sums[0] + 1e-6f);
+        g0 = c * a.gt_norm[i]; g1 = c * a.gt_norm[P + i]; g2 = c * a.gt_norm[2 * P + i];
+    }
+    if (l_smooth != 0.f) {
+        // this pixel is end `a` of the pairs anchored at ... and end `b` of the pairs anchored at ...
+        const int ay[4] = {y, y, y, y - 1}, ax[4] = {x, x, x, x};             // anchors where (y, x) is end a
+        const int by[4] = {y, y - 1, y - 1, y}, bx[4] = {x - 1, x, x - 1, x - 1};   // anchors where (y, x) is end b
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sc = 0.25f * l_smooth / (sums[2 + k] + 1e-6f);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int yy = side ? by[k] : ay[k], xx = side ? bx[k] : ax[k];
+                int ya, xa, yb, xb;
+                if (yy < 0 || xx < 0 || !pair_ends(k, yy, xx, a.H, a.W, ya, xa, yb, xb)) continue;
+                const float w = pair_weight(a, ya, xa, yb, xb) * sc * (side ? -1.f : 1.f);
+                const size_t ia = (size_t)ya * a.W + xa, ib = (size_t)yb * a.W + xb;
+                const float e0 = a.norm[ia] - a.norm[ib], e1 = a.norm[P + ia] - a.norm[P + ib], e2 = a.norm[2 * P + ia] - a.norm[2 * P + ib];
+                g0 += w * ((e0 > 0.f) ? 1.f : ((e0 < 0.f) ? -1.f : 0.f));
+                g1 += w * ((e1 > 0.f) ? 1.f : ((e1 < 0.f) ? -1.f : 0.f));
+                g2 += w * ((e2 > 0.f) ? 1.f : ((e2 < 0.f) ? -1.f : 0.f));
+            }
+        }
+    }
+    if (d_norm) { d_norm[i] = g0; d_norm[P + i] = g1; d_norm[2 * P + i] = g2; }
+    if (d_depth && l_depth != 0.f) {
+        const float e = a.depth[i] - a.gt_depth[i];
+        d_depth[i] = (l_depth / (float)P) * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
+    }
+}
+
 }  // namespace
+
+int launch_geom_losses(const float* norm, const float* gt_norm, const float* gt_image, const float* mask, const float* depth,
+                       const float* gt_depth, int H, int W, float lambda_norm, float lambda_smooth, float gamma,
+                       float lambda_depth, float* sums, float* d_norm, float* d_depth, hipStream_t s) {
+    GeomArgs a;
+    a.H = H; a.W = W; a.norm = norm; a.gt_norm = gt_norm; a.gt_image = gt_image; a.mask = mask; a.depth = depth;
+    a.gt_depth = gt_depth; a.inv_gamma = 1.f / gamma;
+    (void)hipMemsetAsync(sums, 0, 12 * sizeof(float), s);
+    const int P = H * W, blocks = (P + 255) / 256;
+    hipLaunchKernelGGL(k_geom_sums, dim3(blocks), dim3(256), 0, s, a, lambda_norm != 0.f, lambda_smooth != 0.f,
+                       lambda_depth != 0.f, sums);
+    hipLaunchKernelGGL(k_geom_grad, dim3(blocks), dim3(256), 0, s, a, lambda_norm, lambda_smooth, lambda_depth,
+                       (const float*)sums, d_norm, d_depth);
+    return 0;
+}
 
 // returns 0; sums[0..2] = sum|I-Igt|, sum SSIM, sum|A-Agt| (device); dL/dI and dL/dA are for d(loss) = 1
 int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float* alpha, const float* gt_alpha, int H,

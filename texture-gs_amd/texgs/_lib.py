@@ -53,7 +53,7 @@ class Grads(C.Structure):
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
-           "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops"]
+           "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
 
@@ -90,6 +90,9 @@ def load():
     lib.texgs_rgb_alpha_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                          C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_rgb_alpha_loss.restype = C.c_int
+    lib.texgs_geom_losses.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_geom_losses.restype = C.c_int
     lib.texgs_selftest_waveops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_selftest_waveops.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]

@@ -56,3 +56,57 @@ def rgb_alpha_loss(image, gt_image, alpha=None, gt_alpha=None, lambda_dssim=0.2,
     """(1-l)*l1_loss(image, gt) + l*(1 - ssim_loss(image, gt)) [+ la*l1_loss(alpha, gt_alpha)] with the reference's
     definitions (losses/pixelwise_loss.py, losses/ssim_loss.py:16-54); differentiable w.r.t. image and alpha."""
     return _RgbAlphaLoss.apply(image, gt_image, alpha, gt_alpha, float(lambda_dssim), float(lambda_alpha))
+
+
+class _GeomLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, norm, gt_norm, gt_image, mask, depth, gt_depth, lambda_norm, lambda_smooth, gamma, lambda_depth):
+        lib = _lib.load()
+        ref = norm if norm is not None else depth
+        dev = ref.device
+        if dev.type != "cuda":
+            raise RuntimeError("texgs.losses runs on an AMD GPU; there is no CPU fallback")
+        H, W = ref.shape[-2:]
+        c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        n, gn, gi, m, d, gd = c(norm), c(gt_norm), c(gt_image), c(mask), c(depth), c(gt_depth)
+        use_n = n is not None and (lambda_norm != 0.0 or lambda_smooth != 0.0)
+        use_d = d is not None and lambda_depth != 0.0
+        sums = torch.empty(12, dtype=torch.float32, device=dev)
+        d_n = torch.empty_like(n) if use_n else None
+        d_d = torch.empty_like(d) if use_d else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.texgs_geom_losses(p(n), p(gn), p(gi), p(m), p(d), p(gd), H, W, float(lambda_norm), float(lambda_smooth),
+                                             float(gamma), float(lambda_depth) if use_d else 0.0, p(sums), p(d_n), p(d_d),
+                                             torch.cuda.current_stream(dev).cuda_stream), "texgs_geom_losses")
+        loss = sums.new_zeros(())
+        stats = {}
+        if lambda_norm != 0.0:
+            stats["Lnorm"] = sums[1] / (sums[0] + 1e-6)
+            loss = loss + lambda_norm * stats["Lnorm"]
+        if lambda_smooth != 0.0:
+            stats["Lnorm_smooth"] = (sums[6:10] / (sums[2:6] + 1e-6)).sum() / 4
+            loss = loss + lambda_smooth * stats["Lnorm_smooth"]
+        if use_d:
+            stats["Ldepth"] = sums[10] / (H * W)
+            loss = loss + lambda_depth * stats["Ldepth"]
+        ctx.save_for_backward(d_n if use_n else torch.empty(0, device=dev), d_d if use_d else torch.empty(0, device=dev))
+        ctx.use = (use_n, use_d)
+        ctx.stats = stats
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_n, d_d = ctx.saved_tensors
+        use_n, use_d = ctx.use
+        return (g * d_n if use_n else None), None, None, None, (g * d_d if use_d else None), None, None, None, None, None
+
+
+def geom_losses(norm=None, gt_norm=None, gt_image=None, mask=None, depth=None, gt_depth=None, lambda_norm=0.0,
+                lambda_smooth=0.0, gamma=0.1, lambda_depth=0.0):
+    """lambda_norm * norm_loss(norm, gt_norm, mask) + lambda_smooth * smooth_loss(gt_image, norm, mask, gamma)
+    + lambda_depth * l1_loss(depth, gt_depth) with the reference's definitions (losses/norm_reg_loss.py:66-71,
+    losses/smooth_loss.py:4-27, losses/pixelwise_loss.py), as the terms of models/texture_gaussian3d.py:347-368 use them;
+    differentiable w.r.t. norm and depth -- the gradients go straight into the rasterizer's backward."""
+    return _GeomLosses.apply(norm, gt_norm, gt_image, mask, depth, gt_depth, float(lambda_norm), float(lambda_smooth),
+                             float(gamma), float(lambda_depth))
