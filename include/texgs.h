@@ -208,6 +208,23 @@ int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_i
                       const float* gt_depth, int32_t H, int32_t W, float lambda_norm, float lambda_smooth, float gamma,
                       float lambda_depth, float* sums, float* dL_dnorm, float* dL_ddepth, void* stream);
 
+/* Fused UV-Taylor producer: the operator inputs `uvs` and `gradient_uvs` straight from the Gaussian centres, replacing
+ * UVNet.forward (models/modules/uv_net.py:19-36) + torch.autograd.functional.jacobian (models/texture_gaussian3d.py:216-227).
+ * Weights are nn.Linear tensors (row-major [out, in]) of the shipped architecture (hidden width 128): pre_mlp = W1, W2;
+ * mlp = W3, W4, W5; biases may be NULL (tiny-cuda-nn networks have none); emb f32[128] is geo_emb.weight[0]; xyz_offset /
+ * xyz_scale f32[3] or NULL.  uvs f32[N,3] (unit), grad_uvs f32[N,9] with [3*i+j] = d uv_i / d x_j.  fp32 MFMA. */
+typedef struct TexGSUVNet {
+    const float *W1, *b1;      /* [128,3], [128]   */
+    const float *W2, *b2;      /* [128,128], [128] */
+    const float *emb;          /* [128]            */
+    const float *W3, *b3, *W4, *b4;
+    const float *W5, *b5;      /* [3,128], [3]     */
+    const float *xyz_offset, *xyz_scale;
+    int32_t hidden;            /* must be 128      */
+} TexGSUVNet;
+size_t texgs_uv_taylor_temp_bytes(void);
+int texgs_uv_taylor(const TexGSUVNet* net, const float* xyz, int32_t N, float* uvs, float* grad_uvs, void* temp, void* stream);
+
 /* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
  * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,
  * nine blocks of 64 differences against the __shfl_xor formulation -- all exactly 0 on gfx950. */

@@ -13,6 +13,10 @@ no source) travel to the GPU box, the reference does not.
   geom_losses.npz  losses/norm_reg_loss.py norm_loss, losses/smooth_loss.py smooth_loss and losses/pixelwise_loss.py l1_loss
                combined as models/texture_gaussian3d.py:347-368 combines them (lambda_norm 0.1, lambda_norm_smooth 0.5 of
                configs/texture_gaussian3d.yaml, plus a depth term), values AND autograd gradients w.r.t. norm / depth
+  uvnet.npz    models/modules/uv_net.py UVNet with models/modules/utils.py build_nn_network (the `use_tcnn: False` path; utils.py
+               imports tinycudann at top level, so the class / function definitions are taken from the two sources with `ast`
+               and RUN): weights, embedding, 64 points, uvs, and the Jacobian exactly as
+               models/texture_gaussian3d.py:216-227 computes it (autograd.functional.jacobian of the column sums)
   texture_io.npz  models/texture_gaussian3d.py rgb2sh0 / sh02rgb / cube_map / change_texture(modes -1..3): the module
                itself cannot be imported here (cv2, tinycudann, nvdiffrast), so the four function definitions are taken
                from its source with `ast` at generation time and RUN (nothing of them is stored); input = a 12-px-per-face
@@ -144,6 +148,39 @@ def geom_losses():
     np.savez_compressed(os.path.join(HERE, "geom_losses.npz"), **out)
 
 
+def uvnet():
+    import ast
+    from torch import nn
+    import torch.nn.functional as F
+
+    class Cfg(dict):                       # addict.Dict stand-in: attribute access, missing keys falsy
+        def __getattr__(self, k):
+            v = self.get(k)
+            return Cfg(v) if isinstance(v, dict) else v
+    ns = {"torch": torch, "nn": nn, "F": F, "np": np}
+    tree = ast.parse(open(os.path.join(REF, "models", "modules", "utils.py")).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("build_nn_network",)]
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "<utils>", "exec"), ns)
+    ns["build_mlp"] = lambda cfg, i, o: ns["build_nn_network"](cfg, i, o)      # the not-use_tcnn branch of build_mlp
+    tree = ast.parse(open(os.path.join(REF, "models", "modules", "uv_net.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "UVNet"]
+    exec(compile(ast.Module(body=cls, type_ignores=[]), "<uv_net>", "exec"), ns)
+    torch.manual_seed(3)
+    cfg = Cfg(emb_dim=128, pre_mlp_cfg=dict(use_tcnn=False, n_hidden_layers=1, n_neurons=128),
+              mlp_cfg=dict(use_tcnn=False, n_hidden_layers=2, n_neurons=128))
+    net = ns["UVNet"](cfg).double()          # float32-initialised weights, evaluated in float64 (exactly representable)
+    emb = (torch.randn(128) * 0.3).double()
+    g = torch.Generator().manual_seed(4)
+    xyz = torch.randn(64, 3, generator=g)
+    xyz = (xyz / xyz.norm(dim=1, keepdim=True) * (1 + 0.05 * torch.randn(64, 1, generator=g))).double()
+    uv = net(xyz, emb)
+    jac = torch.autograd.functional.jacobian(lambda inp: net(inp, emb).float().contiguous().sum(dim=0).double(), xyz)
+    J = jac.permute(1, 0, 2).reshape(-1, 9)
+    out = {k.replace(".", "__"): v.detach().numpy().astype(np.float32) for k, v in net.state_dict().items()}
+    out.update(emb=emb.numpy(), xyz=xyz.numpy(), uvs=uv.detach().numpy(), J=J.detach().numpy())
+    np.savez_compressed(os.path.join(HERE, "uvnet.npz"), **out)
+
+
 def texture_io():
     import ast
     from PIL import Image
@@ -198,7 +235,7 @@ def op_small():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "texture_io", "op_small"]
+    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "uvnet", "texture_io", "op_small"]
     for name in which:
         globals()[name]()
     print("golden fixtures written to", HERE)

@@ -24,6 +24,7 @@ UNITS = {
     "render.hip": ["-munsafe-fp-atomics", "-ffp-contract=fast"],
     "loss.hip": [],
     "selftest.hip": [],
+    "uvnet.hip": [],
     "abi.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "texgs.h")]

@@ -263,6 +263,17 @@ int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_i
     return e == hipSuccess ? 0 : fail("geom_losses", e);
 }
 
+size_t texgs_uv_taylor_temp_bytes(void) { return uv_taylor_temp_bytes(); }
+
+int texgs_uv_taylor(const TexGSUVNet* net, const float* xyz, int32_t N, float* uvs, float* grad_uvs, void* temp, void* stream) {
+    if (!net || !xyz || !uvs || !grad_uvs || !temp) return fail_msg("NULL argument");
+    if (net->hidden != 128) return fail_msg("texgs_uv_taylor supports the shipped UVNet shape only (hidden width 128)");
+    if (!net->W1 || !net->W2 || !net->W3 || !net->W4 || !net->W5 || !net->emb) return fail_msg("weight pointer is NULL");
+    if (N < 0) return fail_msg("N < 0");
+    if (int r = launch_uv_taylor(net, xyz, N, uvs, grad_uvs, temp, (hipStream_t)stream)) return fail("uv_taylor", (hipError_t)r);
+    return 0;
+}
+
 int texgs_selftest_waveops(const float* seed128, float* out576, void* stream) {
     if (!seed128 || !out576) return fail_msg("NULL argument");
     launch_selftest_waveops(seed128, out576, (hipStream_t)stream);
