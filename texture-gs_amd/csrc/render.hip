@@ -15,11 +15,12 @@
 // dL_dtexture once.  No MFMA: there is no dense contraction on this path.
 #include "common.h"
 #include "wave_ops.h"
+#include <stdlib.h>
 
 namespace {
 
 #ifndef TG_WAVES_PER_WG
-#define TG_WAVES_PER_WG 4          // 4: one workgroup per tile; 1: one workgroup per 8x8 block (finer-grained dispatch)
+#define TG_WAVES_PER_WG 1          // 1: one workgroup per 8x8 block (finest dispatch; K7 keeps 11 waves/CU by LDS); 4: one per tile
 #endif
 #define TG_WG_THREADS (64 * TG_WAVES_PER_WG)
 
@@ -190,15 +191,26 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         }
     };
 
+    // Records are double-buffered in registers: while chunk c is blended, chunk c+1's records (and chunk c+2's indices) are
+    // already in flight.  The longest tile lists ARE the kernel's critical path (the 16 longest tiles alone take 60 % of the
+    // whole launch), and half of a chunk's time on that path was the exposed index -> record load latency.
+    const float4 rz = make_float4(0.f, 0.f, 0.f, 0.f), rcullz = make_float4(-1.f, 1.f, 0.f, 0.f);
+    float4 n0 = rz, n1 = rz, n2 = rz, n3 = rz, n4 = rz, n5 = rz, n6 = rcullz;
+    uint32_t id_next = 0u;
+    if (lane < min(64, todo)) {
+        const float4* __restrict__ r = a.rec + (size_t)a.point_list[range.x + lane] * (TEXGS_REC_FLOATS / 4);
+        n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
+    }
+    if (64 + lane < todo) id_next = a.point_list[range.x + 64 + lane];
     for (int base = 0; base < todo; base += 64) {
         if (__ballot(!done) == 0ull) break;
-        const int cnt = min(64, todo - base);
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
-        if (lane < cnt) {
-            const uint32_t id = a.point_list[range.x + base + lane];
-            const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6];
+        const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4, r5 = n5, r6 = n6;
+        n0 = rz; n1 = rz; n2 = rz; n3 = rz; n4 = rz; n5 = rz; n6 = rcullz;
+        if (base + 64 + lane < todo) {
+            const float4* __restrict__ r = a.rec + (size_t)id_next * (TEXGS_REC_FLOATS / 4);
+            n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
         }
+        if (base + 128 + lane < todo) id_next = a.point_list[range.x + base + 128 + lane];
         // dense-phase copy of the chunk (the previous chunk's items were all drained before this point)
         s_rec[lane] = make_float4(r0.x, r0.y, r1.z, r1.w); s_rec[64 + lane] = r2; s_rec[128 + lane] = r3; s_rec[192 + lane] = r4;
         __builtin_amdgcn_wave_barrier();
@@ -268,10 +280,11 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //   stage B  dense, 64 items per round: UV Taylor step, cubemap address, 4 dwordx3 tap loads, colour; stores per item
 //            q = colour . dL/dpixel (for the suffix recurrence) and dL/dcolour (3), dL/duv (3), 1/den, dL/dden; appends
 //            the item's texture-gradient record to its texture bin (see the file header).
-//   stage C  sequential, scalar suffix recurrence dL/dalpha = T (s - suffix) + bg term with s = q + geometry
-//            channels; the 28 per-Gaussian moment sums are formed by the owning pixel lane, reduced over the wave with
-//            ONE transposing butterfly (value k ends in one lane, DPP + permlane swaps only, wave_ops.h) and 28 lanes add
-//            28 dwords of the 128-byte accumulator row: one coalesced memory-side request.
+//   stage C1 sequential, per pixel: the scalar suffix recurrence dL/dalpha = T (s - suffix) + bg term with s = q + geometry
+//            channels; leaves w and dL/dpower in the item.
+//   stage C2 dense over TASKS (<= 16 consecutive items of one Gaussian, 4 tasks per round): the 28 per-Gaussian moment
+//            terms of every item, a 16-lane transposing butterfly (DPP only, wave_ops.h), and the 16 lanes add the
+//            Gaussian's 128-byte accumulator row as two 64-byte runs.
 #ifndef BQ_CAP
 #define BQ_CAP 128
 #endif
@@ -304,6 +317,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     __shared__ float4 s_items_all[TG_WAVES_PER_WG][BQ_CAP * 3];   // 3 float4 per item: {T, araw, q, key} {dc, du0} {du1, du2, inv, dden}
     __shared__ float s_dpix_all[TG_WAVES_PER_WG][64 * 3];
     __shared__ float4 s_recs_all[TG_WAVES_PER_WG][6 * 64];        // the chunk's records, plane-major [k][lane]
+    __shared__ float s_dgeo_all[TG_WAVES_PER_WG][64 * 4];         // dL/d(depth, normal) of the wave's pixels
+    __shared__ uint32_t s_ids_all[TG_WAVES_PER_WG][64];           // Gaussian index of the chunk's instances
+    __shared__ uint32_t s_task_all[TG_WAVES_PER_WG][BQ_CAP / 16 + 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int tile, wave;
     if (!wave_block(a, tile, wave)) return;
@@ -319,6 +335,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     float4* s_items = s_items_all[wv];
     float4* s_recs = s_recs_all[wv];
     float* s_dpix = s_dpix_all[wv];
+    float* s_dgeo = s_dgeo_all[wv];
+    uint32_t* s_ids = s_ids_all[wv];
+    uint32_t* s_task = s_task_all[wv];
 
     float Tfin = 1.f; int last = 0;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
@@ -331,6 +350,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
     s_dpix[lane * 3 + 0] = dpix[0]; s_dpix[lane * 3 + 1] = dpix[1]; s_dpix[lane * 3 + 2] = dpix[2];
+    *reinterpret_cast<float4*>(&s_dgeo[lane * 4]) = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
     if (tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale.
         // Positive floats order like their bit patterns; the plain read first keeps 10^4 waves off one hot word.
@@ -344,24 +364,37 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     float T = Tfin;
     float suffix = 0.f, last_alpha = 0.f, last_s = 0.f;
 
+    // Records double-buffered in registers, as in K6: chunk c-1's records and chunk c-2's indices are in flight while
+    // chunk c is replayed.
     const int nchunks = (wave_last + 63) >> 6;
+    const float4 rz = make_float4(0.f, 0.f, 0.f, 0.f), rcullz = make_float4(-1.f, 1.f, 0.f, 0.f);
+    float4 n0 = rz, n1 = rz, n2 = rz, n3 = rz, n4 = rz, n5 = rz, n6 = rcullz;
+    uint32_t id_cur = 0u, id_next = 0u;
+    if (nchunks > 0 && ((nchunks - 1) << 6) + lane < wave_last) {
+        id_cur = a.point_list[range.x + ((nchunks - 1) << 6) + lane];
+        const float4* __restrict__ r = a.rec + (size_t)id_cur * (TEXGS_REC_FLOATS / 4);
+        n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
+    }
+    if (nchunks > 1) id_next = a.point_list[range.x + ((nchunks - 2) << 6) + lane];
     for (int c = nchunks - 1; c >= 0; --c) {
         const int base = c << 6;
-        const int jtop = min(64, wave_last - base);           // instances [0, jtop) of this chunk matter
         // ---- lane l <- instance l of the chunk
-        uint32_t id = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2v = r0, r3v = r0, r4v = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
-        if (lane < jtop) {
-            id = a.point_list[range.x + base + lane];
-            const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5]; r6 = r[6];
+        const uint32_t id = id_cur;
+        const float4 r0 = n0, r1 = n1, r2v = n2, r3v = n3, r4v = n4, r5 = n5, r6 = n6;
+        n0 = rz; n1 = rz; n2 = rz; n3 = rz; n4 = rz; n5 = rz; n6 = rcullz;
+        id_cur = id_next;
+        if (c >= 1) {                                              // chunks below the top one are complete (64 instances)
+            const float4* __restrict__ r = a.rec + (size_t)id_next * (TEXGS_REC_FLOATS / 4);
+            n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
         }
+        if (c >= 2) id_next = a.point_list[range.x + ((c - 2) << 6) + lane];
         // stage A broadcasts from registers (v_readlane: no LDS latency in its dependent chain); stages B and C fetch the
         // per-Gaussian fields from this LDS copy (stage C: 6 broadcast ds_read_b128 instead of ~29 v_readlane whose SGPR
         // results collide with gfx9's one-SGPR-per-VALU constant-bus limit; stage B: per-lane gather)
         __builtin_amdgcn_wave_barrier();
         s_recs[0 * 64 + lane] = r0; s_recs[1 * 64 + lane] = r1; s_recs[2 * 64 + lane] = r2v;
         s_recs[3 * 64 + lane] = r3v; s_recs[4 * 64 + lane] = r4v; s_recs[5 * 64 + lane] = r5;
+        s_ids[lane] = id;
         __builtin_amdgcn_wave_barrier();
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
         const unsigned long long cull_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
@@ -394,12 +427,15 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    s_items[(n_items + rank) * 3] = make_float4(T, araw, 0.f, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
+                    s_items[(n_items + rank) * 3] = make_float4(T, 0.f, araw, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
                 }
                 n_items += nb;
             }
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage B
+            // Order inside a round: addresses -> tap loads issued -> bin grouping + cursor atomic issued -> colour /
+            // gradient math (the loads and the returning atomic are in flight underneath it) -> record stores.  K7 is
+            // latency-bound (44 % of wave-cycles in s_waitcnt with VALU to spare), so nothing waits right after its issue.
             for (int r = 0; r < n_items; r += 64) {
                 const int e = r + lane;
                 const bool have = e < n_items;
@@ -409,27 +445,45 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const int pl = (int)(key >> 8) & 63, jj = (int)(key & 63u);
                 const float4 q0 = s_recs[0 * 64 + jj], q1 = s_recs[1 * 64 + jj], r2 = s_recs[2 * 64 + jj],
                              r3 = s_recs[3 * 64 + jj], r4 = s_recs[4 * 64 + jj];
-                bool want = false;                               // this lane has a texture-gradient record to append
-                uint32_t bin = 0u, cell = 0u;
-                float rfx = 0.f, rfy = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
-                CubeTap ct;
-                ct.o00 = ct.o01 = ct.o10 = ct.o11 = 0;
-                float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+                // ---- (1) UV Taylor step, cubemap address, tap loads
+                const float dpx = (float)(wave_px + (pl & 7)) - q0.x, dpy = (float)(wave_py + (pl >> 3)) - q0.y;
+                const float den = 1.0f + q1.z * dpx + q1.w * dpy;
+                const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+                const float nu0 = r2.x * dpx + r2.y * dpy, nu1 = r2.z * dpx + r2.w * dpy, nu2 = r3.x * dpx + r3.y * dpy;
+                const CubeTap ct = cube_address(r3.z + nu0 * inv, r3.w + nu1 * inv, r4.x + nu2 * inv, a.R);
+                Texel3 t00 = {0.f, 0.f, 0.f}, t01 = t00, t10 = t00, t11 = t00;
                 if (have) {
-                    const float alpha = fminf(TG_ALPHA_MAX, it.y);
-                    const float w = alpha * it.x;
-                    const float ipx = (float)(wave_px + (pl & 7)), ipy = (float)(wave_py + (pl >> 3));
-                    const float dpx = ipx - q0.x, dpy = ipy - q0.y;
-                    const float den = 1.0f + q1.z * dpx + q1.w * dpy;
-                    const bool good = den >= TG_DEN_MIN;
-                    const float inv = good ? __builtin_amdgcn_rcpf(den) : 0.0f;
-                    const float nu0 = r2.x * dpx + r2.y * dpy, nu1 = r2.z * dpx + r2.w * dpy, nu2 = r3.x * dpx + r3.y * dpy;
-                    const float u0 = r3.z + nu0 * inv, u1 = r3.w + nu1 * inv, u2 = r4.x + nu2 * inv;
-                    ct = cube_address(u0, u1, u2, a.R);
-                    w00 = (1.f - ct.fx) * (1.f - ct.fy); w01 = ct.fx * (1.f - ct.fy);
-                    w10 = (1.f - ct.fx) * ct.fy;         w11 = ct.fx * ct.fy;
-                    const Texel3 t00 = load_texel(tex, ct.o00), t01 = load_texel(tex, ct.o01);
-                    const Texel3 t10 = load_texel(tex, ct.o10), t11 = load_texel(tex, ct.o11);
+                    t00 = load_texel(tex, ct.o00); t01 = load_texel(tex, ct.o01);
+                    t10 = load_texel(tex, ct.o10); t11 = load_texel(tex, ct.o11);
+                }
+                // ---- (2) slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group
+                // the lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
+                const bool binned = have && tb.rec != nullptr && ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1;   // not clamped at a face border
+                const uint32_t bin = (uint32_t)((ct.face * tb.nb + (ct.y0 >> 5)) * tb.nb + (ct.x0 >> 5));
+                bool leader = false;
+                int my_leader = lane, my_rank = 0, my_n = 0;
+                {
+                    unsigned long long pend = __ballot(binned);
+                    while (pend != 0ull) {
+                        const int l0 = __ffsll((long long)pend) - 1;
+                        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
+                        const unsigned long long m = __ballot(binned && bin == b0);
+                        if ((m >> lane) & 1ull) {
+                            my_leader = l0;
+                            my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (lane == l0) { leader = true; my_n = __popcll(m); }
+                        }
+                        pend &= ~m;
+                    }
+                }
+                uint32_t slot0 = 0u;
+                if (leader) slot0 = atomicAdd(tb.cursor + bin, (uint32_t)my_n);
+                // ---- (3) colour, dL/dcolour, dL/duv
+                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+                const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+                if (have) {
+                    const float w = fminf(TG_ALPHA_MAX, it.z) * it.x;
                     const float d0 = s_dpix[pl * 3 + 0], d1 = s_dpix[pl * 3 + 1], d2 = s_dpix[pl * 3 + 2];
                     const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + r4.y + 0.5f;
                     const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + r4.z + 0.5f;
@@ -450,102 +504,113 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     if (ct.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
                     else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
                     else                   { du2 = dum; du0 = dua; du1 = dub; }
-                    const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;   // inv = 0 when !good
-                    s_items[e * 3].z = qv;
+                    const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;   // inv = 0 when den < DEN_MIN
+                    s_items[e * 3].y = qv;
                     s_items[e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
                     s_items[e * 3 + 2] = make_float4(du1, du2, inv, dden);
-                    // ---- texture gradient of this pair: bilinear footprint anchored at (face, y0, x0)
-                    want = (x0 != 0.f) || (x1 != 0.f) || (x2 != 0.f);
-                    if (want && (tb.rec == nullptr || ct.x1 != ct.x0 + 1 || ct.y1 != ct.y0 + 1)) {   // clamped at a face border
-                        scatter_direct(dtex, ct, w00, w01, w10, w11, x0, x1, x2);
-                        want = false;
-                    }
-                    bin = (uint32_t)((ct.face * tb.nb + (ct.y0 >> 5)) * tb.nb + (ct.x0 >> 5));
-                    cell = (uint32_t)(((ct.y0 & 31) << 8) | (ct.x0 & 31));
-                    rfx = ct.fx; rfy = ct.fy;
                 }
-                // one returning atomic per distinct bin of the round: group the lanes by bin (ballots only), then every
-                // group leader bumps its bin's cursor in ONE instruction and the members pick their slot from it
-                unsigned long long pend = __ballot(want);
-                if (pend != 0ull) {
-                    bool leader = false;
-                    int my_leader = lane, my_rank = 0, my_n = 0;
-                    while (pend != 0ull) {
-                        const int l0 = __ffsll((long long)pend) - 1;
-                        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
-                        const unsigned long long m = __ballot(want && bin == b0);
-                        if ((m >> lane) & 1ull) {
-                            my_leader = l0;
-                            my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (lane == l0) { leader = true; my_n = __popcll(m); }
-                        }
-                        pend &= ~m;
-                    }
-                    uint32_t slot0 = 0u;
-                    if (leader) slot0 = atomicAdd(tb.cursor + bin, (uint32_t)my_n);
-                    slot0 = (uint32_t)__builtin_amdgcn_ds_bpermute(my_leader << 2, (int)slot0);
-                    if (want) {
-                        const uint32_t slot = slot0 + (uint32_t)my_rank;
-                        if (slot < tb.cap) {
-                            float* __restrict__ rp = tb.rec + (size_t)bin * tb.cap * 6 + slot;
-                            rp[0] = __uint_as_float(cell); rp[tb.cap] = rfx; rp[2 * (size_t)tb.cap] = rfy;
-                            rp[3 * (size_t)tb.cap] = x0; rp[4 * (size_t)tb.cap] = x1; rp[5 * (size_t)tb.cap] = x2;
-                        } else {
-                            scatter_direct(dtex, ct, w00, w01, w10, w11, x0, x1, x2);       // bin full: still correct, just slow
-                        }
-                    }
+                // ---- (4) texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is
+                // clamped at a face border / the bin is full (still correct, just slow)
+                slot0 = (uint32_t)__builtin_amdgcn_ds_bpermute(my_leader << 2, (int)slot0);
+                const uint32_t slot = slot0 + (uint32_t)my_rank;
+                if (binned && slot < tb.cap) {
+                    float* __restrict__ rp = tb.rec + (size_t)bin * tb.cap * 6 + slot;
+                    rp[0] = __uint_as_float((uint32_t)(((ct.y0 & 31) << 8) | (ct.x0 & 31)));
+                    rp[tb.cap] = ct.fx; rp[2 * (size_t)tb.cap] = ct.fy;
+                    rp[3 * (size_t)tb.cap] = x0; rp[4 * (size_t)tb.cap] = x1; rp[5 * (size_t)tb.cap] = x2;
+                } else if (have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
+                    scatter_direct(dtex, ct, w00, w01, w10, w11, x0, x1, x2);
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // ================================================================ stage C
+            // ================================================================ stage C1: per-pixel recurrence (sequential in j)
+            // dL/dalpha = T (s - suffix) - bg term, s = colour . dL/dpixel + geometry channels; leaves w = alpha T and
+            // P = dL/dpower in the item.  ~30 instructions per Gaussian -- the 28-value reduction is NOT done here.
             int it0 = 0;
-            while (seg_mask != 0ull) {
-                const int jj = 63 - __clzll((long long)seg_mask);
-                seg_mask &= ~(1ull << jj);
-                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)touched_lo, jj);
-                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)touched_hi, jj);
-                const unsigned long long bal = ((unsigned long long)bhi << 32) | blo;
-                const bool ok = (bal >> lane) & 1ull;
-                float part[32];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) part[k] = 0.f;
-                const float4 c0 = s_recs[0 * 64 + jj], c5 = s_recs[5 * 64 + jj];             // uniform address: LDS broadcast
-                if (ok) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
-                    const float4 i0 = s_items[(it0 + rank) * 3], i1 = s_items[(it0 + rank) * 3 + 1], i2 = s_items[(it0 + rank) * 3 + 2];
-                    const float Ti = i0.x, araw = i0.y, qv = i0.z;
-                    const float alpha = fminf(TG_ALPHA_MAX, araw);
-                    const float dx = c0.x - pxf, dy = c0.y - pyf;               // xy - pixel
-                    const float w = alpha * Ti;
-                    const float s_i = qv + c5.x * dpix[3] + c5.y * dpix[4] + c5.z * dpix[5] + c5.w * dpix[6] + dpix[7];
-                    suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
-                    last_s = s_i; last_alpha = alpha;
-                    const float dL_dalpha_ = (s_i - suffix) * Ti - Tfin * __builtin_amdgcn_rcpf(1.0f - alpha) * bgdot;
-                    const float P = araw * dL_dalpha_;                // dL/dpower, straight through the 0.99 clamp (lineage)
-                    // The per-Gaussian sums are RAW MOMENTS about the splat centre (TexGSGrads.acc layout, texgs.h); K8, which
-                    // has conic / opacity / G / g in registers anyway, turns them into dL/d(xy, conic, opacity, G, g, ...).
-                    const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
-                    const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
-                    const float dpx = -dx, dpy = -dy;                           // pixel - xy
-                    const float Pdx = P * dx, Pdy = P * dy;
-                    part[M_P] = P; part[M_P + 1] = Pdx; part[M_P + 2] = Pdy;
-                    part[M_P + 3] = Pdx * dx; part[M_P + 4] = Pdx * dy; part[M_P + 5] = Pdy * dy;
-                    part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
-                    part[M_DN + 0] = dn0; part[M_DN + 1] = dn0 * dpx; part[M_DN + 2] = dn0 * dpy;
-                    part[M_DN + 3] = dn1; part[M_DN + 4] = dn1 * dpx; part[M_DN + 5] = dn1 * dpy;
-                    part[M_DN + 6] = dn2; part[M_DN + 7] = dn2 * dpx; part[M_DN + 8] = dn2 * dpy;
-                    part[M_PHI] = du0; part[M_PHI + 1] = du1; part[M_PHI + 2] = du2;
-                    part[M_VD] = i1.x; part[M_VD + 1] = i1.y; part[M_VD + 2] = i1.z;
-                    part[M_DEPTH] = w * dpix[3];
-                    part[M_N] = w * dpix[4]; part[M_N + 1] = w * dpix[5]; part[M_N + 2] = w * dpix[6];
+            uint32_t my_it0 = 0u;                                  // lane j: first item of Gaussian j in this segment
+            {
+                unsigned long long sm = seg_mask;
+                while (sm != 0ull) {
+                    const int jj = 63 - __clzll((long long)sm);
+                    sm &= ~(1ull << jj);
+                    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)touched_lo, jj);
+                    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)touched_hi, jj);
+                    const float4 c5 = s_recs[5 * 64 + jj];                                       // uniform address: LDS broadcast
+                    if (lane == jj) my_it0 = (uint32_t)it0;
+                    if ((((unsigned long long)bhi << 32 | blo) >> lane) & 1ull) {
+                        const int it = it0 + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                        const float4 i0 = s_items[it * 3];
+                        const float Ti = i0.x, qv = i0.y, araw = i0.z;
+                        const float alpha = fminf(TG_ALPHA_MAX, araw);
+                        const float s_i = qv + c5.x * dpix[3] + c5.y * dpix[4] + c5.z * dpix[5] + c5.w * dpix[6] + dpix[7];
+                        suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
+                        last_s = s_i; last_alpha = alpha;
+                        const float dL_dalpha_ = (s_i - suffix) * Ti - Tfin * __builtin_amdgcn_rcpf(1.0f - alpha) * bgdot;
+                        // {w, P}: P = dL/dpower straight through the 0.99 clamp (lineage)
+                        *reinterpret_cast<float2*>(&s_items[it * 3]) = make_float2(alpha * Ti, araw * dL_dalpha_);
+                    }
+                    it0 += __popcll(((unsigned long long)bhi << 32) | blo);
                 }
-                it0 += __popcll(bal);
-                // bank-first transposing butterfly (wave_ops.h): lane l < 32 ends with the wave total of slot transposed_index(l);
-                // the slots are the 32 dwords of one 128-byte accumulator row -> one coalesced memory-side request
-                const int slot = transposed_index(lane);
-                const float tot = reduce32_bankfirst(part, lane);
-                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)id, jj);
-                if (lane < 32 && slot < TEXGS_ACC_FLOATS && tot != 0.f) unsafeAtomicAdd(acc + (size_t)idj * TEXGS_ACC_FLOATS + slot, tot);
+            }
+            // ================================================================ stage C2: per-Gaussian moment sums, 16 lanes per task
+            // A task = up to 16 consecutive items of ONE Gaussian (its items are contiguous in the list).  Four tasks per
+            // round: every lane forms the 28 moment terms of its item, a transposing butterfly over the 16 lanes (bank-masked
+            // DPP for lane^4 / lane^8, quad_perm for lane^1 / lane^2) leaves two of the 32 row slots in each lane, and the
+            // 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.  (The wave-wide version of this --
+            // one 64-lane butterfly per (wave, Gaussian) with ~17 of 64 lanes live -- was 42 % of K7's instructions.)
+            {
+                const uint32_t nb_mine = ((seg_mask >> lane) & 1ull) ? (uint32_t)(__popc(touched_lo) + __popc(touched_hi)) : 0u;
+                const uint32_t ntask = (nb_mine + 15u) >> 4;
+                uint32_t incl = ntask;                            // inclusive prefix over the lanes (any fixed order works)
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+                const int total = __builtin_amdgcn_readlane((int)incl, 63);
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t t = 0; t < ntask; ++t)             // task word: j | first item << 6 | item count << 14
+                    s_task[incl - ntask + t] = (uint32_t)lane | ((my_it0 + 16u * t) << 6) | (min(16u, nb_mine - 16u * t) << 14);
+                __builtin_amdgcn_wave_barrier();
+                const int sub = lane & 15;
+                for (int q0 = 0; q0 < total; q0 += 4) {
+                    const int q = q0 + (lane >> 4);
+                    const uint32_t task = (q < total) ? s_task[q] : 0u;
+                    const int jt = (int)(task & 63u), item = (int)((task >> 6) & 255u) + sub;
+                    const bool have = (uint32_t)sub < (task >> 14);
+                    float part[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) part[k] = 0.f;
+                    const float2 gxy = *reinterpret_cast<const float2*>(&s_recs[jt]);
+                    if (have) {
+                        const float4 i0 = s_items[item * 3], i1 = s_items[item * 3 + 1], i2 = s_items[item * 3 + 2];
+                        const uint32_t key = __float_as_uint(i0.w);
+                        const int pl = (int)(key >> 8) & 63;
+                        const float w = i0.x, P = i0.y;
+                        const float dx = gxy.x - (float)(wave_px + (pl & 7)), dy = gxy.y - (float)(wave_py + (pl >> 3));   // xy - pixel
+                        // RAW MOMENTS about the splat centre (TexGSGrads.acc layout, texgs.h); K8, which has conic / opacity /
+                        // G / g in registers anyway, turns them into dL/d(xy, conic, opacity, G, g, ...)
+                        const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
+                        const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
+                        const float dpx = -dx, dpy = -dy;                       // pixel - xy
+                        const float Pdx = P * dx, Pdy = P * dy;
+                        const float d3 = s_dgeo[pl * 4 + 0], d4 = s_dgeo[pl * 4 + 1], d5 = s_dgeo[pl * 4 + 2], d6 = s_dgeo[pl * 4 + 3];
+                        part[M_P] = P; part[M_P + 1] = Pdx; part[M_P + 2] = Pdy;
+                        part[M_P + 3] = Pdx * dx; part[M_P + 4] = Pdx * dy; part[M_P + 5] = Pdy * dy;
+                        part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
+                        part[M_DN + 0] = dn0; part[M_DN + 1] = dn0 * dpx; part[M_DN + 2] = dn0 * dpy;
+                        part[M_DN + 3] = dn1; part[M_DN + 4] = dn1 * dpx; part[M_DN + 5] = dn1 * dpy;
+                        part[M_DN + 6] = dn2; part[M_DN + 7] = dn2 * dpx; part[M_DN + 8] = dn2 * dpy;
+                        part[M_PHI] = du0; part[M_PHI + 1] = du1; part[M_PHI + 2] = du2;
+                        part[M_VD] = i1.x; part[M_VD + 1] = i1.y; part[M_VD + 2] = i1.z;
+                        part[M_DEPTH] = w * d3;
+                        part[M_N] = w * d4; part[M_N + 1] = w * d5; part[M_N + 2] = w * d6;
+                    }
+                    float lo, hi;
+                    reduce32_rows16(part, lane, lo, hi);          // lane holds slots transposed_index(lane & 15) and 16 + that
+                    if (q < total) {
+                        float* row = acc + (size_t)s_ids[jt] * TEXGS_ACC_FLOATS + transposed_index(sub);
+                        if (lo != 0.f) unsafeAtomicAdd(row, lo);
+                        if (hi != 0.f) unsafeAtomicAdd(row + 16, hi);
+                    }
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -668,6 +733,9 @@ size_t tex_bin_count(int R) {
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
     PixArgs a = make_pix(c, f, in, g, b);
+#ifdef TEXGS_EXPERIMENTS     // critical-path experiments: blend only the K longest tile lists (results are wrong by construction)
+    if (getenv("TEXGS_MAXTILES_FWD")) a.num_tiles = min(a.num_tiles, atoi(getenv("TEXGS_MAXTILES_FWD")));
+#endif
     hipLaunchKernelGGL(k_render_fwd, dim3(blend_grid(a.num_tiles)), dim3(TG_WG_THREADS), 0, s, a, img->out_color, img->out_depth,
                        img->out_norm, img->out_alpha, img->final_T, img->n_contrib);
 }
@@ -675,6 +743,9 @@ void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     PixArgs a = make_pix(c, f, in, g, b);
+#ifdef TEXGS_EXPERIMENTS
+    if (getenv("TEXGS_MAXTILES_BWD")) a.num_tiles = min(a.num_tiles, atoi(getenv("TEXGS_MAXTILES_BWD")));
+#endif
     hipLaunchKernelGGL(k_render_bwd, dim3(blend_grid(a.num_tiles)), dim3(TG_WG_THREADS), 0, s, a, make_bins(c, gr), img->final_T,
                        img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture);
 }

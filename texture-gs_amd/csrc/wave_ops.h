@@ -144,3 +144,28 @@ __device__ __forceinline__ float reduce32_bankfirst(float (&v)[32], int lane) {
     const float r = keep + (b4 ? __int_as_float(sw[0]) : __int_as_float(sw[1]));
     return sum_xor32(r);
 }
+
+// 16-lane version: sums v[0..31] over each DPP row (16 lanes) separately.  On return lane l holds, for its row, the total of
+// slot transposed_index(l & 15) in `lo` and of slot 16 + transposed_index(l & 15) in `hi` (the four steps of
+// reduce32_bankfirst before its cross-row exchanges: lane^4, lane^8 bank-masked, lane^1, lane^2 quad_perm).
+__device__ __forceinline__ void reduce32_rows16(float (&v)[32], int lane, float& lo, float& hi) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float a[16], b[8], c[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = pair_xor4(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = pair_xor8(a[2 * i], a[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b0 ? b[2 * i + 1] : b[2 * i], send = b0 ? b[2 * i] : b[2 * i + 1];
+        c[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+    }
+    {
+        const float keep = b1 ? c[1] : c[0], send = b1 ? c[0] : c[1];
+        lo = keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    }
+    {
+        const float keep = b1 ? c[3] : c[2], send = b1 ? c[2] : c[3];
+        hi = keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    }
+}
