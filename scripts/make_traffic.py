@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(root, "pmc*", "*counter_collection.csv")):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             n = r["Kernel_Name"]
             for k, short in (("k_render_fwd", "render_fwd"), ("k_render_bwd", "render_bwd"), ("k_preprocess_fwd", "preprocess_fwd"),
-                             ("k_preprocess_bwd", "preprocess_bwd"), ("k_texgrad_gather", "texgrad_gather"), ("k_duplicate", "duplicate"),
+                             ("k_preprocess_bwd", "preprocess_bwd"), ("k_texgrad_reduce", "texgrad_reduce"), ("k_duplicate", "duplicate"),
                              ("k_ranges", "ranges")):
                 if k in n:
                     vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -75,6 +75,31 @@ __device__ __forceinline__ float gauss_power(float ah, float bh, float ch, float
 }
 __device__ __forceinline__ float gauss_alpha_raw(float op, float power) { return op * __expf(power); }
 
+// Per-wave cull, lane-parallel (lane = one instance of the chunk): can the instance reach alpha >= 1/255 at ANY point of the
+// wave's 8x8 pixel block?  power(d) = ah dx^2 + bh dx dy + ch dy^2 is concave with its maximum 0 at the splat centre, so its
+// maximum over the block's rectangle is 0 if the centre is inside, else it sits on one of the four edges, where it is a 1-D
+// concave parabola maximised at the clamped stationary point.  Exact for the continuous rectangle, hence conservative for
+// the pixel centres; `thr` already carries a margin far above fp32 rounding.  (The bounding-disc test alone let through
+// twice as many instances as ever produced an item: edge-on splats are needles, not discs.)
+__device__ __forceinline__ bool block_reachable(float gx, float gy, float ah, float bh, float ch, float thr, float rcull,
+                                                float x0, float y0) {
+    const float x1 = x0 + 7.0f, y1 = y0 + 7.0f;
+    if (!(rcull >= 0.f && (gx + rcull >= x0) && (gx - rcull <= x1) && (gy + rcull >= y0) && (gy - rcull <= y1))) return false;
+    const float dx0 = gx - x1, dx1 = gx - x0, dy0 = gy - y1, dy1 = gy - y0;     // d = centre - pixel ranges over [dx0,dx1] x [dy0,dy1]
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;     // centre inside the block
+    const float ihc = -0.5f * __builtin_amdgcn_rcpf(ch), iha = -0.5f * __builtin_amdgcn_rcpf(ah);
+    auto edge_x = [&](float dx) {       // dx fixed, dy free in [dy0, dy1]
+        const float dy = fminf(dy1, fmaxf(dy0, bh * dx * ihc));
+        return ah * dx * dx + bh * dx * dy + ch * dy * dy;
+    };
+    auto edge_y = [&](float dy) {
+        const float dx = fminf(dx1, fmaxf(dx0, bh * dy * iha));
+        return ah * dx * dx + bh * dx * dy + ch * dy * dy;
+    };
+    const float best = fmaxf(fmaxf(edge_x(dx0), edge_x(dx1)), fmaxf(edge_y(dy0), edge_y(dy1)));
+    return best >= thr - 1e-3f * fabsf(thr) - 1e-4f;
+}
+
 struct PixArgs {
     int W, H, tiles_x, num_tiles, R;
     const uint2* ranges;
@@ -215,8 +240,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         s_rec[lane] = make_float4(r0.x, r0.y, r1.z, r1.w); s_rec[64 + lane] = r2; s_rec[128 + lane] = r3; s_rec[192 + lane] = r4;
         __builtin_amdgcn_wave_barrier();
         // per-wave cull, lane-parallel: can instance `lane` reach alpha >= 1/255 anywhere in this wave's 8x8 block?
-        unsigned long long todo_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
-                                                (r0.y + r6.x >= (float)wave_py) && (r0.y - r6.x <= (float)(wave_py + 7)));
+        unsigned long long todo_mask = __ballot(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
         while (todo_mask != 0ull) {
             const int j = __ffsll((long long)todo_mask) - 1;
             todo_mask &= todo_mask - 1ull;
@@ -397,8 +421,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         s_ids[lane] = id;
         __builtin_amdgcn_wave_barrier();
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
-        const unsigned long long cull_mask = __ballot((r0.x + r6.x >= (float)wave_px) && (r0.x - r6.x <= (float)(wave_px + 7)) &&
-                                                      (r0.y + r6.x >= (float)wave_py) && (r0.y - r6.x <= (float)(wave_py + 7)));
+        const unsigned long long cull_mask = __ballot(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
         uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
         unsigned long long amask = cull_mask;                 // instances still to be tested (stage A), high to low
         while (amask != 0ull) {
