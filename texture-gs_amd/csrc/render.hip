@@ -116,6 +116,7 @@ struct PixArgs {
 __device__ __forceinline__ bool wave_block(const PixArgs& a, int& tile, int& wave) {
 #if TG_WAVES_PER_WG == 4
     if ((int)blockIdx.x >= a.num_tiles) return false;
+    const int rank = (int)blockIdx.x;
     tile = (int)a.tile_order[blockIdx.x];
     wave = (int)(threadIdx.x >> 6);
 #else
@@ -125,6 +126,7 @@ __device__ __forceinline__ bool wave_block(const PixArgs& a, int& tile, int& wav
     if (rank >= a.num_tiles) return false;
     tile = (int)a.tile_order[rank];
 #endif
+    (void)rank;
     return true;
 }
 inline int blend_grid(int num_tiles) {
@@ -185,57 +187,62 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     uint32_t last = 0;
     int qhead = 0, qtail = 0;                                  // wave-uniform
 
+    // The dense phase is software-pipelined by one batch: drain(n) first FINISHES the previous batch (its 4 taps were
+    // loaded a whole batch interval ago: colour, Q32.32 accumulate), then STARTS the new one (queue pop, record fields, UV
+    // Taylor step, cubemap address, tap loads issued) and returns without waiting for them.
+    int pn = 0;                                    // lanes of the batch in flight (wave-uniform)
+    int p_pl = 0;
+    float p_w = 0.f, p_fx = 0.f, p_fy = 0.f, p_vd0 = 0.f, p_vd1 = 0.f, p_vd2 = 0.f;
+    Texel3 p00 = {0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+    auto finish = [&]() {
+        if (lane < pn) {
+            const float w00 = (1.f - p_fx) * (1.f - p_fy), w01 = p_fx * (1.f - p_fy);
+            const float w10 = (1.f - p_fx) * p_fy,         w11 = p_fx * p_fy;
+            const float t0 = w00 * p00.x + w01 * p01.x + w10 * p10.x + w11 * p11.x;
+            const float t1 = w00 * p00.y + w01 * p01.y + w10 * p10.y + w11 * p11.y;
+            const float t2 = w00 * p00.z + w01 * p01.z + w10 * p10.z + w11 * p11.z;
+            // w * colour (>= 0) goes to the owning pixel's accumulator as Q32.32 fixed point with an INTEGER LDS atomic:
+            // ds_add_f32 retires ~3 cycles per LANE on gfx950 (193 cycles per wave instruction, scripts/ubench/lds_atomics.hip),
+            // ds_add_u64 6 cycles per instruction.  2^-32 resolution (45 items: < 1e-8), exact and order-independent below 2^31.
+            unsigned long long* cp = s_c + p_pl * 3;
+            atomicAdd(cp + 0, (unsigned long long)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t0 + p_vd0 + 0.5f), 2.0e9f) * 4294967296.0f));
+            atomicAdd(cp + 1, (unsigned long long)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t1 + p_vd1 + 0.5f), 2.0e9f) * 4294967296.0f));
+            atomicAdd(cp + 2, (unsigned long long)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t2 + p_vd2 + 0.5f), 2.0e9f) * 4294967296.0f));
+        }
+        pn = 0;
+    };
     auto drain = [&](int n_) {
+        finish();
         uint2 e_ = make_uint2(0u, 0u);
         if (lane < n_) e_ = s_q[(qhead + lane) & (FQ_CAP - 1)];
         const int pl_ = (int)(e_.y >> 8) & 63, jj_ = (int)(e_.y & 63u);
         const float4 p0 = s_rec[jj_], p1 = s_rec[64 + jj_], p2 = s_rec[128 + jj_], p3 = s_rec[192 + jj_];
+        const float dpx = (float)(wave_px + (pl_ & 7)) - p0.x, dpy = (float)(wave_py + (pl_ >> 3)) - p0.y;
+        const float den = 1.0f + p0.z * dpx + p0.w * dpy;
+        const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+        const float u0 = p2.z + (p1.x * dpx + p1.y * dpy) * inv;
+        const float u1 = p2.w + (p1.z * dpx + p1.w * dpy) * inv;
+        const float u2 = p3.x + (p2.x * dpx + p2.y * dpy) * inv;
+        const CubeTap ct = cube_address(u0, u1, u2, a.R);
         if (lane < n_) {
-            const float w_ = __uint_as_float(e_.x);
-            const float dpx = (float)(wave_px + (pl_ & 7)) - p0.x, dpy = (float)(wave_py + (pl_ >> 3)) - p0.y;
-            const float den = 1.0f + p0.z * dpx + p0.w * dpy;
-            const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-            const float u0 = p2.z + (p1.x * dpx + p1.y * dpy) * inv;
-            const float u1 = p2.w + (p1.z * dpx + p1.w * dpy) * inv;
-            const float u2 = p3.x + (p2.x * dpx + p2.y * dpy) * inv;
-            const CubeTap ct = cube_address(u0, u1, u2, a.R);
-            const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
-            const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
-            const Texel3 q00 = load_texel(tex, ct.o00), q01 = load_texel(tex, ct.o01);
-            const Texel3 q10 = load_texel(tex, ct.o10), q11 = load_texel(tex, ct.o11);
-            const float t0 = w00 * q00.x + w01 * q01.x + w10 * q10.x + w11 * q11.x;
-            const float t1 = w00 * q00.y + w01 * q01.y + w10 * q10.y + w11 * q11.y;
-            const float t2 = w00 * q00.z + w01 * q01.z + w10 * q10.z + w11 * q11.z;
-            // w * colour (>= 0) goes to the owning pixel's accumulator as Q32.32 fixed point with an INTEGER LDS atomic:
-            // ds_add_f32 retires ~3 cycles per LANE on gfx950 (193 cycles per wave instruction, scripts/ubench/lds_atomics.hip),
-            // ds_add_u64 6 cycles per instruction.  2^-32 resolution (45 items: < 1e-8), exact and order-independent below 2^31.
-            unsigned long long* cp = s_c + pl_ * 3;
-            atomicAdd(cp + 0, (unsigned long long)(fminf(w_ * fmaxf(0.f, TG_SH_C0 * t0 + p3.y + 0.5f), 2.0e9f) * 4294967296.0f));
-            atomicAdd(cp + 1, (unsigned long long)(fminf(w_ * fmaxf(0.f, TG_SH_C0 * t1 + p3.z + 0.5f), 2.0e9f) * 4294967296.0f));
-            atomicAdd(cp + 2, (unsigned long long)(fminf(w_ * fmaxf(0.f, TG_SH_C0 * t2 + p3.w + 0.5f), 2.0e9f) * 4294967296.0f));
+            p00 = load_texel(tex, ct.o00); p01 = load_texel(tex, ct.o01);
+            p10 = load_texel(tex, ct.o10); p11 = load_texel(tex, ct.o11);
         }
+        p_w = __uint_as_float(e_.x); p_pl = pl_; p_fx = ct.fx; p_fy = ct.fy; p_vd0 = p3.y; p_vd1 = p3.z; p_vd2 = p3.w;
+        pn = n_;
     };
 
-    // Records are double-buffered in registers: while chunk c is blended, chunk c+1's records (and chunk c+2's indices) are
-    // already in flight.  The longest tile lists ARE the kernel's critical path (the 16 longest tiles alone take 60 % of the
-    // whole launch), and half of a chunk's time on that path was the exposed index -> record load latency.
-    const float4 rz = make_float4(0.f, 0.f, 0.f, 0.f), rcullz = make_float4(-1.f, 1.f, 0.f, 0.f);
-    float4 n0 = rz, n1 = rz, n2 = rz, n3 = rz, n4 = rz, n5 = rz, n6 = rcullz;
-    uint32_t id_next = 0u;
-    if (lane < min(64, todo)) {
-        const float4* __restrict__ r = a.rec + (size_t)a.point_list[range.x + lane] * (TEXGS_REC_FLOATS / 4);
-        n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
-    }
-    if (64 + lane < todo) id_next = a.point_list[range.x + 64 + lane];
+    // (Double-buffering the records in registers -- chunk c+1 in flight while chunk c is blended -- was measured: no gain,
+    // +28 VGPRs.  The kernel is bound by VALU issue at its occupancy, not by the index -> record load latency.)
     for (int base = 0; base < todo; base += 64) {
         if (__ballot(!done) == 0ull) break;
-        const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4, r5 = n5, r6 = n6;
-        n0 = rz; n1 = rz; n2 = rz; n3 = rz; n4 = rz; n5 = rz; n6 = rcullz;
-        if (base + 64 + lane < todo) {
-            const float4* __restrict__ r = a.rec + (size_t)id_next * (TEXGS_REC_FLOATS / 4);
-            n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
+        const int cnt = min(64, todo - base);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
+        if (lane < cnt) {
+            const uint32_t id = a.point_list[range.x + base + lane];
+            const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
+            r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6];
         }
-        if (base + 128 + lane < todo) id_next = a.point_list[range.x + base + 128 + lane];
         // dense-phase copy of the chunk (the previous chunk's items were all drained before this point)
         s_rec[lane] = make_float4(r0.x, r0.y, r1.z, r1.w); s_rec[64 + lane] = r2; s_rec[128 + lane] = r3; s_rec[192 + lane] = r4;
         __builtin_amdgcn_wave_barrier();
@@ -282,6 +289,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         }
         __builtin_amdgcn_wave_barrier();
     }
+    finish();
     __builtin_amdgcn_wave_barrier();
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
@@ -388,30 +396,18 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     float T = Tfin;
     float suffix = 0.f, last_alpha = 0.f, last_s = 0.f;
 
-    // Records double-buffered in registers, as in K6: chunk c-1's records and chunk c-2's indices are in flight while
-    // chunk c is replayed.
     const int nchunks = (wave_last + 63) >> 6;
-    const float4 rz = make_float4(0.f, 0.f, 0.f, 0.f), rcullz = make_float4(-1.f, 1.f, 0.f, 0.f);
-    float4 n0 = rz, n1 = rz, n2 = rz, n3 = rz, n4 = rz, n5 = rz, n6 = rcullz;
-    uint32_t id_cur = 0u, id_next = 0u;
-    if (nchunks > 0 && ((nchunks - 1) << 6) + lane < wave_last) {
-        id_cur = a.point_list[range.x + ((nchunks - 1) << 6) + lane];
-        const float4* __restrict__ r = a.rec + (size_t)id_cur * (TEXGS_REC_FLOATS / 4);
-        n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
-    }
-    if (nchunks > 1) id_next = a.point_list[range.x + ((nchunks - 2) << 6) + lane];
     for (int c = nchunks - 1; c >= 0; --c) {
         const int base = c << 6;
+        const int jtop = min(64, wave_last - base);           // instances [0, jtop) of this chunk matter
         // ---- lane l <- instance l of the chunk
-        const uint32_t id = id_cur;
-        const float4 r0 = n0, r1 = n1, r2v = n2, r3v = n3, r4v = n4, r5 = n5, r6 = n6;
-        n0 = rz; n1 = rz; n2 = rz; n3 = rz; n4 = rz; n5 = rz; n6 = rcullz;
-        id_cur = id_next;
-        if (c >= 1) {                                              // chunks below the top one are complete (64 instances)
-            const float4* __restrict__ r = a.rec + (size_t)id_next * (TEXGS_REC_FLOATS / 4);
-            n0 = r[0]; n1 = r[1]; n2 = r[2]; n3 = r[3]; n4 = r[4]; n5 = r[5]; n6 = r[6];
+        uint32_t id = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2v = r0, r3v = r0, r4v = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
+        if (lane < jtop) {
+            id = a.point_list[range.x + base + lane];
+            const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
+            r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5]; r6 = r[6];
         }
-        if (c >= 2) id_next = a.point_list[range.x + ((c - 2) << 6) + lane];
         // stage A broadcasts from registers (v_readlane: no LDS latency in its dependent chain); stages B and C fetch the
         // per-Gaussian fields from this LDS copy (stage C: 6 broadcast ds_read_b128 instead of ~29 v_readlane whose SGPR
         // results collide with gfx9's one-SGPR-per-VALU constant-bus limit; stage B: per-lane gather)
@@ -456,94 +452,124 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             }
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage B
-            // Order inside a round: addresses -> tap loads issued -> bin grouping + cursor atomic issued -> colour /
-            // gradient math (the loads and the returning atomic are in flight underneath it) -> record stores.  K7 is
-            // latency-bound (44 % of wave-cycles in s_waitcnt with VALU to spare), so nothing waits right after its issue.
-            for (int r = 0; r < n_items; r += 64) {
-                const int e = r + lane;
-                const bool have = e < n_items;
+            // A segment holds at most two rounds of 64 items.  Both rounds' FRONT halves run first (addresses, the 4 tap
+            // loads, bin grouping, the cursor atomic: 8 loads + 2 returning atomics in flight), then both BACK halves
+            // (colour / gradient math, record stores).  K7's time falls as a + b / (waves per CU) with a large b: its waves
+            // mostly wait on memory, so the loads of round 1 are issued before anything waits on those of round 0.
+            struct Round {                                        // what the back half needs, as few registers as possible
+                bool have, binned;
+                int e, pl, my_leader, my_rank, axis;
+                uint32_t bin, cell, slot0;
+                int o00, dox, doy;                                // tap offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
+                float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
+                float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
+                Texel3 t00, t01, t10, t11;
+            };
+            auto front = [&](int r, Round& R) {
+                R.e = r + lane;
+                R.have = R.e < n_items;
                 float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
-                if (have) it = s_items[e * 3];
+                if (R.have) it = s_items[R.e * 3];
                 const uint32_t key = __float_as_uint(it.w);
-                const int pl = (int)(key >> 8) & 63, jj = (int)(key & 63u);
+                R.pl = (int)(key >> 8) & 63;
+                const int jj = (int)(key & 63u);
                 const float4 q0 = s_recs[0 * 64 + jj], q1 = s_recs[1 * 64 + jj], r2 = s_recs[2 * 64 + jj],
                              r3 = s_recs[3 * 64 + jj], r4 = s_recs[4 * 64 + jj];
-                // ---- (1) UV Taylor step, cubemap address, tap loads
-                const float dpx = (float)(wave_px + (pl & 7)) - q0.x, dpy = (float)(wave_py + (pl >> 3)) - q0.y;
+                R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
+                R.vd0 = r4.y; R.vd1 = r4.z; R.vd2 = r4.w;
+                // UV Taylor step, cubemap address, tap loads
+                const float dpx = (float)(wave_px + (R.pl & 7)) - q0.x, dpy = (float)(wave_py + (R.pl >> 3)) - q0.y;
                 const float den = 1.0f + q1.z * dpx + q1.w * dpy;
-                const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-                const float nu0 = r2.x * dpx + r2.y * dpy, nu1 = r2.z * dpx + r2.w * dpy, nu2 = r3.x * dpx + r3.y * dpy;
-                const CubeTap ct = cube_address(r3.z + nu0 * inv, r3.w + nu1 * inv, r4.x + nu2 * inv, a.R);
-                Texel3 t00 = {0.f, 0.f, 0.f}, t01 = t00, t10 = t00, t11 = t00;
-                if (have) {
-                    t00 = load_texel(tex, ct.o00); t01 = load_texel(tex, ct.o01);
-                    t10 = load_texel(tex, ct.o10); t11 = load_texel(tex, ct.o11);
+                R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+                R.nu0 = r2.x * dpx + r2.y * dpy; R.nu1 = r2.z * dpx + r2.w * dpy; R.nu2 = r3.x * dpx + r3.y * dpy;
+                const CubeTap ct = cube_address(r3.z + R.nu0 * R.inv, r3.w + R.nu1 * R.inv, r4.x + R.nu2 * R.inv, a.R);
+                const Texel3 tz = {0.f, 0.f, 0.f};
+                R.t00 = tz; R.t01 = tz; R.t10 = tz; R.t11 = tz;
+                if (R.have) {
+                    R.t00 = load_texel(tex, ct.o00); R.t01 = load_texel(tex, ct.o01);
+                    R.t10 = load_texel(tex, ct.o10); R.t11 = load_texel(tex, ct.o11);
                 }
-                // ---- (2) slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group
-                // the lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
-                const bool binned = have && tb.rec != nullptr && ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1;   // not clamped at a face border
-                const uint32_t bin = (uint32_t)((ct.face * tb.nb + (ct.y0 >> 5)) * tb.nb + (ct.x0 >> 5));
+                R.axis = ct.axis; R.fx = ct.fx; R.fy = ct.fy;
+                R.ka = ct.su * ct.h; R.kb = ct.sv * ct.h;
+                const float km = ct.h * ct.rma * ct.sm;
+                R.kc = ct.sc * km; R.kd = ct.tc * km;
+                R.o00 = ct.o00; R.dox = ct.o01 - ct.o00; R.doy = ct.o10 - ct.o00;
+                R.cell = (uint32_t)(((ct.y0 & 31) << 8) | (ct.x0 & 31));
+                // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
+                // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
+                R.binned = R.have && tb.rec != nullptr && ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1;   // not clamped at a face border
+                R.bin = (uint32_t)((ct.face * tb.nb + (ct.y0 >> 5)) * tb.nb + (ct.x0 >> 5));
                 bool leader = false;
-                int my_leader = lane, my_rank = 0, my_n = 0;
-                {
-                    unsigned long long pend = __ballot(binned);
-                    while (pend != 0ull) {
-                        const int l0 = __ffsll((long long)pend) - 1;
-                        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
-                        const unsigned long long m = __ballot(binned && bin == b0);
-                        if ((m >> lane) & 1ull) {
-                            my_leader = l0;
-                            my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (lane == l0) { leader = true; my_n = __popcll(m); }
-                        }
-                        pend &= ~m;
+                R.my_leader = lane; R.my_rank = 0;
+                int my_n = 0;
+                unsigned long long pend = __ballot(R.binned);
+                while (pend != 0ull) {
+                    const int l0 = __ffsll((long long)pend) - 1;
+                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
+                    const unsigned long long m = __ballot(R.binned && R.bin == b0);
+                    if ((m >> lane) & 1ull) {
+                        R.my_leader = l0;
+                        R.my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (lane == l0) { leader = true; my_n = __popcll(m); }
                     }
+                    pend &= ~m;
                 }
-                uint32_t slot0 = 0u;
-                if (leader) slot0 = atomicAdd(tb.cursor + bin, (uint32_t)my_n);
-                // ---- (3) colour, dL/dcolour, dL/duv
-                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
-                const float w10 = (1.f - ct.fx) * ct.fy,         w11 = ct.fx * ct.fy;
+                R.slot0 = 0u;
+                if (leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)my_n);
+            };
+            auto back = [&](Round& R) {
+                const Texel3 &t00 = R.t00, &t01 = R.t01, &t10 = R.t10, &t11 = R.t11;
+                const float w00 = (1.f - R.fx) * (1.f - R.fy), w01 = R.fx * (1.f - R.fy);
+                const float w10 = (1.f - R.fx) * R.fy,         w11 = R.fx * R.fy;
                 float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-                if (have) {
-                    const float w = fminf(TG_ALPHA_MAX, it.z) * it.x;
-                    const float d0 = s_dpix[pl * 3 + 0], d1 = s_dpix[pl * 3 + 1], d2 = s_dpix[pl * 3 + 2];
-                    const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + r4.y + 0.5f;
-                    const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + r4.z + 0.5f;
-                    const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + r4.w + 0.5f;
+                if (R.have) {
+                    const float w = R.w;
+                    const float d0 = s_dpix[R.pl * 3 + 0], d1 = s_dpix[R.pl * 3 + 1], d2 = s_dpix[R.pl * 3 + 2];
+                    const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + R.vd0 + 0.5f;
+                    const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + R.vd1 + 0.5f;
+                    const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + R.vd2 + 0.5f;
                     const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
                     // colour -> view-dependent term and texture
                     const float dc0 = (pre0 > 0.f) ? w * d0 : 0.f, dc1 = (pre1 > 0.f) ? w * d1 : 0.f, dc2 = (pre2 > 0.f) ? w * d2 : 0.f;
                     x0 = TG_SH_C0 * dc0; x1 = TG_SH_C0 * dc1; x2 = TG_SH_C0 * dc2;
-                    const float dLdcol = x0 * ((1.f - ct.fy) * (t01.x - t00.x) + ct.fy * (t11.x - t10.x))
-                                       + x1 * ((1.f - ct.fy) * (t01.y - t00.y) + ct.fy * (t11.y - t10.y))
-                                       + x2 * ((1.f - ct.fy) * (t01.z - t00.z) + ct.fy * (t11.z - t10.z));
-                    const float dLdrow = x0 * ((1.f - ct.fx) * (t10.x - t00.x) + ct.fx * (t11.x - t01.x))
-                                       + x1 * ((1.f - ct.fx) * (t10.y - t00.y) + ct.fx * (t11.y - t01.y))
-                                       + x2 * ((1.f - ct.fx) * (t10.z - t00.z) + ct.fx * (t11.z - t01.z));
-                    const float dua = dLdcol * ct.su * ct.h, dub = dLdrow * ct.sv * ct.h;
-                    const float dum = -(dLdcol * ct.sc + dLdrow * ct.tc) * ct.h * ct.rma * ct.sm;
+                    const float dLdcol = x0 * ((1.f - R.fy) * (t01.x - t00.x) + R.fy * (t11.x - t10.x))
+                                       + x1 * ((1.f - R.fy) * (t01.y - t00.y) + R.fy * (t11.y - t10.y))
+                                       + x2 * ((1.f - R.fy) * (t01.z - t00.z) + R.fy * (t11.z - t10.z));
+                    const float dLdrow = x0 * ((1.f - R.fx) * (t10.x - t00.x) + R.fx * (t11.x - t01.x))
+                                       + x1 * ((1.f - R.fx) * (t10.y - t00.y) + R.fx * (t11.y - t01.y))
+                                       + x2 * ((1.f - R.fx) * (t10.z - t00.z) + R.fx * (t11.z - t01.z));
+                    const float dua = dLdcol * R.ka, dub = dLdrow * R.kb;
+                    const float dum = -(dLdcol * R.kc + dLdrow * R.kd);
                     float du0, du1, du2;
-                    if (ct.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
-                    else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
-                    else                   { du2 = dum; du0 = dua; du1 = dub; }
-                    const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;   // inv = 0 when den < DEN_MIN
-                    s_items[e * 3].y = qv;
-                    s_items[e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
-                    s_items[e * 3 + 2] = make_float4(du1, du2, inv, dden);
+                    if (R.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
+                    else if (R.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
+                    else                  { du2 = dum; du0 = dua; du1 = dub; }
+                    const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
+                    s_items[R.e * 3].y = qv;
+                    s_items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
+                    s_items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
                 }
-                // ---- (4) texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is
-                // clamped at a face border / the bin is full (still correct, just slow)
-                slot0 = (uint32_t)__builtin_amdgcn_ds_bpermute(my_leader << 2, (int)slot0);
-                const uint32_t slot = slot0 + (uint32_t)my_rank;
-                if (binned && slot < tb.cap) {
-                    float* __restrict__ rp = tb.rec + (size_t)bin * tb.cap * 6 + slot;
-                    rp[0] = __uint_as_float((uint32_t)(((ct.y0 & 31) << 8) | (ct.x0 & 31)));
-                    rp[tb.cap] = ct.fx; rp[2 * (size_t)tb.cap] = ct.fy;
+                // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
+                // a face border / the bin is full (still correct, just slow)
+                const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0) + (uint32_t)R.my_rank;
+                if (R.binned && slot < tb.cap) {
+                    float* __restrict__ rp = tb.rec + (size_t)R.bin * tb.cap * 6 + slot;
+                    rp[0] = __uint_as_float(R.cell);
+                    rp[tb.cap] = R.fx; rp[2 * (size_t)tb.cap] = R.fy;
                     rp[3 * (size_t)tb.cap] = x0; rp[4 * (size_t)tb.cap] = x1; rp[5 * (size_t)tb.cap] = x2;
-                } else if (have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
+                } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
+                    CubeTap ct;
+                    ct.o00 = R.o00; ct.o01 = R.o00 + R.dox; ct.o10 = R.o00 + R.doy; ct.o11 = R.o00 + R.dox + R.doy;
                     scatter_direct(dtex, ct, w00, w01, w10, w11, x0, x1, x2);
                 }
+            };
+            static_assert(BQ_CAP <= 128, "stage B is unrolled for at most two rounds per segment");
+            if (n_items > 0) {
+                Round R0, R1;
+                front(0, R0);
+                if (n_items > 64) front(64, R1);
+                back(R0);
+                if (n_items > 64) back(R1);
             }
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage C1: per-pixel recurrence (sequential in j)
