@@ -138,6 +138,9 @@ inline int blend_grid(int num_tiles) {
 }
 
 #define RLF(V, J) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), (J)))
+// HIP's __ballot(int) materialises the predicate as 0/1 in a VGPR and compares it again (v_cndmask + v_cmp per ballot);
+// the builtin takes the lane mask the compares already produced.
+#define TG_BALLOT(P) __builtin_amdgcn_ballot_w64((bool)(P))
 
 // ------------------------------------------------------------------------------------------------ K6
 // Forward blend.  Per chunk of 64 instances:
@@ -182,6 +185,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     __builtin_amdgcn_wave_barrier();
 
     bool done = !inside;
+    unsigned long long done_mask = TG_BALLOT(!inside);        // the same, as a wave-level lane mask (scalar registers)
     float T = 1.0f;
     float Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, Al = 0.f;
     uint32_t last = 0;
@@ -235,7 +239,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     // (Double-buffering the records in registers -- chunk c+1 in flight while chunk c is blended -- was measured: no gain,
     // +28 VGPRs.  The kernel is bound by VALU issue at its occupancy, not by the index -> record load latency.)
     for (int base = 0; base < todo; base += 64) {
-        if (__ballot(!done) == 0ull) break;
+        if (~done_mask == 0ull) break;
         const int cnt = min(64, todo - base);
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
         if (lane < cnt) {
@@ -247,20 +251,26 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         s_rec[lane] = make_float4(r0.x, r0.y, r1.z, r1.w); s_rec[64 + lane] = r2; s_rec[128 + lane] = r3; s_rec[192 + lane] = r4;
         __builtin_amdgcn_wave_barrier();
         // per-wave cull, lane-parallel: can instance `lane` reach alpha >= 1/255 anywhere in this wave's 8x8 block?
-        unsigned long long todo_mask = __ballot(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
+        unsigned long long todo_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
         while (todo_mask != 0ull) {
             const int j = __ffsll((long long)todo_mask) - 1;
             todo_mask &= todo_mask - 1ull;
             const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
             const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
             const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-            if (__ballot((!done) && (power <= 0.0f) && (power >= thr)) == 0ull) continue;   // conservative prefilter
+            // wave-level decisions as PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask
+            // and the combination is scalar ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip
+            const unsigned long long m_neg = TG_BALLOT(power <= 0.0f) & ~done_mask;
+            if ((m_neg & TG_BALLOT(power >= thr)) == 0ull) continue;                          // conservative prefilter
             const float op = RLF(r1.y, j);
             const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
             bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
             const float Tn = T * (1.0f - alpha);
+            const unsigned long long m_ok = m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+            const unsigned long long m_kill = m_ok & TG_BALLOT(Tn < TG_T_EPS);
             if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
-            const unsigned long long bal = __ballot(ok);
+            done_mask |= m_kill;
+            const unsigned long long bal = m_ok & ~m_kill;
             if (bal != 0ull) {
                 const float dep = RLF(r5.x, j), n0 = RLF(r5.y, j), n1 = RLF(r5.z, j), n2 = RLF(r5.w, j);
                 if (ok) {
@@ -278,7 +288,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
                     drain(64);
                     qhead += 64;
                 }
-                if (__ballot(!done) == 0ull) break;
+                if (~done_mask == 0ull) break;
             }
         }
         // items reference this chunk's LDS copy: finish them before the next chunk is loaded
@@ -417,7 +427,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         s_ids[lane] = id;
         __builtin_amdgcn_wave_barrier();
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
-        const unsigned long long cull_mask = __ballot(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
+        const unsigned long long cull_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
         uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
         unsigned long long amask = cull_mask;                 // instances still to be tested (stage A), high to low
         while (amask != 0ull) {
@@ -430,12 +440,14 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
                 const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
                 const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-                if (__ballot(inside && (base + j < last) && (power <= 0.0f) && (power >= thr)) == 0ull) { amask &= ~jbit; continue; }
+                // products of single-compare ballots (see K6): `last` bounds which pixels still replay instance base + j
+                const unsigned long long m_neg = TG_BALLOT(power <= 0.0f) & TG_BALLOT(base + j < last);
+                if ((m_neg & TG_BALLOT(power >= thr)) == 0ull) { amask &= ~jbit; continue; }
                 const float op = RLF(r1.y, j);
                 const float araw = gauss_alpha_raw(op, power);
                 const float alpha = fminf(TG_ALPHA_MAX, araw);
-                const bool ok = inside && (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-                const unsigned long long bal = __ballot(ok);
+                const bool ok = (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                const unsigned long long bal = m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN);
                 const int nb = __popcll(bal);
                 if (nb == 0) { amask &= ~jbit; continue; }
                 if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
@@ -502,11 +514,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 bool leader = false;
                 R.my_leader = lane; R.my_rank = 0;
                 int my_n = 0;
-                unsigned long long pend = __ballot(R.binned);
+                unsigned long long pend = TG_BALLOT(R.binned);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
-                    const unsigned long long m = __ballot(R.binned && R.bin == b0);
+                    const unsigned long long m = TG_BALLOT(R.binned && R.bin == b0);
                     if ((m >> lane) & 1ull) {
                         R.my_leader = l0;
                         R.my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
