@@ -174,6 +174,15 @@ int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const T
 int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                    const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream);
 
+/* The two halves of texgs_backward, for callers that pipeline several views over HIP streams: the first (K7 + bin reduce)
+ * only touches grads->acc, the texture bins and dL_dtexture (atomics); the second (K8) is the one that writes -- or, with
+ * grads->accumulate, read-modify-writes -- the per-Gaussian outputs, so it alone has to be ordered between two views that
+ * share a gradient buffer (hipStreamWaitEvent between the two calls).  texgs_backward == render, then preprocess. */
+int texgs_backward_render(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                          const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream);
+int texgs_backward_preprocess(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom, TexGSGrads* grads,
+                              void* stream);
+
 /* Optional per-kernel HIP-event timing (used by bench.py for the live roofline figure).  While enabled,
  * every kernel launch of this library is bracketed by hipEventRecord on the launch stream.
  * texgs_profile_read synchronises the recorded events, adds elapsed ms / launch counts per kernel id into

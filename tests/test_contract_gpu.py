@@ -8,6 +8,7 @@ files do not reach.
          backward; second backward.
 * C4  -- 8 views split over two "virtual ranks" (each with its own bucket + grad_sink) sum to the single-bucket run; the
          same through a 1-rank RCCL group.
+* ViewPipeline -- the views of a step over 2-3 HIP streams (all three ordering modes) against the serial loop.
 * C5  -- 1M Gaussians / 2048^2 cubemap / 1600x1200 against the C oracle (integer stages bit-exact, fwd, bwd).
 * wave_ops.h self-test on hardware.
 """
@@ -171,6 +172,51 @@ def test_c4_semantics_two_virtual_ranks_equal_single_bucket(lib_built):
     parts = sum(accumulate(shard_views(8, r, 2)).flat.double() for r in range(2))
     rel = float((whole - parts).norm() / whole.norm())
     Hh.report("c4_semantics/2_virtual_ranks_vs_single", rel_l2=rel, max_abs=float((whole - parts).abs().max()),
+              grad_max=float(whole.abs().max()))
+    assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("depth,order", [(2, "backward"), (2, "accumulate"), (2, "none"), (3, "none"), (3, "accumulate")])
+def test_view_pipeline_streams_equal_serial(lib_built, depth, order):
+    """texgs.multiview.ViewPipeline: the views of a step pipelined over HIP streams accumulate the same bucket as the
+    serial loop (per-Gaussian sums: same K8 order in "backward"/"accumulate", a different association in "none"; the
+    texture gradient and K7's moment sums go through atomics either way)."""
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from texgs.multiview import GradBucket, ViewPipeline
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(20000, 256, seed=5, scale_mean=0.012)
+    cams = synth.fibonacci_cameras(7, 400, 304)
+    juv = scene.gradient_uvs.to(dev)
+    target, nhat = synth.make_targets(304, 400, seed=3)
+    target, nhat = target.to(dev), nhat.to(dev)
+    sts = [Hh.settings_for(c, 3, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings) for c in cams]
+
+    def accumulate(pipe_depth, pipe_order, steps=2):
+        names, leaves = _leaves(scene, dev)
+        m2 = torch.zeros(20000, 3, device=dev, requires_grad=True)
+        bucket = GradBucket(leaves + [m2])
+        pipe = ViewPipeline(dev, depth=pipe_depth)
+        images = []
+
+        def fwd(v):
+            out = _view(GaussianRasterizer, sts[v], leaves, m2, juv, sink=bucket)
+            return out, synth.synthetic_loss(out[0], out[3], out[2], target, nhat)
+
+        def bwd(obj):
+            obj[1].backward()
+        for _ in range(steps):                        # two steps: the replicas / scratch must come back clean
+            bucket.zero()
+            res = pipe.run(range(7), fwd, bwd, sink=bucket, order=pipe_order)
+            torch.cuda.synchronize()
+            images = [r[0][0].detach().clone() for r in res]
+        assert bucket.before_accumulate is None and bucket.active == 0
+        return bucket.flat.double().clone(), images
+    whole, img_s = accumulate(1, "backward")
+    got, img_p = accumulate(depth, order)
+    for a, b in zip(img_s, img_p):
+        assert torch.equal(a, b), "forward images differ between the serial and the pipelined run"
+    rel = float((whole - got).norm() / whole.norm())
+    Hh.report(f"view_pipeline/depth{depth}_{order}_vs_serial", rel_l2=rel, max_abs=float((whole - got).abs().max()),
               grad_max=float(whole.abs().max()))
     assert rel < 1e-5, rel
 

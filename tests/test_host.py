@@ -130,3 +130,37 @@ def test_grad_bucket_allreduce_two_ranks_equals_single_process():
         ref[off:off + p.numel()] = g.reshape(-1)
         off += p.numel()
     assert torch.allclose(res[0], ref, atol=1e-5) and torch.allclose(res[1], ref, atol=1e-5)
+
+
+def test_grad_bucket_replicas_and_serial_pipeline():
+    """GradBucket.select / fold (per-stream replicas of the gradient bucket) and ViewPipeline at depth 1 -- host logic only."""
+    from texgs.multiview import GradBucket, ViewPipeline
+    a = torch.zeros(5, 3, requires_grad=True)
+    b = torch.zeros(4, requires_grad=True)
+    bucket = GradBucket([a, b])
+    assert bucket.sink_for(a).data_ptr() == bucket.flat.data_ptr()
+    bucket.select(2)
+    assert len(bucket.replicas) == 2
+    sa, sb = bucket.sink_for(a), bucket.sink_for(b)
+    assert sa.data_ptr() == bucket.replicas[1].data_ptr() and sb.data_ptr() == bucket.replicas[1].data_ptr() + 4 * 15
+    sa += 1.0
+    sb += 2.0
+    bucket.select(0)
+    bucket.sink_for(a).add_(0.5)
+    bucket.fold()
+    assert bucket.active == 0
+    assert torch.equal(a.grad, torch.full((5, 3), 1.5)) and torch.equal(b.grad, torch.full((4,), 2.0))
+    assert all(float(r.abs().sum()) == 0.0 for r in bucket.replicas)
+    # a .grad that no longer aliases the bucket is never handed out, replica or not
+    a.grad = torch.zeros(5, 3)
+    bucket.select(1)
+    assert bucket.sink_for(a) is None
+    bucket.select(0)
+
+    order = []
+    pipe = ViewPipeline("cpu", depth=1)
+    res = pipe.run([3, 1, 2], lambda v: order.append(("f", v)) or v * 10, lambda o: order.append(("b", o)))
+    assert res == [30, 10, 20]
+    assert order == [("f", 3), ("b", 30), ("f", 1), ("b", 10), ("f", 2), ("b", 20)]
+    with pytest.raises(ValueError):
+        ViewPipeline("cpu", depth=0)

@@ -182,8 +182,8 @@ int texgs_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geo
     return texgs_bin_sort_render_forward(frame, in, geom, bin, img, stream);
 }
 
-int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
-                   const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
+int texgs_backward_render(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                          const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !bin || !img || !grads) return fail_msg("NULL argument");
     if (!grads->acc || !grads->dL_dtexture) return fail_msg("acc / dL_dtexture must be allocated (zero-filled)");
@@ -201,8 +201,24 @@ int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGe
             if (int r = check(frame, s, "texgrad_reduce")) return r;
         }
     }
+    return 0;
+}
+
+int texgs_backward_preprocess(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom, TexGSGrads* grads,
+                              void* stream) {
+    if (int r = validate_frame(frame)) return r;
+    if (!in || !geom || !grads) return fail_msg("NULL argument");
+    if (!grads->acc) return fail_msg("acc must be allocated");
+    hipStream_t s = (hipStream_t)stream;
+    const CamConst c = make_cam(frame);
     { ProfScope p(TEXGS_K_PREPROCESS_BWD, s); launch_preprocess_bwd(c, frame, in, geom, grads, s); }
     return check(frame, s, "preprocess_bwd");
+}
+
+int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                   const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
+    if (int r = texgs_backward_render(frame, in, geom, bin, img, grads, stream)) return r;
+    return texgs_backward_preprocess(frame, in, geom, grads, stream);
 }
 
 int texgs_profile_enable(int on) {

@@ -20,8 +20,8 @@
 namespace {
 
 constexpr int RS_THREADS = 256;         // 4 waves
-constexpr int RS_MAX_BLOCKS = 256;      // count-table rows per pass
-constexpr int RS_GROUP = 16;            // rows per group partial
+constexpr int RS_MAX_BLOCKS = 1024;     // count-table rows per pass
+constexpr int RS_GROUP = 32;            // rows per group partial
 
 struct RadixTables {                    // one per pass
     uint32_t* table;                    // [RS_MAX_BLOCKS][256] per-block digit counts (written, not accumulated)
@@ -113,38 +113,59 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
         for (int w = 0; w < 4; ++w) { const uint32_t c = s_wcnt[w][tid]; s_wcnt[w][tid] = run; run += c; }
     }
     __syncthreads();
-    // ---- stable ranking + scatter, one 64-element row at a time (rows in order, lanes in order)
+    // ---- stable ranking + scatter, one 64-element row at a time (rows in order, lanes in order); the keys (and values) of
+    // RB rows are loaded together first, so a wave has RB loads in flight instead of one exposed round trip per row
+    constexpr int RB = 8;
     uint32_t* cur = s_wcnt[wv];
-    for (uint32_t i0 = wlo; i0 < whi; i0 += 64u) {
-        const uint32_t i = i0 + lane;
-        const bool have = i < whi;
-        KEY k = 0;
-        if (have) k = keys_in[i];
-        const uint32_t d = have ? digit_of(k, shift, mask) : 0xFFFFFFFFu;
-        // peers = lanes of this row with my digit (one ballot per digit bit)
-        unsigned long long peers = __ballot(have);
-        for (int bt = 0; bt < bits; ++bt) {
-            const unsigned long long m = __ballot((d >> bt) & 1u);
-            peers &= ((d >> bt) & 1u) ? m : ~m;
+    for (uint32_t b0 = wlo; b0 < whi; b0 += 64u * RB) {
+        KEY kk[RB];
+        uint32_t vv[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const uint32_t i = b0 + 64u * rr + lane;
+            kk[rr] = (i < whi) ? keys_in[i] : (KEY)0;
+            vv[rr] = (MODE == 0 && vals_in != nullptr && i < whi) ? vals_in[i] : i;
         }
-        uint32_t pos = 0u;
-        if (have) {
-            const uint32_t below = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-            pos = cur[d] + below;
+        uint32_t dr[RB];
+        if (MODE == 2) {        // the final pass's two gathers by depth rank, also batched
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                const bool have = b0 + 64u * rr + lane < whi;
+                dr[rr] = have ? depth_rank[(uint32_t)kk[rr]] : 0u;
+                vv[rr] = have ? id_rank[(uint32_t)kk[rr]] : 0u;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (have && (peers >> lane) >> 1 == 0ull) cur[d] = pos + 1u;       // highest peer advances the cursor past the row
-        __builtin_amdgcn_wave_barrier();
-        if (have) {
-            if (MODE == 0) {
-                keys_out[pos] = k;
-                vals_out[pos] = vals_in ? vals_in[i] : i;
-            } else if (MODE == 1) {
-                keys_out[pos] = k;
-            } else {
-                const uint32_t rank = (uint32_t)k;
-                keys_out[pos] = (KEY)(((uint64_t)k & 0xFFFFFFFF00000000ull) | (uint64_t)depth_rank[rank]);
-                vals_out[pos] = id_rank[rank];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const uint32_t i = b0 + 64u * rr + lane;
+            if (b0 + 64u * rr >= whi) break;                      // wave-uniform
+            const bool have = i < whi;
+            const KEY k = kk[rr];
+            const uint32_t d = have ? digit_of(k, shift, mask) : 0xFFFFFFFFu;
+            // peers = lanes of this row with my digit (one ballot per digit bit)
+            unsigned long long peers = __ballot(have);
+            for (int bt = 0; bt < bits; ++bt) {
+                const unsigned long long m = __ballot((d >> bt) & 1u);
+                peers &= ((d >> bt) & 1u) ? m : ~m;
+            }
+            uint32_t pos = 0u;
+            if (have) {
+                const uint32_t below = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+                pos = cur[d] + below;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (have && (peers >> lane) >> 1 == 0ull) cur[d] = pos + 1u;       // highest peer advances the cursor past the row
+            __builtin_amdgcn_wave_barrier();
+            if (have) {
+                if (MODE == 0) {
+                    keys_out[pos] = k;
+                    vals_out[pos] = vv[rr];
+                } else if (MODE == 1) {
+                    keys_out[pos] = k;
+                } else {
+                    keys_out[pos] = (KEY)(((uint64_t)k & 0xFFFFFFFF00000000ull) | (uint64_t)dr[rr]);
+                    vals_out[pos] = vv[rr];
+                }
             }
         }
     }

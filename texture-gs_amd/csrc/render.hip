@@ -334,6 +334,15 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 #define BWD_WAVES_PER_SIMD 2
 #endif
 
+#ifdef K7_STATS        // diagnostics build (scripts/k7_stats.py): dynamic work counters of K7, summed over the launch
+__device__ unsigned long long g_k7_stats[16];
+#define K7_COUNT(i, n) (k7s[i] += (unsigned)(n))
+#else
+#define K7_COUNT(i, n) ((void)0)
+#endif
+#ifndef K7_ABL
+#define K7_ABL 0      // timing-only ablations (scripts/bench_variants.sh): 1 = no stage C1, 2 = no stage C2, 4 = no stage B
+#endif
 struct TexBinArgs {
     float*    rec;         // [nbins][6][cap]: cell | fx | fy | dL/dtexel-colour r, g, b   (plane-major inside a bin)
     uint32_t* cursor;      // [nbins] records appended so far (may exceed cap: the excess went to dL_dtexture directly)
@@ -405,6 +414,10 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 
     float T = Tfin;
     float suffix = 0.f, last_alpha = 0.f, last_s = 0.f;
+    uint32_t my_it0_sink = 0u;
+#ifdef K7_STATS
+    unsigned k7s[16] = {0};
+#endif
 
     const int nchunks = (wave_last + 63) >> 6;
     for (int c = nchunks - 1; c >= 0; --c) {
@@ -428,6 +441,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         __builtin_amdgcn_wave_barrier();
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
         const unsigned long long cull_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
+        K7_COUNT(0, 1); K7_COUNT(1, jtop); K7_COUNT(2, __popcll(cull_mask));      // chunks, instances, instances after the cull
         uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
         unsigned long long amask = cull_mask;                 // instances still to be tested (stage A), high to low
         while (amask != 0ull) {
@@ -437,6 +451,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             while (amask != 0ull) {
                 const int j = 63 - __clzll((long long)amask);
                 const unsigned long long jbit = 1ull << j;
+                K7_COUNT(3, 1);                                   // stage-A iterations
                 const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
                 const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
                 const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
@@ -453,6 +468,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
                 amask &= ~jbit;
                 seg_mask |= jbit;
+                K7_COUNT(4, 1); K7_COUNT(5, nb); K7_COUNT(6, (nb + 15) >> 4);      // instances with items, items, C2 tasks
                 if (lane == j) { touched_lo = (uint32_t)bal; touched_hi = (uint32_t)(bal >> 32); }
                 if (ok) {
                     T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
@@ -519,6 +535,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     const int l0 = __ffsll((long long)pend) - 1;
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
                     const unsigned long long m = TG_BALLOT(R.binned && R.bin == b0);
+                    K7_COUNT(9, 1);                               // bin-grouping iterations
                     if ((m >> lane) & 1ull) {
                         R.my_leader = l0;
                         R.my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -576,7 +593,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 }
             };
             static_assert(BQ_CAP <= 128, "stage B is unrolled for at most two rounds per segment");
-            if (n_items > 0) {
+            K7_COUNT(7, 1); K7_COUNT(8, (n_items + 63) >> 6);                       // segments, stage-B rounds
+            if (n_items > 0 && !(K7_ABL & 4)) {
                 Round R0, R1;
                 front(0, R0);
                 if (n_items > 64) front(64, R1);
@@ -589,7 +607,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             // P = dL/dpower in the item.  ~30 instructions per Gaussian -- the 28-value reduction is NOT done here.
             int it0 = 0;
             uint32_t my_it0 = 0u;                                  // lane j: first item of Gaussian j in this segment
-            {
+            if (K7_ABL != 0) my_it0_sink += (uint32_t)n_items + touched_lo;
+            if (!(K7_ABL & 1)) {
                 unsigned long long sm = seg_mask;
                 while (sm != 0ull) {
                     const int jj = 63 - __clzll((long long)sm);
@@ -619,7 +638,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             // DPP for lane^4 / lane^8, quad_perm for lane^1 / lane^2) leaves two of the 32 row slots in each lane, and the
             // 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.  (The wave-wide version of this --
             // one 64-lane butterfly per (wave, Gaussian) with ~17 of 64 lanes live -- was 42 % of K7's instructions.)
-            {
+            if (!(K7_ABL & 2)) {
                 const uint32_t nb_mine = ((seg_mask >> lane) & 1ull) ? (uint32_t)(__popc(touched_lo) + __popc(touched_hi)) : 0u;
                 const uint32_t ntask = (nb_mine + 15u) >> 4;
                 uint32_t incl = ntask;                            // inclusive prefix over the lanes (any fixed order works)
@@ -632,6 +651,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 __builtin_amdgcn_wave_barrier();
                 const int sub = lane & 15;
                 for (int q0 = 0; q0 < total; q0 += 4) {
+                    K7_COUNT(10, 1);                              // C2 rounds (4 tasks each)
                     const int q = q0 + (lane >> 4);
                     const uint32_t task = (q < total) ? s_task[q] : 0u;
                     const int jt = (int)(task & 63u), item = (int)((task >> 6) & 255u) + sub;
@@ -676,6 +696,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             __builtin_amdgcn_wave_barrier();
         }
     }
+#ifdef K7_STATS
+    K7_COUNT(11, 1);
+    if (lane == 0) for (int i = 0; i < 16; ++i) if (k7s[i]) atomicAdd(&g_k7_stats[i], (unsigned long long)k7s[i]);
+#endif
+    if (K7_ABL != 0 && s_items[lane * 3].x == 12345.678f) acc[0] = (float)my_it0_sink;    // ablation builds: keep the LDS traffic alive
 }
 
 // ------------------------------------------------------------------------------------------------ texture-gradient reduce
@@ -816,3 +841,11 @@ void launch_texgrad_reduce(const CamConst& c, TexGSGrads* gr, hipStream_t s) {
     if (!tb.rec) return;
     hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(256), 0, s, c.R, tb, gr->dL_dtexture);
 }
+
+#ifdef K7_STATS
+extern "C" int texgs_debug_k7_stats(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_k7_stats), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { unsigned long long z[16] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_k7_stats), z, sizeof(z)); }
+    return (int)e;
+}
+#endif

@@ -57,7 +57,8 @@ class UVNetStruct(C.Structure):
 
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-           "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
+           "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
+           "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
            "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
@@ -91,6 +92,8 @@ def load():
     lib.texgs_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), C.c_uint32, P(Image), P(C.c_uint32), C.c_void_p]
     lib.texgs_forward.restype = C.c_int
     lib.texgs_backward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), P(Grads), C.c_void_p]
+    lib.texgs_backward_render.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), P(Grads), C.c_void_p]
+    lib.texgs_backward_preprocess.argtypes = [P(Frame), P(Inputs), P(Geom), P(Grads), C.c_void_p]
     lib.texgs_mark_visible.argtypes = [P(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_rgb_alpha_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                          C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -110,7 +113,8 @@ def load():
     lib.texgs_profile_read.argtypes = [P(C.c_float), P(C.c_uint32)]
     lib.texgs_profile_read.restype = C.c_int
     for name in ("texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_bin_sort_render_forward",
-                 "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_rgb_alpha_loss", "texgs_mark_visible"):
+                 "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render",
+                 "texgs_backward_preprocess", "texgs_rgb_alpha_loss", "texgs_mark_visible"):
         getattr(lib, name).restype = C.c_int
     v = lib.texgs_abi_version()
     if v != ABI_VERSION:

@@ -42,6 +42,25 @@ class GradBucket:
             p.grad = self.flat[off:off + n].view_as(p)
             self.slices.append((off, n))
             off += n
+        # ViewPipeline state: replica buffers (one per extra stream) that kernels accumulate into instead of `flat`, the
+        # replica in use, and the hook the rasterizer's backward calls before its accumulating kernel (K8)
+        self.replicas = []
+        self.active = 0
+        self.before_accumulate = None
+
+    def select(self, k: int):
+        """Accumulate the following views into buffer k (0 = `flat`, the one .grad aliases; k > 0 = a private replica,
+        zero-filled when first made and after every fold()).  Lets views on different streams accumulate with no ordering
+        between them; fold() adds the replicas into `flat` before anything reads .grad."""
+        while len(self.replicas) < k:
+            self.replicas.append(torch.zeros_like(self.flat))
+        self.active = k
+
+    def fold(self):
+        self.active = 0
+        for r in self.replicas:
+            self.flat.add_(r)
+            r.zero_()
 
     def sink_for(self, tensor):
         """The bucket slice backing `tensor`'s gradient if `tensor` is one of the registered leaves AND its .grad still
@@ -59,7 +78,7 @@ class GradBucket:
                     p.grad = sl.view_as(p)
                 elif p.grad.data_ptr() != self.flat.data_ptr() + 4 * off or not p.grad.is_contiguous():
                     return None
-                return sl
+                return sl if self.active == 0 else self.replicas[self.active - 1][off:off + n]
         return None
 
     def zero(self):
@@ -74,3 +93,75 @@ class GradBucket:
         if average_over:
             self.flat.div_(float(average_over))
         return self.flat
+
+
+class ViewPipeline:
+    """The views of one multi-view step on `depth` HIP streams (default 2), round-robin.
+
+    Inside one view every kernel depends on the one before it, and the two big ones end in a long tail (the 16 longest
+    tiles are ~40 % of K7's duration, ~65 % of K6's, with most CUs idle), while K1..K5 are nine small launches that never
+    fill the chip.  Views are independent of each other, so view i+1's forward is issued on the other stream and fills the
+    holes of view i's backward.  Ordering that remains:
+
+    * backward(i+1) waits for backward(i): K8 adds into the shared gradient sink with plain read-modify-writes (the texture
+      gradient uses atomics and would not need it);
+    * a stream runs its own views in order, so per-stream scratch (moment accumulators, texture bins: keyed by stream in
+      texgs.rasterizer) is never shared by two views in flight;
+    * the caller's stream is joined before (parameters, zeroed sinks) and after (all-reduce, optimizer).
+
+    `forward_fn(view)` runs the forward and whatever loss is attached and returns what `backward_fn` needs;
+    `backward_fn(obj)` calls autograd (which runs each node on the stream its forward ran on)."""
+
+    def __init__(self, device, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)] if depth > 1 else []
+
+    def run(self, views, forward_fn, backward_fn=None, sink=None, order="accumulate"):
+        """order (what of view i+1 waits for view i when both add into `sink`):
+        "backward"   -- its whole backward (works with any gradient path, e.g. plain autograd accumulation);
+        "accumulate" -- only its accumulating kernel K8, through sink.before_accumulate (needs a GradBucket sink);
+        "none"       -- nothing: every stream accumulates into its own replica of the bucket, folded at the end."""
+        results = []
+        if not self.streams:                       # depth 1: the caller's stream, nothing to order
+            for v in views:
+                obj = forward_fn(v)
+                if backward_fn is not None:
+                    backward_fn(obj)
+                results.append(obj)
+            return results
+        if order not in ("backward", "accumulate", "none"):
+            raise ValueError(order)
+        if sink is None and order != "backward":
+            order = "backward"
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+        prev_bwd = None
+        try:
+            for i, v in enumerate(views):
+                k = i % len(self.streams)
+                s = self.streams[k]
+                with torch.cuda.stream(s):
+                    if order == "none":
+                        sink.select(k)
+                    obj = forward_fn(v)
+                    if backward_fn is not None:
+                        if order == "backward" and prev_bwd is not None:
+                            s.wait_event(prev_bwd)
+                        if order == "accumulate":
+                            sink.before_accumulate = (lambda ev=prev_bwd, s=s: s.wait_event(ev)) if prev_bwd is not None \
+                                else (lambda: None)
+                        backward_fn(obj)
+                        prev_bwd = torch.cuda.Event()
+                        prev_bwd.record(s)
+                results.append(obj)
+        finally:
+            if sink is not None:
+                sink.before_accumulate = None
+            for s in self.streams:
+                cur.wait_stream(s)
+            if sink is not None and order == "none":
+                sink.fold()
+        return results

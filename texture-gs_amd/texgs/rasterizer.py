@@ -229,8 +229,11 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     return (out_color, out_depth, out_norm, out_alpha, radii), s
 
 
-def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None):
+def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None, before_accumulate=None):
     """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture).
+
+    `before_accumulate` (optional callable): invoked between K7 + bin reduce and K8 -- the point where a multi-view
+    pipeline makes this stream wait for the previous view's K8 (texgs.multiview.ViewPipeline).
 
     `sinks` (optional): dict name -> existing float32 gradient buffer of the input's shape.  If EVERY per-Gaussian
     output has a sink the kernels ADD into them (fused multi-view accumulation, TexGSGrads.accumulate = 1); a texture
@@ -286,8 +289,15 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
                            _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff),
                            _ptr(bins.rec) if bins else None, _ptr(bins.cursor) if bins else None, bins.cap if bins else 0,
                            1 if fused else 0)
-        _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
-                                      C.byref(s.img), C.byref(grads), stream), "texgs_backward")
+        if before_accumulate is None:
+            _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
+                                          C.byref(s.img), C.byref(grads), stream), "texgs_backward")
+        else:
+            _lib.check(lib.texgs_backward_render(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
+                                                 C.byref(s.img), C.byref(grads), stream), "texgs_backward_render")
+            before_accumulate()
+            _lib.check(lib.texgs_backward_preprocess(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom),
+                                                     C.byref(grads), stream), "texgs_backward_preprocess")
     _ACC_SCRATCH[akey] = acc                 # only re-cached after a successful call (an exception drops it)
     if bins is not None:
         bins.after_call()
@@ -305,6 +315,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None,
                 grad_sink=None):
         ctx.sinks = None
+        ctx.grad_sink = grad_sink
         ctx.set_materialize_grads(False)     # outputs without an upstream gradient arrive as None, not as zero-filled tensors
         if grad_sink is not None:        # fused accumulation: inputs that ARE registered leaves get their .grad slice
             named = dict(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales,
@@ -337,7 +348,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise RuntimeError("an input of the rasterizer was modified in place between its forward and backward "
                                    "(the backward re-reads inputs through saved pointers); clone it before modifying")
         d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex = backward_raw(
-            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=ctx.sinks)
+            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=ctx.sinks,
+            before_accumulate=getattr(ctx.grad_sink, "before_accumulate", None) if ctx.sinks else None)
         d_coff = s.tensors.get("d_color_offset")
         ctx.state = None
         ctx.versions = None
