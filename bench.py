@@ -201,13 +201,16 @@ def main():
     kern_timed = _lib.profile_read()
     # the per-kernel table: two extra steps with every kernel group bracketed, views one after the other on one stream, so
     # that each duration is the kernel's own (in the pipelined region a kernel shares the GPU with other views' kernels)
+    _lib.profile_enable(True, only=[DOMINANT])
+    step(pipe_serial)
+    fence()
+    kern_solo_dom = _lib.profile_read()[DOMINANT]      # the dominant kernel alone on the GPU, only it bracketed
     _lib.profile_enable(True)
     for _ in range(2):
         step(pipe_serial)
     fence()
     kern = _lib.profile_read()
     _lib.profile_enable(False)
-    kern_solo_dom = kern[DOMINANT]
     kern[DOMINANT] = kern_timed[DOMINANT]
     step_ms = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]

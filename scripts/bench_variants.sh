@@ -8,6 +8,6 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l)
-        print(json.dumps({'lib': '$lib', 'views_per_s': d['value'], 'ms_per_view': d['ms_per_view'], 'kernel_avg_us': {k: round(v['avg_us'], 1) for k, v in d['kernels'].items()}}))
+        print(json.dumps({'lib': '$lib', 'views_per_s': d['value'], 'ms_per_view': d['ms_per_view'], 'dominant_solo_us': (d.get('roofline') or {}).get('solo_launch_us'), 'kernel_avg_us': {k: round(v['avg_us'], 1) for k, v in d['kernels'].items()}}))
 "
 done

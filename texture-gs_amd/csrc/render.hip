@@ -23,6 +23,9 @@ namespace {
 #define TG_WAVES_PER_WG 1          // 1: one workgroup per 8x8 block (finest dispatch; K7 keeps 11 waves/CU by LDS); 4: one per tile
 #endif
 #define TG_WG_THREADS (64 * TG_WAVES_PER_WG)
+#ifndef K6_A_SINGLE
+#define K6_A_SINGLE 1      // one exit per tested instance (alpha always evaluated); 0 = power-threshold prefilter, then the alpha test
+#endif
 
 struct __attribute__((packed, aligned(4))) Texel3 { float x, y, z; };   // one global_load_dwordx3 per tap
 __device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, int off) {
@@ -255,6 +258,14 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         while (todo_mask != 0ull) {
             const int j = __ffsll((long long)todo_mask) - 1;
             todo_mask &= todo_mask - 1ull;
+#if K6_A_SINGLE
+            const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
+            const float cc = RLF(r1.x, j), op = RLF(r1.y, j);
+            const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
+            const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
+            const unsigned long long m_neg = TG_BALLOT(power <= 0.0f) & ~done_mask;
+            if ((m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN)) == 0ull) continue;
+#else
             const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
             const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
             const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
@@ -264,6 +275,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             if ((m_neg & TG_BALLOT(power >= thr)) == 0ull) continue;                          // conservative prefilter
             const float op = RLF(r1.y, j);
             const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
+#endif
             bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
             const float Tn = T * (1.0f - alpha);
             const unsigned long long m_ok = m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN);
@@ -320,10 +332,10 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //   stage A  sequential, ~30 VALU / test: falloff, alpha, T /= (1-alpha); contributing (pixel, j) pairs are
 //            compacted (ballot + mbcnt) into an LDS item list {T, alpha_raw, q, key}; per-j ballots stay in VGPRs.
 //   stage B  dense, 64 items per round: UV Taylor step, cubemap address, 4 dwordx3 tap loads, colour; stores per item
-//            q = colour . dL/dpixel (for the suffix recurrence) and dL/dcolour (3), dL/duv (3), 1/den, dL/dden; appends
-//            the item's texture-gradient record to its texture bin (see the file header).
-//   stage C1 sequential, per pixel: the scalar suffix recurrence dL/dalpha = T (s - suffix) + bg term with s = q + geometry
-//            channels; leaves w and dL/dpower in the item.
+//            s = colour . dL/dcolour + geometry channels . their gradients (what stage C1 sums) and dL/dcolour (3),
+//            dL/duv (3), 1/den, dL/dden; appends the item's texture-gradient record to its texture bin (see the file header).
+//   stage C1 sequential, per pixel: dL/dalpha_i = T_i s_i - (sum of s_k alpha_k T_k behind i + bg term) / (1 - alpha_i), one
+//            running sum per pixel; leaves w and dL/dpower in the item.
 //   stage C2 dense over TASKS (<= 16 consecutive items of one Gaussian, 4 tasks per round): the 28 per-Gaussian moment
 //            terms of every item, a 16-lane transposing butterfly (DPP only, wave_ops.h), and the 16 lanes add the
 //            Gaussian's 128-byte accumulator row as two 64-byte runs.
@@ -339,6 +351,12 @@ __device__ unsigned long long g_k7_stats[16];
 #define K7_COUNT(i, n) (k7s[i] += (unsigned)(n))
 #else
 #define K7_COUNT(i, n) ((void)0)
+#endif
+#ifndef K7_A_SINGLE
+#define K7_A_SINGLE 1
+#endif
+#ifndef K6_A_SINGLE
+#define K6_A_SINGLE 0
 #endif
 #ifndef K7_ABL
 #define K7_ABL 0      // timing-only ablations (scripts/bench_variants.sh): 1 = no stage C1, 2 = no stage C2, 4 = no stage B
@@ -365,11 +383,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
              float* __restrict__ acc, float* __restrict__ dtex) {
-    __shared__ float4 s_items_all[TG_WAVES_PER_WG][BQ_CAP * 3];   // 3 float4 per item: {T, araw, q, key} {dc, du0} {du1, du2, inv, dden}
-    __shared__ float s_dpix_all[TG_WAVES_PER_WG][64 * 3];
+    // 3 float4 per item: {T -> w, s -> dL/dpower, alpha_raw, key} {dc, du0} {du1, du2, inv, dden}; + one all-zero item (stage C2's idle lanes)
+    __shared__ float4 s_items_all[TG_WAVES_PER_WG][BQ_CAP * 3 + 3];
+    __shared__ float4 s_dpix_all[TG_WAVES_PER_WG][64];            // dL/d(r, g, b, alpha) of the wave's pixels
     __shared__ float4 s_recs_all[TG_WAVES_PER_WG][6 * 64];        // the chunk's records, plane-major [k][lane]
     __shared__ float s_dgeo_all[TG_WAVES_PER_WG][64 * 4];         // dL/d(depth, normal) of the wave's pixels
-    __shared__ uint32_t s_ids_all[TG_WAVES_PER_WG][64];           // Gaussian index of the chunk's instances
     __shared__ uint32_t s_task_all[TG_WAVES_PER_WG][BQ_CAP / 16 + 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int tile, wave;
@@ -385,9 +403,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     const float* __restrict__ tex = a.texture;
     float4* s_items = s_items_all[wv];
     float4* s_recs = s_recs_all[wv];
-    float* s_dpix = s_dpix_all[wv];
+    float4* s_dpix = s_dpix_all[wv];
     float* s_dgeo = s_dgeo_all[wv];
-    uint32_t* s_ids = s_ids_all[wv];
     uint32_t* s_task = s_task_all[wv];
 
     float Tfin = 1.f; int last = 0;
@@ -400,7 +417,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         if (dL_dalpha) dpix[7] = dL_dalpha[pix];
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
-    s_dpix[lane * 3 + 0] = dpix[0]; s_dpix[lane * 3 + 1] = dpix[1]; s_dpix[lane * 3 + 2] = dpix[2];
+    if (lane < 3) s_items[BQ_CAP * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_dpix[lane] = make_float4(dpix[0], dpix[1], dpix[2], dpix[7]);
     *reinterpret_cast<float4*>(&s_dgeo[lane * 4]) = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
     if (tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale.
@@ -413,7 +431,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     __builtin_amdgcn_wave_barrier();
 
     float T = Tfin;
-    float suffix = 0.f, last_alpha = 0.f, last_s = 0.f;
+    float behind = Tfin * bgdot;      // sum of s_k alpha_k T_k over the contributors BEHIND the current one, + the background term
     uint32_t my_it0_sink = 0u;
 #ifdef K7_STATS
     unsigned k7s[16] = {0};
@@ -437,7 +455,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         __builtin_amdgcn_wave_barrier();
         s_recs[0 * 64 + lane] = r0; s_recs[1 * 64 + lane] = r1; s_recs[2 * 64 + lane] = r2v;
         s_recs[3 * 64 + lane] = r3v; s_recs[4 * 64 + lane] = r4v; s_recs[5 * 64 + lane] = r5;
-        s_ids[lane] = id;
         __builtin_amdgcn_wave_barrier();
         // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
         const unsigned long long cull_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
@@ -452,6 +469,19 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const int j = 63 - __clzll((long long)amask);
                 const unsigned long long jbit = 1ull << j;
                 K7_COUNT(3, 1);                                   // stage-A iterations
+#if K7_A_SINGLE
+                // one exit: alpha for every candidate that survived the block cull (84 % of them produce items anyway), all
+                // seven broadcasts up front so that their latencies overlap
+                const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
+                const float cc = RLF(r1.x, j), op = RLF(r1.y, j);
+                const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
+                const float araw = gauss_alpha_raw(op, power);
+                const float alpha = fminf(TG_ALPHA_MAX, araw);
+                const bool ok = (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                const unsigned long long bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(base + j < last) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+                const int nb = __popcll(bal);
+                if (nb == 0) { amask &= ~jbit; continue; }
+#else
                 const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
                 const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
                 const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
@@ -465,6 +495,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const unsigned long long bal = m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN);
                 const int nb = __popcll(bal);
                 if (nb == 0) { amask &= ~jbit; continue; }
+#endif
                 if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
                 amask &= ~jbit;
                 seg_mask |= jbit;
@@ -486,7 +517,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             // mostly wait on memory, so the loads of round 1 are issued before anything waits on those of round 0.
             struct Round {                                        // what the back half needs, as few registers as possible
                 bool have, binned;
-                int e, pl, my_leader, my_rank, axis;
+                int e, pl, jj, my_leader, my_rank, axis;
                 uint32_t bin, cell, slot0;
                 int o00, dox, doy;                                // tap offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
                 float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
@@ -501,6 +532,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const uint32_t key = __float_as_uint(it.w);
                 R.pl = (int)(key >> 8) & 63;
                 const int jj = (int)(key & 63u);
+                R.jj = jj;
                 const float4 q0 = s_recs[0 * 64 + jj], q1 = s_recs[1 * 64 + jj], r2 = s_recs[2 * 64 + jj],
                              r3 = s_recs[3 * 64 + jj], r4 = s_recs[4 * 64 + jj];
                 R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
@@ -553,7 +585,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 float x0 = 0.f, x1 = 0.f, x2 = 0.f;
                 if (R.have) {
                     const float w = R.w;
-                    const float d0 = s_dpix[R.pl * 3 + 0], d1 = s_dpix[R.pl * 3 + 1], d2 = s_dpix[R.pl * 3 + 2];
+                    const float4 dp = s_dpix[R.pl];
+                    const float d0 = dp.x, d1 = dp.y, d2 = dp.z;
                     const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + R.vd0 + 0.5f;
                     const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + R.vd1 + 0.5f;
                     const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + R.vd2 + 0.5f;
@@ -574,7 +607,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     else if (R.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
                     else                  { du2 = dum; du0 = dua; du1 = dub; }
                     const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
-                    s_items[R.e * 3].y = qv;
+                    // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
+                    // recurrence needs from this pair, formed here where all 64 lanes work
+                    const float4 c5 = s_recs[5 * 64 + R.jj];
+                    const float4 dg = *reinterpret_cast<const float4*>(&s_dgeo[R.pl * 4]);
+                    s_items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
                     s_items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
                     s_items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
                 }
@@ -603,8 +640,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             }
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage C1: per-pixel recurrence (sequential in j)
-            // dL/dalpha = T (s - suffix) - bg term, s = colour . dL/dpixel + geometry channels; leaves w = alpha T and
-            // P = dL/dpower in the item.  ~30 instructions per Gaussian -- the 28-value reduction is NOT done here.
+            // dL/dalpha_i = T_i s_i - (B_i + T_final bg . dL/dcolour) / (1 - alpha_i),  B_i = sum over the contributors k BEHIND i
+            // of s_k alpha_k T_k: one running sum per pixel (`behind`), back to front.  s_i (colour . dL/dcolour + geometry
+            // channels) comes ready-made from stage B; this loop leaves w = alpha T and P = dL/dpower in the item.
             int it0 = 0;
             uint32_t my_it0 = 0u;                                  // lane j: first item of Gaussian j in this segment
             if (K7_ABL != 0) my_it0_sink += (uint32_t)n_items + touched_lo;
@@ -615,19 +653,17 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     sm &= ~(1ull << jj);
                     const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)touched_lo, jj);
                     const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)touched_hi, jj);
-                    const float4 c5 = s_recs[5 * 64 + jj];                                       // uniform address: LDS broadcast
                     if (lane == jj) my_it0 = (uint32_t)it0;
                     if ((((unsigned long long)bhi << 32 | blo) >> lane) & 1ull) {
                         const int it = it0 + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
                         const float4 i0 = s_items[it * 3];
-                        const float Ti = i0.x, qv = i0.y, araw = i0.z;
+                        const float Ti = i0.x, s_i = i0.y, araw = i0.z;
                         const float alpha = fminf(TG_ALPHA_MAX, araw);
-                        const float s_i = qv + c5.x * dpix[3] + c5.y * dpix[4] + c5.z * dpix[5] + c5.w * dpix[6] + dpix[7];
-                        suffix = last_alpha * last_s + (1.f - last_alpha) * suffix;
-                        last_s = s_i; last_alpha = alpha;
-                        const float dL_dalpha_ = (s_i - suffix) * Ti - Tfin * __builtin_amdgcn_rcpf(1.0f - alpha) * bgdot;
+                        const float w = alpha * Ti;
+                        const float dL_dalpha_ = Ti * s_i - behind * __builtin_amdgcn_rcpf(1.0f - alpha);
+                        behind = __fmaf_rn(s_i, w, behind);
                         // {w, P}: P = dL/dpower straight through the 0.99 clamp (lineage)
-                        *reinterpret_cast<float2*>(&s_items[it * 3]) = make_float2(alpha * Ti, araw * dL_dalpha_);
+                        *reinterpret_cast<float2*>(&s_items[it * 3]) = make_float2(w, araw * dL_dalpha_);
                     }
                     it0 += __popcll(((unsigned long long)bhi << 32) | blo);
                 }
@@ -654,13 +690,17 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     K7_COUNT(10, 1);                              // C2 rounds (4 tasks each)
                     const int q = q0 + (lane >> 4);
                     const uint32_t task = (q < total) ? s_task[q] : 0u;
-                    const int jt = (int)(task & 63u), item = (int)((task >> 6) & 255u) + sub;
+                    const int jt = (int)(task & 63u);
                     const bool have = (uint32_t)sub < (task >> 14);
+                    // lanes without an item read the all-zero item behind the list: every moment below comes out 0 with no
+                    // branch and no 32-register clear (the butterfly needs all 64 lanes anyway)
+                    const int item = have ? (int)((task >> 6) & 255u) + sub : BQ_CAP;
+                    // Gaussian index of the task: lane jt holds instance jt's (all 64 lanes are active here: bpermute reads 0
+                    // from an inactive source lane)
+                    const uint32_t gid = (uint32_t)__builtin_amdgcn_ds_bpermute(jt << 2, (int)id);
                     float part[32];
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) part[k] = 0.f;
                     const float2 gxy = *reinterpret_cast<const float2*>(&s_recs[jt]);
-                    if (have) {
+                    {
                         const float4 i0 = s_items[item * 3], i1 = s_items[item * 3 + 1], i2 = s_items[item * 3 + 2];
                         const uint32_t key = __float_as_uint(i0.w);
                         const int pl = (int)(key >> 8) & 63;
@@ -672,7 +712,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                         const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
                         const float dpx = -dx, dpy = -dy;                       // pixel - xy
                         const float Pdx = P * dx, Pdy = P * dy;
-                        const float d3 = s_dgeo[pl * 4 + 0], d4 = s_dgeo[pl * 4 + 1], d5 = s_dgeo[pl * 4 + 2], d6 = s_dgeo[pl * 4 + 3];
+                        const float4 dg = *reinterpret_cast<const float4*>(&s_dgeo[pl * 4]);
                         part[M_P] = P; part[M_P + 1] = Pdx; part[M_P + 2] = Pdy;
                         part[M_P + 3] = Pdx * dx; part[M_P + 4] = Pdx * dy; part[M_P + 5] = Pdy * dy;
                         part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
@@ -681,13 +721,15 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                         part[M_DN + 6] = dn2; part[M_DN + 7] = dn2 * dpx; part[M_DN + 8] = dn2 * dpy;
                         part[M_PHI] = du0; part[M_PHI + 1] = du1; part[M_PHI + 2] = du2;
                         part[M_VD] = i1.x; part[M_VD + 1] = i1.y; part[M_VD + 2] = i1.z;
-                        part[M_DEPTH] = w * d3;
-                        part[M_N] = w * d4; part[M_N + 1] = w * d5; part[M_N + 2] = w * d6;
+                        part[M_DEPTH] = w * dg.x;
+                        part[M_N] = w * dg.y; part[M_N + 1] = w * dg.z; part[M_N + 2] = w * dg.w;
+#pragma unroll
+                        for (int k = M_N + 3; k < 32; ++k) part[k] = 0.f;
                     }
                     float lo, hi;
                     reduce32_rows16(part, lane, lo, hi);          // lane holds slots transposed_index(lane & 15) and 16 + that
                     if (q < total) {
-                        float* row = acc + (size_t)s_ids[jt] * TEXGS_ACC_FLOATS + transposed_index(sub);
+                        float* row = acc + (size_t)gid * TEXGS_ACC_FLOATS + transposed_index(sub);
                         if (lo != 0.f) unsafeAtomicAdd(row, lo);
                         if (hi != 0.f) unsafeAtomicAdd(row + 16, hi);
                     }
@@ -716,6 +758,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 #define TB_EDGE 33
 #ifndef TB_COPIES
 #define TB_COPIES 1
+#endif
+#ifndef TB_INFLIGHT
+#define TB_INFLIGHT 2
 #endif
 #ifndef TB_PLAIN_RMW
 #define TB_PLAIN_RMW 0
@@ -753,16 +798,21 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         TB_ADD(t + TB_EDGE * 3 + 3, w11 * dx0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * dx1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * dx2);
 #undef TB_ADD
     };
+    constexpr uint32_t NF = TB_INFLIGHT;                         // records per thread in flight (6 loads each)
     uint32_t i = (uint32_t)tid;
-    for (; i + 256u < cnt; i += 512u) {                          // two records per thread in flight (12 loads)
-        const uint32_t i2 = i + 256u;
-        const uint32_t ca = __float_as_uint(rp[i]), cb = __float_as_uint(rp[i2]);
-        const float fxa = rp[cap + i], fya = rp[2 * cap + i], xa0 = rp[3 * cap + i], xa1 = rp[4 * cap + i], xa2 = rp[5 * cap + i];
-        const float fxb = rp[cap + i2], fyb = rp[2 * cap + i2], xb0 = rp[3 * cap + i2], xb1 = rp[4 * cap + i2], xb2 = rp[5 * cap + i2];
-        add_record(ca, fxa, fya, xa0, xa1, xa2);
-        add_record(cb, fxb, fyb, xb0, xb1, xb2);
+    for (; i + 256u * (NF - 1u) < cnt; i += 256u * NF) {
+        uint32_t cl[NF];
+        float fx[NF], fy[NF], x0[NF], x1[NF], x2[NF];
+#pragma unroll
+        for (uint32_t k = 0; k < NF; ++k) {
+            const uint32_t ik = i + 256u * k;
+            cl[k] = __float_as_uint(rp[ik]);
+            fx[k] = rp[cap + ik]; fy[k] = rp[2 * cap + ik]; x0[k] = rp[3 * cap + ik]; x1[k] = rp[4 * cap + ik]; x2[k] = rp[5 * cap + ik];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NF; ++k) add_record(cl[k], fx[k], fy[k], x0[k], x1[k], x2[k]);
     }
-    if (i < cnt) add_record(__float_as_uint(rp[i]), rp[cap + i], rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i], rp[5 * cap + i]);
+    for (; i < cnt; i += 256u) add_record(__float_as_uint(rp[i]), rp[cap + i], rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i], rp[5 * cap + i]);
     __syncthreads();
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
