@@ -201,6 +201,10 @@ def main():
     kern_timed = _lib.profile_read()
     # the per-kernel table: two extra steps with every kernel group bracketed, views one after the other on one stream, so
     # that each duration is the kernel's own (in the pipelined region a kernel shares the GPU with other views' kernels)
+    _lib.profile_enable(False)
+    for _ in range(2):          # the serial path runs on another stream: its per-stream scratch (texture-bin capacity) adapts first
+        step(pipe_serial)
+    fence()
     _lib.profile_enable(True, only=[DOMINANT])
     step(pipe_serial)
     fence()

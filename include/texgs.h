@@ -217,6 +217,13 @@ int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_i
                       const float* gt_depth, int32_t H, int32_t W, float lambda_norm, float lambda_smooth, float gamma,
                       float lambda_depth, float* sums, float* dL_dnorm, float* dL_ddepth, void* stream);
 
+/* Pseudo-normal and validity mask from the operator's depth output -- norm_from_depth of losses/norm_reg_loss.py:16-63, the
+ * producer of (gt_norm, mask) for the normal-regularisation term norm_reg_loss (:73-78, models/texture_gaussian3d.py:360-363;
+ * the reference detaches depth there, so there is no backward).  depth f32[1,H,W]; cam_to_world = 12 HOST floats, rows 0..2 of
+ * inverse(world_view_transform^T) (camera -> world, column-vector convention); out_norm f32[3,H,W]; out_mask f32[1,H,W]. */
+int texgs_norm_from_depth(const float* depth, const float* cam_to_world, float tanfovx, float tanfovy, int32_t H, int32_t W,
+                          float threshold, float* out_norm, float* out_mask, void* stream);
+
 /* Fused UV-Taylor producer: the operator inputs `uvs` and `gradient_uvs` straight from the Gaussian centres, replacing
  * UVNet.forward (models/modules/uv_net.py:19-36) + torch.autograd.functional.jacobian (models/texture_gaussian3d.py:216-227).
  * Weights are nn.Linear tensors (row-major [out, in]) of the shipped architecture (hidden width 128): pre_mlp = W1, W2;

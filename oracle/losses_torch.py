@@ -58,3 +58,32 @@ def geom_losses(norm, gt_norm, gt_image, mask, depth, gt_depth, ln, ls, ld, gamm
     if depth is not None:
         loss = loss + ld * (depth - gt_depth).abs().mean()
     return loss
+
+
+def norm_from_depth(depth, world_view_transform, tanfovx, tanfovy, threshold=1e-2):
+    """losses/norm_reg_loss.py:16-63 restated with slices instead of conv2d filters: back-projection of every pixel with
+    ndc = (2 p + 1) / S - 1, one-sided differences with replicate border, normal = normalise(cross(grad_y, grad_x), eps 1e-6),
+    mask = all four one-sided differences shorter than `threshold`.  Works in the dtype of `depth`."""
+    _, H, W = depth.shape
+    dt = depth.dtype
+    px = torch.arange(W, dtype=dt).reshape(1, 1, W).expand(1, H, W)
+    py = torch.arange(H, dtype=dt).reshape(1, H, 1).expand(1, H, W)
+    nx, ny = (2.0 * px + 1.0) / W - 1.0, (2.0 * py + 1.0) / H - 1.0
+    cc = torch.cat([nx * tanfovx * depth, ny * tanfovy * depth, depth, torch.ones_like(depth)], dim=0)
+    c2w = torch.linalg.inv(world_view_transform.to(dt).transpose(0, 1))
+    xyz = (c2w @ cc.reshape(4, H * W)).reshape(4, H, W)[:3]
+    pad = F.pad(xyz.unsqueeze(0), (1, 1, 1, 1), mode="replicate").squeeze(0)
+    c = pad[:, 1:-1, 1:-1]
+    gl, gr = c - pad[:, 1:-1, :-2], pad[:, 1:-1, 2:] - c
+    gu, gd = c - pad[:, :-2, 1:-1], pad[:, 2:, 1:-1] - c
+    gx, gy = (gr + gl) / 2, (gd + gu) / 2
+    mask = ((gl.norm(dim=0, keepdim=True) < threshold) & (gr.norm(dim=0, keepdim=True) < threshold)
+            & (gu.norm(dim=0, keepdim=True) < threshold) & (gd.norm(dim=0, keepdim=True) < threshold))
+    n = torch.cross(gy, gx, dim=0)
+    return F.normalize(n, p=2, dim=0, eps=1e-6), mask.to(dt)
+
+
+def norm_reg_loss(norm, depth, world_view_transform, tanfovx, tanfovy, gt_alpha, threshold=1e-2):
+    """losses/norm_reg_loss.py:73-78."""
+    norm2, mask = norm_from_depth(depth.detach(), world_view_transform, tanfovx, tanfovy, threshold)
+    return norm_loss(norm, norm2, gt_alpha * mask)

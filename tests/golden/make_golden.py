@@ -13,6 +13,8 @@ no source) travel to the GPU box, the reference does not.
   geom_losses.npz  losses/norm_reg_loss.py norm_loss, losses/smooth_loss.py smooth_loss and losses/pixelwise_loss.py l1_loss
                combined as models/texture_gaussian3d.py:347-368 combines them (lambda_norm 0.1, lambda_norm_smooth 0.5 of
                configs/texture_gaussian3d.yaml, plus a depth term), values AND autograd gradients w.r.t. norm / depth
+  norm_from_depth.npz  losses/norm_reg_loss.py norm_from_depth (pseudo-normal + mask of a depth map) and norm_reg_loss with its
+               autograd gradient w.r.t. the predicted normal, two cameras from utils/graphics.py getWorld2View2
   uvnet.npz    models/modules/uv_net.py UVNet with models/modules/utils.py build_nn_network (the `use_tcnn: False` path; utils.py
                imports tinycudann at top level, so the class / function definitions are taken from the two sources with `ast`
                and RUN): weights, embedding, 64 points, uvs, and the Jacobian exactly as
@@ -148,6 +150,39 @@ def geom_losses():
     np.savez_compressed(os.path.join(HERE, "geom_losses.npz"), **out)
 
 
+def norm_from_depth():
+    """losses/norm_reg_loss.py norm_from_depth / norm_reg_loss on a smooth synthetic depth map (a tilted, gently bumpy
+    surface with one depth step so that the mask has both values), camera from utils/graphics.py getWorld2View2."""
+    sys.path.insert(0, REF)
+    from losses.norm_reg_loss import norm_from_depth as ref_nfd, norm_reg_loss as ref_nrl
+    from utils.graphics import getWorld2View2
+    rng = np.random.RandomState(5)
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for tag, (H, W, fovx, fovy) in {"a": (40, 52, 0.9, 0.7), "b": (33, 24, 0.5, 0.65)}.items():
+        q, _ = np.linalg.qr(rng.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        wvt = torch.tensor(getWorld2View2(q, rng.randn(3), np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+        yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        depth = 0.35 + 0.002 * xx + 0.001 * yy + 0.004 * torch.sin(0.3 * xx) * torch.cos(0.2 * yy)
+        depth[:, W // 2:] += 0.05                                  # a depth discontinuity: mask 0 along it
+        depth = (depth + 1e-4 * torch.rand(H, W, generator=g)).reshape(1, H, W)
+
+        class View:
+            FoVx, FoVy, world_view_transform = fovx, fovy, wvt
+        norm2, mask = ref_nfd(depth, View)
+        pred = torch.randn(3, H, W, generator=g)
+        pred = (pred / pred.norm(dim=0, keepdim=True)).requires_grad_(True)
+        gt_alpha = (torch.rand(1, H, W, generator=g) > 0.2).float()
+        loss = ref_nrl(pred, depth, View, gt_alpha)
+        loss.backward()
+        out.update({f"{tag}_depth": depth.numpy(), f"{tag}_wvt": wvt.numpy(), f"{tag}_fov": np.array([fovx, fovy]),
+                    f"{tag}_norm2": norm2.numpy(), f"{tag}_mask": mask.numpy(), f"{tag}_pred": pred.detach().numpy(),
+                    f"{tag}_gt_alpha": gt_alpha.numpy(), f"{tag}_loss": float(loss), f"{tag}_dpred": pred.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, "norm_from_depth.npz"), **out)
+
+
 def uvnet():
     import ast
     from torch import nn
@@ -235,7 +270,7 @@ def op_small():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "uvnet", "texture_io", "op_small"]
+    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "norm_from_depth", "uvnet", "texture_io", "op_small"]
     for name in which:
         globals()[name]()
     print("golden fixtures written to", HERE)

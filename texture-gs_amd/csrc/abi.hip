@@ -279,6 +279,15 @@ int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_i
     return e == hipSuccess ? 0 : fail("geom_losses", e);
 }
 
+int texgs_norm_from_depth(const float* depth, const float* cam_to_world, float tanfovx, float tanfovy, int32_t H, int32_t W,
+                          float threshold, float* out_norm, float* out_mask, void* stream) {
+    if (!depth || !cam_to_world || !out_norm || !out_mask) return fail_msg("NULL argument");
+    if (H <= 0 || W <= 0) return fail_msg("image size must be positive");
+    launch_norm_from_depth(depth, cam_to_world, tanfovx, tanfovy, H, W, threshold, out_norm, out_mask, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("norm_from_depth", e);
+}
+
 size_t texgs_uv_taylor_temp_bytes(void) { return uv_taylor_temp_bytes(); }
 
 int texgs_uv_taylor(const TexGSUVNet* net, const float* xyz, int32_t N, float* uvs, float* grad_uvs, void* temp, void* stream) {

@@ -238,6 +238,50 @@ k_geom_grad(GeomArgs a, float l_norm, float l_smooth, float l_depth, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------ pseudo-normal from depth
+// losses/norm_reg_loss.py:16-63 (norm_from_depth): back-project every pixel's depth to a world-space point, one-sided
+// differences to the four neighbours (replicate border), normal = normalise(cross(grad_y, grad_x)) with grad_x / grad_y the
+// means of the two one-sided differences, mask = all four differences shorter than `threshold`.  `c2w` is the inverse of the
+// column-convention view matrix (world_view_transform^T), rows 0..2 (12 floats).  One thread per pixel: 5 depth reads (L1 / L2
+// hits), 16 bytes written -- elementwise HBM work, no LDS.
+struct DepthNormArgs { int H, W; float tx, ty, thr; float m[12]; };
+
+__device__ __forceinline__ void backproject(const DepthNormArgs& a, const float* __restrict__ depth, int x, int y, float (&p)[3]) {
+    const float d = depth[y * a.W + x];
+    const float nx = (2.0f * (float)x + 1.0f) / (float)a.W - 1.0f, ny = (2.0f * (float)y + 1.0f) / (float)a.H - 1.0f;
+    const float cx = nx * a.tx * d, cy = ny * a.ty * d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = a.m[4 * k] * cx + a.m[4 * k + 1] * cy + a.m[4 * k + 2] * d + a.m[4 * k + 3];
+}
+
+__global__ void __launch_bounds__(256)
+k_norm_from_depth(DepthNormArgs a, const float* __restrict__ depth, float* __restrict__ out_norm, float* __restrict__ out_mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x, P = a.H * a.W;
+    if (i >= P) return;
+    const int y = i / a.W, x = i - y * a.W;
+    float c[3], l[3], r[3], u[3], dn[3];
+    backproject(a, depth, x, y, c);
+    backproject(a, depth, max(x - 1, 0), y, l);
+    backproject(a, depth, min(x + 1, a.W - 1), y, r);
+    backproject(a, depth, x, max(y - 1, 0), u);
+    backproject(a, depth, x, min(y + 1, a.H - 1), dn);
+    float gl[3], gr[3], gu[3], gd[3], gx[3], gy[3];
+    float nl = 0.f, nr = 0.f, nu = 0.f, nd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gl[k] = c[k] - l[k]; gr[k] = r[k] - c[k]; gu[k] = c[k] - u[k]; gd[k] = dn[k] - c[k];
+        nl += gl[k] * gl[k]; nr += gr[k] * gr[k]; nu += gu[k] * gu[k]; nd += gd[k] * gd[k];
+        gx[k] = (gr[k] + gl[k]) * 0.5f; gy[k] = (gd[k] + gu[k]) * 0.5f;
+    }
+    const float t2 = a.thr;
+    const bool ok = sqrtf(nl) < t2 && sqrtf(nr) < t2 && sqrtf(nu) < t2 && sqrtf(nd) < t2;
+    // cross(grad_y, grad_x)
+    const float n0 = gy[1] * gx[2] - gy[2] * gx[1], n1 = gy[2] * gx[0] - gy[0] * gx[2], n2 = gy[0] * gx[1] - gy[1] * gx[0];
+    const float len = fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-6f);      // F.normalize(eps = 1e-6)
+    out_norm[i] = n0 / len; out_norm[P + i] = n1 / len; out_norm[2 * P + i] = n2 / len;
+    out_mask[i] = ok ? 1.0f : 0.0f;
+}
+
 }  // namespace
 
 int launch_geom_losses(const float* norm, const float* gt_norm, const float* gt_image, const float* mask, const float* depth,
@@ -274,5 +318,15 @@ int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float
         hipLaunchKernelGGL(k_alpha_l1, dim3((P + 255) / 256), dim3(256), 0, s, P, alpha, gt_alpha, lambda_alpha / (float)P,
                            d_alpha, sums);
     }
+    return 0;
+}
+
+int launch_norm_from_depth(const float* depth, const float* c2w12, float tanfovx, float tanfovy, int H, int W, float threshold,
+                           float* out_norm, float* out_mask, hipStream_t s) {
+    DepthNormArgs a;
+    a.H = H; a.W = W; a.tx = tanfovx; a.ty = tanfovy; a.thr = threshold;
+    for (int k = 0; k < 12; ++k) a.m[k] = c2w12[k];
+    const int P = H * W;
+    hipLaunchKernelGGL(k_norm_from_depth, dim3((P + 255) / 256), dim3(256), 0, s, a, depth, out_norm, out_mask);
     return 0;
 }

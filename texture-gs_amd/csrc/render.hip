@@ -160,7 +160,7 @@ inline int blend_grid(int num_tiles) {
 //  the wave time an LDS-issue stall: profiles/r01_v7_summary.txt.)
 #define FQ_CAP 128
 #ifndef FWD_WAVES_PER_SIMD
-#define FWD_WAVES_PER_SIMD 8
+#define FWD_WAVES_PER_SIMD 5       // 81 VGPRs.  (6 = 80 VGPRs was measured: same solo time, slower next to another view's K7)
 #endif
 
 __global__ void __launch_bounds__(TG_WG_THREADS, FWD_WAVES_PER_SIMD)
@@ -759,6 +759,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 #ifndef TB_COPIES
 #define TB_COPIES 1
 #endif
+#ifndef TB_PLANAR
+#define TB_PLANAR 0
+#endif
 #ifndef TB_INFLIGHT
 #define TB_INFLIGHT 2
 #endif
@@ -789,6 +792,17 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         const double dx0 = (double)x0 * up, dx1 = (double)x1 * up, dx2 = (double)x2 * up;
         const double w00 = (double)((1.f - fx) * (1.f - fy)), w01 = (double)(fx * (1.f - fy));
         const double w10 = (double)((1.f - fx) * fy), w11 = (double)(fx * fy);
+#if TB_PLANAR
+        // planar tile [channel][row][col]: records of neighbouring pixels land on neighbouring 8-byte words (no bank conflict)
+        // instead of 24 bytes apart
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + (cell >> 8) * TB_EDGE + (cell & 0xFFu);
+#define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(__double_as_longlong((V) + magic) - magic_bits))
+        constexpr int PL = TB_EDGE * TB_EDGE;
+        TB_ADD(t, w00 * dx0); TB_ADD(t + PL, w00 * dx1); TB_ADD(t + 2 * PL, w00 * dx2);
+        TB_ADD(t + 1, w01 * dx0); TB_ADD(t + PL + 1, w01 * dx1); TB_ADD(t + 2 * PL + 1, w01 * dx2);
+        TB_ADD(t + TB_EDGE, w10 * dx0); TB_ADD(t + PL + TB_EDGE, w10 * dx1); TB_ADD(t + 2 * PL + TB_EDGE, w10 * dx2);
+        TB_ADD(t + TB_EDGE + 1, w11 * dx0); TB_ADD(t + PL + TB_EDGE + 1, w11 * dx1); TB_ADD(t + 2 * PL + TB_EDGE + 1, w11 * dx2);
+#else
         unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + (tid & (TB_COPIES - 1)) * (TB_EDGE * TB_EDGE * 3)
                               + ((cell >> 8) * TB_EDGE + (cell & 0xFFu)) * 3;
 #define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(__double_as_longlong((V) + magic) - magic_bits))
@@ -796,6 +810,7 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         TB_ADD(t + 3, w01 * dx0); TB_ADD(t + 4, w01 * dx1); TB_ADD(t + 5, w01 * dx2);
         TB_ADD(t + TB_EDGE * 3 + 0, w10 * dx0); TB_ADD(t + TB_EDGE * 3 + 1, w10 * dx1); TB_ADD(t + TB_EDGE * 3 + 2, w10 * dx2);
         TB_ADD(t + TB_EDGE * 3 + 3, w11 * dx0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * dx1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * dx2);
+#endif
 #undef TB_ADD
     };
     constexpr uint32_t NF = TB_INFLIGHT;                         // records per thread in flight (6 loads each)
@@ -816,11 +831,15 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __syncthreads();
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
+        const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
+#if TB_PLANAR
+        long long q = s_tile[(c % 3) * (TB_EDGE * TB_EDGE) + row * TB_EDGE + c / 3];
+#else
         long long q = s_tile[k];
 #pragma unroll
         for (int cp = 1; cp < TB_COPIES; ++cp) q += s_tile[cp * TB_EDGE * TB_EDGE * 3 + k];
+#endif
         if (q == 0ll) continue;
-        const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
         const int y = by * 32 + row, xq = bx * 96 + c;
         if (y >= R || xq >= R * 3) continue;
         float* o = dtex + ((size_t)(face * R + y) * R) * 3 + xq;

@@ -110,3 +110,35 @@ def geom_losses(norm=None, gt_norm=None, gt_image=None, mask=None, depth=None, g
     differentiable w.r.t. norm and depth -- the gradients go straight into the rasterizer's backward."""
     return _GeomLosses.apply(norm, gt_norm, gt_image, mask, depth, gt_depth, float(lambda_norm), float(lambda_smooth),
                              float(gamma), float(lambda_depth))
+
+
+def norm_from_depth(depth, world_view_transform, tanfovx, tanfovy, threshold=1e-2):
+    """Pseudo-normal [3,H,W] and validity mask [1,H,W] from a depth map [1,H,W] (losses/norm_reg_loss.py:16-63): pixels are
+    back-projected with the camera (`world_view_transform` as the reference stores it: row-vector convention, [4,4]), the
+    normal is the normalised cross product of the central differences and the mask keeps pixels whose four one-sided
+    differences are all shorter than `threshold`.  No gradient (the reference calls it on depth.detach())."""
+    lib = _lib.load()
+    depth = depth.detach()
+    if depth.device.type != "cuda":
+        raise RuntimeError("norm_from_depth runs on an AMD GPU (torch device 'cuda' = HIP); there is no CPU fallback")
+    if depth.dim() != 3 or depth.shape[0] != 1 or depth.dtype != torch.float32:
+        raise ValueError(f"depth must be float32 [1,H,W], got {depth.dtype} {tuple(depth.shape)}")
+    depth = depth.contiguous()
+    _, H, W = depth.shape
+    # inverse of the column-convention view matrix, as the reference forms it (float32 torch.linalg.inv)
+    c2w = torch.linalg.inv(world_view_transform.detach().to(torch.float32).cpu().transpose(0, 1))[:3].contiguous()
+    m = (C.c_float * 12)(*[float(v) for v in c2w.reshape(-1)])
+    norm = torch.empty(3, H, W, dtype=torch.float32, device=depth.device)
+    mask = torch.empty(1, H, W, dtype=torch.float32, device=depth.device)
+    with torch.cuda.device(depth.device):
+        _lib.check(lib.texgs_norm_from_depth(depth.data_ptr(), m, float(tanfovx), float(tanfovy), H, W, float(threshold),
+                                             norm.data_ptr(), mask.data_ptr(),
+                                             torch.cuda.current_stream(depth.device).cuda_stream), "texgs_norm_from_depth")
+    return norm, mask
+
+
+def norm_reg_loss(norm, depth, world_view_transform, tanfovx, tanfovy, gt_alpha, threshold=1e-2):
+    """norm_reg_loss of losses/norm_reg_loss.py:73-78 (models/texture_gaussian3d.py:360-363): the rendered normal against the
+    pseudo-normal of the rendered (detached) depth, masked by gt_alpha * validity; differentiable w.r.t. `norm`."""
+    norm2, mask = norm_from_depth(depth, world_view_transform, tanfovx, tanfovy, threshold)
+    return geom_losses(norm=norm, gt_norm=norm2, mask=gt_alpha * mask, lambda_norm=1.0)
