@@ -23,9 +23,6 @@ namespace {
 #define TG_WAVES_PER_WG 1          // 1: one workgroup per 8x8 block (finest dispatch; K7 keeps 11 waves/CU by LDS); 4: one per tile
 #endif
 #define TG_WG_THREADS (64 * TG_WAVES_PER_WG)
-#ifndef K6_A_SINGLE
-#define K6_A_SINGLE 1      // one exit per tested instance (alpha always evaluated); 0 = power-threshold prefilter, then the alpha test
-#endif
 
 struct __attribute__((packed, aligned(4))) Texel3 { float x, y, z; };   // one global_load_dwordx3 per tap
 __device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, int off) {
@@ -255,39 +252,30 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         __builtin_amdgcn_wave_barrier();
         // per-wave cull, lane-parallel: can instance `lane` reach alpha >= 1/255 anywhere in this wave's 8x8 block?
         unsigned long long todo_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
-        while (todo_mask != 0ull) {
-            const int j = __ffsll((long long)todo_mask) - 1;
-            todo_mask &= todo_mask - 1ull;
-#if K6_A_SINGLE
+        // One exit per tested instance: alpha is evaluated for every candidate that survived the block cull (84 % of them blend
+        // somewhere in the block; a power-threshold prefilter ahead of the alpha test was slower).  Wave-level decisions are
+        // PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask and the combination is scalar
+        // ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip.
+        auto test = [&](int j, float& power, float& alpha, float4& geo) {
             const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
             const float cc = RLF(r1.x, j), op = RLF(r1.y, j);
-            const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-            const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
-            const unsigned long long m_neg = TG_BALLOT(power <= 0.0f) & ~done_mask;
-            if ((m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN)) == 0ull) continue;
-#else
-            const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
-            const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
-            const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-            // wave-level decisions as PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask
-            // and the combination is scalar ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip
-            const unsigned long long m_neg = TG_BALLOT(power <= 0.0f) & ~done_mask;
-            if ((m_neg & TG_BALLOT(power >= thr)) == 0ull) continue;                          // conservative prefilter
-            const float op = RLF(r1.y, j);
-            const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
-#endif
+            geo = make_float4(RLF(r5.x, j), RLF(r5.y, j), RLF(r5.z, j), RLF(r5.w, j));       // depth, normal
+            power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
+            alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
+        };
+        auto blend = [&](int j, float power, float alpha, const float4& geo) -> bool {          // true: every pixel is done
+            const unsigned long long m_ok = TG_BALLOT(power <= 0.0f) & ~done_mask & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+            if (m_ok == 0ull) return false;
             bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
             const float Tn = T * (1.0f - alpha);
-            const unsigned long long m_ok = m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN);
             const unsigned long long m_kill = m_ok & TG_BALLOT(Tn < TG_T_EPS);
             if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
             done_mask |= m_kill;
             const unsigned long long bal = m_ok & ~m_kill;
             if (bal != 0ull) {
-                const float dep = RLF(r5.x, j), n0 = RLF(r5.y, j), n1 = RLF(r5.z, j), n2 = RLF(r5.w, j);
                 if (ok) {
                     const float w = alpha * T;
-                    Dp += w * dep; N0 += w * n0; N1 += w * n1; N2 += w * n2; Al += w;
+                    Dp += w * geo.x; N0 += w * geo.y; N1 += w * geo.z; N2 += w * geo.w; Al += w;
                     T = Tn;
                     last = (uint32_t)(base + j + 1);
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
@@ -300,8 +288,16 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
                     drain(64);
                     qhead += 64;
                 }
-                if (~done_mask == 0ull) break;
             }
+            return ~done_mask == 0ull;
+        };
+        while (todo_mask != 0ull) {
+            const int j = __ffsll((long long)todo_mask) - 1;
+            todo_mask &= todo_mask - 1ull;
+            float p, al;
+            float4 g;
+            test(j, p, al, g);
+            if (blend(j, p, al, g)) break;
         }
         // items reference this chunk's LDS copy: finish them before the next chunk is loaded
         if (qtail - qhead > 0) {
@@ -351,12 +347,6 @@ __device__ unsigned long long g_k7_stats[16];
 #define K7_COUNT(i, n) (k7s[i] += (unsigned)(n))
 #else
 #define K7_COUNT(i, n) ((void)0)
-#endif
-#ifndef K7_A_SINGLE
-#define K7_A_SINGLE 1
-#endif
-#ifndef K6_A_SINGLE
-#define K6_A_SINGLE 0
 #endif
 #ifndef K7_ABL
 #define K7_ABL 0      // timing-only ablations (scripts/bench_variants.sh): 1 = no stage C1, 2 = no stage C2, 4 = no stage B
@@ -469,9 +459,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const int j = 63 - __clzll((long long)amask);
                 const unsigned long long jbit = 1ull << j;
                 K7_COUNT(3, 1);                                   // stage-A iterations
-#if K7_A_SINGLE
-                // one exit: alpha for every candidate that survived the block cull (84 % of them produce items anyway), all
-                // seven broadcasts up front so that their latencies overlap
+                // one exit: alpha for every candidate that survived the block cull (84 % of them produce items anyway; a
+                // power-threshold prefilter before the alpha test was slower), all six broadcasts up front
                 const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
                 const float cc = RLF(r1.x, j), op = RLF(r1.y, j);
                 const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
@@ -481,21 +470,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const unsigned long long bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(base + j < last) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
                 const int nb = __popcll(bal);
                 if (nb == 0) { amask &= ~jbit; continue; }
-#else
-                const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
-                const float cc = RLF(r1.x, j), thr = RLF(r6.y, j);
-                const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-                // products of single-compare ballots (see K6): `last` bounds which pixels still replay instance base + j
-                const unsigned long long m_neg = TG_BALLOT(power <= 0.0f) & TG_BALLOT(base + j < last);
-                if ((m_neg & TG_BALLOT(power >= thr)) == 0ull) { amask &= ~jbit; continue; }
-                const float op = RLF(r1.y, j);
-                const float araw = gauss_alpha_raw(op, power);
-                const float alpha = fminf(TG_ALPHA_MAX, araw);
-                const bool ok = (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-                const unsigned long long bal = m_neg & TG_BALLOT(alpha >= TG_ALPHA_MIN);
-                const int nb = __popcll(bal);
-                if (nb == 0) { amask &= ~jbit; continue; }
-#endif
                 if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
                 amask &= ~jbit;
                 seg_mask |= jbit;
