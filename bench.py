@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--views-per-step", type=int, default=8)
     ap.add_argument("--num-views", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true",
+                    help="skip the extra serial steps behind the per-kernel table (profiling runs: every launch is then a pipelined one)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
                     help="HIP streams the views of a step are pipelined over (texgs.multiview.ViewPipeline); 1 = serial")
     ap.add_argument("--order", default=os.environ.get("TEXGS_BENCH_ORDER", "accumulate"), choices=["backward", "accumulate", "none"])
@@ -201,19 +203,22 @@ def main():
     kern_timed = _lib.profile_read()
     # the per-kernel table: two extra steps with every kernel group bracketed, views one after the other on one stream, so
     # that each duration is the kernel's own (in the pipelined region a kernel shares the GPU with other views' kernels)
-    _lib.profile_enable(False)
-    for _ in range(2):          # the serial path runs on another stream: its per-stream scratch (texture-bin capacity) adapts first
+    kern = dict(kern_timed)
+    kern_solo_dom = (0.0, 0)
+    if not args.no_kernel_table:
+        _lib.profile_enable(False)
+        for _ in range(2):      # the serial path runs on another stream: its per-stream scratch (texture-bin capacity) adapts first
+            step(pipe_serial)
+        fence()
+        _lib.profile_enable(True, only=[DOMINANT])
         step(pipe_serial)
-    fence()
-    _lib.profile_enable(True, only=[DOMINANT])
-    step(pipe_serial)
-    fence()
-    kern_solo_dom = _lib.profile_read()[DOMINANT]      # the dominant kernel alone on the GPU, only it bracketed
-    _lib.profile_enable(True)
-    for _ in range(2):
-        step(pipe_serial)
-    fence()
-    kern = _lib.profile_read()
+        fence()
+        kern_solo_dom = _lib.profile_read()[DOMINANT]      # the dominant kernel alone on the GPU, only it bracketed
+        _lib.profile_enable(True)
+        for _ in range(2):
+            step(pipe_serial)
+        fence()
+        kern = _lib.profile_read()
     _lib.profile_enable(False)
     kern[DOMINANT] = kern_timed[DOMINANT]
     step_ms = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
@@ -271,9 +276,10 @@ def main():
             solo_us = 1e3 * kern_solo_dom[0] / kern_solo_dom[1]
             roofline["solo_launch_us"] = round(solo_us, 2)
             roofline["solo_frac"] = round(ab[dom] / (solo_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
-            roofline["note"] = (f"achieved / frac use the launch duration inside the timed region, where {args.streams} views are in "
-                                "flight on separate HIP streams and the kernel shares the GPU with other views' kernels; solo_* is the "
-                                "same kernel with the views run one after the other (two extra steps)")
+            if args.streams > 1:
+                roofline["note"] = (f"achieved / frac use the launch duration inside the timed region, where {args.streams} views are in "
+                                    "flight on separate HIP streams and the kernel shares the GPU with other views' kernels; solo_* is "
+                                    "the same kernel with the views run one after the other (extra steps after the timed region)")
     view_bytes = sum(ab[k] for k in ab if (with_bwd or k not in ("render_bwd", "preprocess_bwd")))
 
     # same-run measured HBM ceiling: device-to-device copy of 1 GiB, read + write bytes
@@ -298,7 +304,7 @@ def main():
     # ---- the same workload through the reference-compatible call pattern: activation OUTPUTS as operator
     # inputs, a fresh non-leaf means2D per view, plain autograd (no grad_sink) -- what render/uv_tex_render.py does.
     compat = None
-    if rank == 0 and with_bwd:
+    if rank == 0 and with_bwd and not args.no_kernel_table:
         raw = {n: leaves[n].detach().clone().requires_grad_(True) for n in names}
         raw["scales"] = leaves["scales"].detach().log().requires_grad_(True)
         op = leaves["opacities"].detach().clamp(1e-6, 1 - 1e-6)

@@ -8,7 +8,7 @@ def short(n):
     if "scan" in n.lower(): return "scan:" + n.split("(")[0][-30:]
     return n[:60]
 # stats
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+for f in sorted(glob.glob(os.path.join(root, "trace*", "**", "*kernel_stats.csv"), recursive=True)):
     print("== kernel stats", f)
     for r in list(csv.DictReader(open(f)))[:25]:
         print(f"{short(r['Name']):50s} calls {r['Calls']:>5s} avg_ns {float(r['AverageNs']):12.0f} total% {r['Percentage']}")
