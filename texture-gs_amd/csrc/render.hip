@@ -730,25 +730,13 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 // < 2^42, so 2^20 records per bin cannot overflow; resolution 2^-42 of the image-wide bound, sums exact and
 // order-independent (the texture gradient of the binned path is bit-reproducible run to run).
 #define TB_EDGE 33
-#ifndef TB_COPIES
-#define TB_COPIES 1
-#endif
-#ifndef TB_PLANAR
-#define TB_PLANAR 0
-#endif
-#ifndef TB_INFLIGHT
-#define TB_INFLIGHT 2
-#endif
-#ifndef TB_PLAIN_RMW
-#define TB_PLAIN_RMW 0
-#endif
 __global__ void __launch_bounds__(256)
 k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
-    __shared__ long long s_tile[TB_COPIES * TB_EDGE * TB_EDGE * 3];      // two copies, even / odd lanes: halves the conflicts of
-    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;      // lanes that hit the same texel (66 % conflict cycles with one)
+    __shared__ long long s_tile[TB_EDGE * TB_EDGE * 3];          // [row][col][channel], 2^42-scaled fixed point
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
     const uint32_t filled = tb.cursor[b];
     if (filled == 0u) return;                                  // uniform per workgroup
-    for (int k = tid; k < TB_COPIES * TB_EDGE * TB_EDGE * 3; k += 256) s_tile[k] = 0ll;
+    for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) s_tile[k] = 0ll;
     __syncthreads();
     const float bound = TG_SH_C0 * __uint_as_float(tb.stats[1]);
     int e = 0;
@@ -766,61 +754,37 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         const double dx0 = (double)x0 * up, dx1 = (double)x1 * up, dx2 = (double)x2 * up;
         const double w00 = (double)((1.f - fx) * (1.f - fy)), w01 = (double)(fx * (1.f - fy));
         const double w10 = (double)((1.f - fx) * fy), w11 = (double)(fx * fy);
-#if TB_PLANAR
-        // planar tile [channel][row][col]: records of neighbouring pixels land on neighbouring 8-byte words (no bank conflict)
-        // instead of 24 bytes apart
-        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + (cell >> 8) * TB_EDGE + (cell & 0xFFu);
-#define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(__double_as_longlong((V) + magic) - magic_bits))
-        constexpr int PL = TB_EDGE * TB_EDGE;
-        TB_ADD(t, w00 * dx0); TB_ADD(t + PL, w00 * dx1); TB_ADD(t + 2 * PL, w00 * dx2);
-        TB_ADD(t + 1, w01 * dx0); TB_ADD(t + PL + 1, w01 * dx1); TB_ADD(t + 2 * PL + 1, w01 * dx2);
-        TB_ADD(t + TB_EDGE, w10 * dx0); TB_ADD(t + PL + TB_EDGE, w10 * dx1); TB_ADD(t + 2 * PL + TB_EDGE, w10 * dx2);
-        TB_ADD(t + TB_EDGE + 1, w11 * dx0); TB_ADD(t + PL + TB_EDGE + 1, w11 * dx1); TB_ADD(t + 2 * PL + TB_EDGE + 1, w11 * dx2);
-#else
-        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + (tid & (TB_COPIES - 1)) * (TB_EDGE * TB_EDGE * 3)
-                              + ((cell >> 8) * TB_EDGE + (cell & 0xFFu)) * 3;
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + ((cell >> 8) * TB_EDGE + (cell & 0xFFu)) * 3;
 #define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(__double_as_longlong((V) + magic) - magic_bits))
         TB_ADD(t + 0, w00 * dx0); TB_ADD(t + 1, w00 * dx1); TB_ADD(t + 2, w00 * dx2);
         TB_ADD(t + 3, w01 * dx0); TB_ADD(t + 4, w01 * dx1); TB_ADD(t + 5, w01 * dx2);
         TB_ADD(t + TB_EDGE * 3 + 0, w10 * dx0); TB_ADD(t + TB_EDGE * 3 + 1, w10 * dx1); TB_ADD(t + TB_EDGE * 3 + 2, w10 * dx2);
         TB_ADD(t + TB_EDGE * 3 + 3, w11 * dx0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * dx1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * dx2);
-#endif
 #undef TB_ADD
     };
-    constexpr uint32_t NF = TB_INFLIGHT;                         // records per thread in flight (6 loads each)
+    // two records per thread in flight (12 loads).  Measured and dropped: 4 / 8 in flight, two tile copies for even / odd lanes, a
+    // planar [channel][row][col] tile, plain read-modify-write of the tile interior on the way out (profiles/README.md): the
+    // kernel sits at 2x its HBM floor (the records, 0.45 GB at C3) with 66 % LDS bank-conflict cycles on the random atomics
     uint32_t i = (uint32_t)tid;
-    for (; i + 256u * (NF - 1u) < cnt; i += 256u * NF) {
-        uint32_t cl[NF];
-        float fx[NF], fy[NF], x0[NF], x1[NF], x2[NF];
-#pragma unroll
-        for (uint32_t k = 0; k < NF; ++k) {
-            const uint32_t ik = i + 256u * k;
-            cl[k] = __float_as_uint(rp[ik]);
-            fx[k] = rp[cap + ik]; fy[k] = rp[2 * cap + ik]; x0[k] = rp[3 * cap + ik]; x1[k] = rp[4 * cap + ik]; x2[k] = rp[5 * cap + ik];
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < NF; ++k) add_record(cl[k], fx[k], fy[k], x0[k], x1[k], x2[k]);
+    for (; i + 256u < cnt; i += 512u) {
+        const uint32_t i2 = i + 256u;
+        const uint32_t ca = __float_as_uint(rp[i]), cb = __float_as_uint(rp[i2]);
+        const float fxa = rp[cap + i], fya = rp[2 * cap + i], xa0 = rp[3 * cap + i], xa1 = rp[4 * cap + i], xa2 = rp[5 * cap + i];
+        const float fxb = rp[cap + i2], fyb = rp[2 * cap + i2], xb0 = rp[3 * cap + i2], xb1 = rp[4 * cap + i2], xb2 = rp[5 * cap + i2];
+        add_record(ca, fxa, fya, xa0, xa1, xa2);
+        add_record(cb, fxb, fyb, xb0, xb1, xb2);
     }
-    for (; i < cnt; i += 256u) add_record(__float_as_uint(rp[i]), rp[cap + i], rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i], rp[5 * cap + i]);
+    if (i < cnt) add_record(__float_as_uint(rp[i]), rp[cap + i], rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i], rp[5 * cap + i]);
     __syncthreads();
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
-        const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
-#if TB_PLANAR
-        long long q = s_tile[(c % 3) * (TB_EDGE * TB_EDGE) + row * TB_EDGE + c / 3];
-#else
-        long long q = s_tile[k];
-#pragma unroll
-        for (int cp = 1; cp < TB_COPIES; ++cp) q += s_tile[cp * TB_EDGE * TB_EDGE * 3 + k];
-#endif
+        const long long q = s_tile[k];
         if (q == 0ll) continue;
+        const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
         const int y = by * 32 + row, xq = bx * 96 + c;
         if (y >= R || xq >= R * 3) continue;
-        float* o = dtex + ((size_t)(face * R + y) * R) * 3 + xq;
-        // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles; the 31x31 interior is this
-        // workgroup's alone (K7's direct atomics finished before this kernel started): plain read-modify-write
-        if (TB_PLAIN_RMW && row >= 1 && row <= 31 && c >= 3 && c < 96) *o += (float)q * down;
-        else unsafeAtomicAdd(o, (float)q * down);
+        // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles, hence atomics
+        unsafeAtomicAdd(dtex + ((size_t)(face * R + y) * R) * 3 + xq, (float)q * down);
     }
     if (tid == 0) {
         tb.cursor[b] = 0u;

@@ -98,13 +98,17 @@ class GradBucket:
 class ViewPipeline:
     """The views of one multi-view step on `depth` HIP streams (default 2), round-robin.
 
-    Inside one view every kernel depends on the one before it, and the two big ones end in a long tail (the 16 longest
-    tiles are ~40 % of K7's duration, ~65 % of K6's, with most CUs idle), while K1..K5 are nine small launches that never
-    fill the chip.  Views are independent of each other, so view i+1's forward is issued on the other stream and fills the
-    holes of view i's backward.  Ordering that remains:
+    Inside one view every kernel depends on the one before it: K1..K5 are fourteen small launches that never fill the chip,
+    K6 and K7 end in a tail, and the host waits once per forward for the instance count.  Views are independent of each other,
+    so view i+1 is issued on another stream and fills the holes of view i (C3 on one MI355X: 621 -> 735 views/s with three
+    streams; K7 itself leaves no room on a CU it occupies, so the gain is the small kernels and the tails).  Ordering that
+    remains:
 
-    * backward(i+1) waits for backward(i): K8 adds into the shared gradient sink with plain read-modify-writes (the texture
-      gradient uses atomics and would not need it);
+    * K8 of view i+1 waits for the whole backward of view i (`order="accumulate"`, the default with a GradBucket sink): K8
+      adds into the shared gradient sink with plain read-modify-writes; K7 and the texture-gradient reduce only use atomics
+      and per-stream scratch and run unordered.  Everything autograd does downstream of the rasterizer node (AccumulateGrad
+      of gradients that are not in the sink) is issued after that K8 on the same stream, hence ordered too; gradient paths
+      that bypass the rasterizer are the caller's to order (`order="backward"` serialises whole backwards);
     * a stream runs its own views in order, so per-stream scratch (moment accumulators, texture bins: keyed by stream in
       texgs.rasterizer) is never shared by two views in flight;
     * the caller's stream is joined before (parameters, zeroed sinks) and after (all-reduce, optimizer).
