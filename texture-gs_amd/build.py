@@ -21,7 +21,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.
 UNITS = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render.hip": ["-munsafe-fp-atomics", "-ffp-contract=fast"],
+    # -fno-slp-vectorize: the SLP vectoriser pairs fp32 ops into v_pk_* (packed fp32); in K6 / K7 the register-pair shuffling
+    # (v_mov) that feeds them costs more issue slots than the packing saves and 9-14 VGPRs: K6 289 -> 265 us, K7 820 -> 772 us
+    "render.hip": ["-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize"],
     "loss.hip": [],
     "selftest.hip": [],
     "uvnet.hip": [],
