@@ -100,7 +100,7 @@ class ViewPipeline:
 
     Inside one view every kernel depends on the one before it: K1..K5 are fourteen small launches that never fill the chip,
     K6 and K7 end in a tail, and the host waits once per forward for the instance count.  Views are independent of each other,
-    so view i+1 is issued on another stream and fills the holes of view i (C3 on one MI355X: 621 -> 735 views/s with three
+    so view i+1 is issued on another stream and fills the holes of view i (C3 on one MI355X: 656 -> 772 views/s with three
     streams; K7 itself leaves no room on a CU it occupies, so the gain is the small kernels and the tails).  Ordering that
     remains:
 
