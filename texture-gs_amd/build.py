@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, os.environ.get("TEXGS_OBJ_DIR", "build"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+          "-I" + CSRC, "-Wall"]
 UNITS = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
