@@ -15,6 +15,8 @@ no source) travel to the GPU box, the reference does not.
                configs/texture_gaussian3d.yaml, plus a depth term), values AND autograd gradients w.r.t. norm / depth
   norm_from_depth.npz  losses/norm_reg_loss.py norm_from_depth (pseudo-normal + mask of a depth map) and norm_reg_loss with its
                autograd gradient w.r.t. the predicted normal, two cameras from utils/graphics.py getWorld2View2
+  host_terms.npz  losses/zero_one_loss.py zero_one_loss (value + autograd gradient, both clamps hit) and
+               TextureGaussian3D.depth2world (models/texture_gaussian3d.py:299-309) on a random depth map
   uvnet.npz    models/modules/uv_net.py UVNet with models/modules/utils.py build_nn_network (the `use_tcnn: False` path; utils.py
                imports tinycudann at top level, so the class / function definitions are taken from the two sources with `ast`
                and RUN): weights, embedding, 64 points, uvs, and the Jacobian exactly as
@@ -183,6 +185,43 @@ def norm_from_depth():
     np.savez_compressed(os.path.join(HERE, "norm_from_depth.npz"), **out)
 
 
+def host_terms():
+    """losses/zero_one_loss.py zero_one_loss (importable) and TextureGaussian3D.depth2world (models/texture_gaussian3d.py:299-309,
+    taken from the source with `ast` and RUN: the module itself needs tinycudann / cv2), camera matrices from utils/graphics.py."""
+    import ast
+    sys.path.insert(0, REF)
+    from losses.zero_one_loss import zero_one_loss
+    from utils.graphics import getWorld2View2, getProjectionMatrix
+    g = torch.Generator().manual_seed(9)
+    out = {}
+    val = torch.rand(500, 1, generator=g)
+    val[:20] = 0.0; val[20:40] = 1.0; val[40:60] = 1e-4                      # both clamps
+    v = val.clone().requires_grad_(True)
+    loss = zero_one_loss(v)
+    loss.backward()
+    out.update(zo_value=val.numpy(), zo_loss=float(loss), zo_grad=v.grad.numpy())
+    src = open(os.path.join(REF, "models", "texture_gaussian3d.py")).read()
+    tree = ast.parse(src)
+    funcs = [n for cls in tree.body if isinstance(cls, ast.ClassDef) and cls.name == "TextureGaussian3D"
+             for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "depth2world"]
+    assert len(funcs) == 1
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), "<reference depth2world>", "exec"), ns)
+    rng = np.random.RandomState(3)
+    q, _ = np.linalg.qr(rng.randn(3, 3))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    znear, zfar, fovx, fovy = 0.01, 100.0, 0.8, 0.6
+    wvt = torch.tensor(getWorld2View2(q, rng.randn(3), np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+    proj = getProjectionMatrix(znear=znear, zfar=zfar, fovX=fovx, fovY=fovy).transpose(0, 1)
+    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+    depth = 2.0 + torch.rand(17, 23, generator=g)
+    xyz = ns["depth2world"](None, depth, full, zfar, znear)
+    out.update(d2w_depth=depth.numpy(), d2w_full_proj=full.numpy(), d2w_zfar=zfar, d2w_znear=znear, d2w_xyz=xyz.numpy(),
+               d2w_wvt=wvt.numpy(), d2w_fov=np.array([fovx, fovy]))
+    np.savez_compressed(os.path.join(HERE, "host_terms.npz"), **out)
+
+
 def uvnet():
     import ast
     from torch import nn
@@ -270,7 +309,7 @@ def op_small():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "norm_from_depth", "uvnet", "texture_io", "op_small"]
+    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "norm_from_depth", "host_terms", "uvnet", "texture_io", "op_small"]
     for name in which:
         globals()[name]()
     print("golden fixtures written to", HERE)

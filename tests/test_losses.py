@@ -208,3 +208,33 @@ def test_hip_norm_from_depth_full_size_vs_restatement(lib_built):
     Hh.report("norm_from_depth/800x800_vs_fp64_restatement", mask_mismatch_frac=mism, normal_abs_p999_valid=p999,
               normal_abs_max_valid=float(e.max()) if e.numel() else 0.0, valid_frac=float(rm.mean()))
     assert mism < 0.01 and p999 < 1e-2
+
+
+# ---- host-side terms next to the operator, pinned to the reference's own functions (tests/golden/host_terms.npz)
+HT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_terms.npz")
+
+
+def test_zero_one_loss_matches_reference():
+    from texgs.losses import zero_one_loss
+    d = np.load(HT)
+    v = torch.tensor(d["zo_value"]).requires_grad_(True)
+    loss = zero_one_loss(v)
+    loss.backward()
+    assert abs(float(loss) - float(d["zo_loss"])) < 1e-6
+    assert np.allclose(v.grad.numpy(), d["zo_grad"], rtol=1e-6, atol=1e-9)
+
+
+def test_depth2world_matches_reference():
+    from texgs.losses import depth2world
+    d = np.load(HT)
+    xyz = depth2world(torch.tensor(d["d2w_depth"]), torch.tensor(d["d2w_full_proj"]), float(d["d2w_zfar"]), float(d["d2w_znear"]))
+    assert xyz.shape == (17, 23, 3)
+    assert float(np.abs(xyz.numpy() - d["d2w_xyz"]).max()) < 2e-5
+    # and it inverts the projection: points at view depth d along each pixel's ray project back onto the pixel grid
+    full = torch.tensor(d["d2w_full_proj"]).double()
+    p = torch.cat([xyz.double().reshape(-1, 3), torch.ones(17 * 23, 1, dtype=torch.float64)], dim=1) @ full
+    ndc = p[:, :2] / p[:, 3:4]
+    gx = ((torch.arange(23, dtype=torch.float64) * 2 + 1) / 23 - 1).repeat(17)
+    gy = ((torch.arange(17, dtype=torch.float64) * 2 + 1) / 17 - 1).repeat_interleave(23)
+    assert float((ndc[:, 0] - gx).abs().max()) < 1e-4 and float((ndc[:, 1] - gy).abs().max()) < 1e-4
+    assert float((p[:, 3] - torch.tensor(d["d2w_depth"]).double().reshape(-1)).abs().max()) < 1e-4

@@ -142,3 +142,29 @@ def norm_reg_loss(norm, depth, world_view_transform, tanfovx, tanfovy, gt_alpha,
     pseudo-normal of the rendered (detached) depth, masked by gt_alpha * validity; differentiable w.r.t. `norm`."""
     norm2, mask = norm_from_depth(depth, world_view_transform, tanfovx, tanfovy, threshold)
     return geom_losses(norm=norm, gt_norm=norm2, mask=gt_alpha * mask, lambda_norm=1.0)
+
+
+def zero_one_loss(value, epsilon: float = 1e-3):
+    """losses/zero_one_loss.py:3-7 (`lambda_opacity_reg`, models/texture_gaussian3d.py:370-373): mean(log v + log(1 - v)) of
+    the clamped opacities -- a regulariser on the opacity PARAMETERS, not on the operator's outputs, so it stays plain torch
+    (one elementwise pass over N values; autograd gives the gradient)."""
+    val = torch.clamp(value, epsilon, 1.0 - epsilon)
+    return torch.mean(torch.log(val) + torch.log(1.0 - val))
+
+
+def depth2world(depth, full_proj_transform, zfar: float, znear: float):
+    """World-space points [H,W,3] of a depth map [H,W] (the operator's depth output, detached and squeezed:
+    models/texture_gaussian3d.py:299-309, used by the inverse-UV term at :394): clip-space point
+    (ndc_x d, ndc_y d, zfar d / (zfar - znear) - zfar znear / (zfar - znear), d) times the inverse of the reference's
+    row-vector full projection.  Host-side torch on whatever device `depth` lives on (one 4x4 inverse + one [HW,4]x[4,4])."""
+    if depth.dim() != 2:
+        raise ValueError(f"depth must be [H,W], got {tuple(depth.shape)}")
+    H, W = depth.shape
+    dev, dt = depth.device, depth.dtype
+    ndc_x = (torch.arange(W, device=dev, dtype=dt) * 2 + 1) / W - 1.0
+    ndc_y = (torch.arange(H, device=dev, dtype=dt) * 2 + 1) / H - 1.0
+    gy, gx = torch.meshgrid(ndc_y, ndc_x, indexing="ij")
+    z = zfar * depth / (zfar - znear) - zfar * znear / (zfar - znear)
+    clip = torch.stack([gx * depth, gy * depth, z, depth], dim=-1).reshape(-1, 4)
+    world = clip @ torch.linalg.inv(full_proj_transform.to(device=dev, dtype=dt))
+    return world[:, :3].reshape(H, W, 3)
