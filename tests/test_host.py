@@ -164,3 +164,116 @@ def test_grad_bucket_replicas_and_serial_pipeline():
     assert order == [("f", 3), ("b", 30), ("f", 1), ("b", 10), ("f", 2), ("b", 20)]
     with pytest.raises(ValueError):
         ViewPipeline("cpu", depth=0)
+
+
+def test_view_pipeline_ordering_with_recorded_streams(monkeypatch):
+    """ViewPipeline's stream protocol without a GPU: torch.cuda's Stream / Event / stream() / current_stream() are replaced by
+    recorders, and the sequence of waits the pipeline issues is checked for each ordering mode."""
+    import contextlib
+    import texgs.multiview as MV
+    log = []
+
+    class FakeEvent:
+        n = 0
+
+        def __init__(self):
+            FakeEvent.n += 1
+            self.id = FakeEvent.n
+
+        def record(self, stream):
+            log.append(("record", stream.name, self.id))
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_stream(self, other):
+            log.append(("wait_stream", self.name, other.name))
+
+        def wait_event(self, ev):
+            log.append(("wait_event", self.name, ev.id))
+
+    main = FakeStream("main")
+    current = [main]
+
+    @contextlib.contextmanager
+    def fake_stream_ctx(s):
+        current.append(s)
+        try:
+            yield
+        finally:
+            current.pop()
+    monkeypatch.setattr(MV.torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(MV.torch.cuda, "stream", fake_stream_ctx)
+    monkeypatch.setattr(MV.torch.cuda, "current_stream", lambda dev=None: current[-1])
+
+    def make(depth):
+        p = MV.ViewPipeline.__new__(MV.ViewPipeline)
+        p.device = torch.device("cpu")
+        p.streams = [FakeStream(f"s{k}") for k in range(depth)]
+        return p
+
+    class Sink:                                 # the part of GradBucket the pipeline touches
+        def __init__(self):
+            self.before_accumulate, self.selected, self.folded = None, [], 0
+
+        def select(self, k):
+            self.selected.append(k)
+
+        def fold(self):
+            self.folded += 1
+
+    def run(order, depth=2, nviews=4, sink=True):
+        log.clear()
+        FakeEvent.n = 0
+        snk = Sink() if sink else None
+
+        def fwd(v):
+            log.append(("fwd", current[-1].name, v))
+            return v
+
+        def bwd(v):
+            log.append(("bwd_render", current[-1].name, v))
+            if snk is not None and snk.before_accumulate is not None:
+                snk.before_accumulate()             # what the rasterizer's backward does between K7 + reduce and K8
+            log.append(("bwd_accumulate", current[-1].name, v))
+        res = make(depth).run(range(nviews), fwd, bwd, sink=snk, order=order)
+        assert res == list(range(nviews))
+        return list(log), snk
+
+    # accumulate: view i's K8 waits for the event recorded after view i-1's whole backward; nothing else is ordered
+    lg, snk = run("accumulate")
+    assert lg[:2] == [("wait_stream", "s0", "main"), ("wait_stream", "s1", "main")]
+    assert lg[-2:] == [("wait_stream", "main", "s0"), ("wait_stream", "main", "s1")]
+    assert snk.before_accumulate is None and snk.folded == 0 and snk.selected == []
+    body = lg[2:-2]
+    for v in range(4):
+        s = f"s{v % 2}"
+        i = body.index(("fwd", s, v))
+        assert body[i + 1] == ("bwd_render", s, v)
+        if v == 0:
+            assert body[i + 2] == ("bwd_accumulate", s, 0) and body[i + 3] == ("record", s, 1)
+        else:
+            assert body[i + 2] == ("wait_event", s, v)              # event v was recorded after backward v-1
+            assert body[i + 3] == ("bwd_accumulate", s, v) and body[i + 4] == ("record", s, v + 1)
+            assert body.index(("record", f"s{(v - 1) % 2}", v)) < i + 2
+    # backward: the wait comes before the whole backward
+    lg, _ = run("backward")
+    body = lg[2:-2]
+    for v in range(1, 4):
+        s = f"s{v % 2}"
+        i = body.index(("bwd_render", s, v))
+        assert body[i - 1] == ("wait_event", s, v)
+    # none: no event waits at all, one replica per stream, folded once at the end
+    lg, snk = run("none", depth=3, nviews=5)
+    assert not [e for e in lg if e[0] == "wait_event"]
+    assert snk.selected == [0, 1, 2, 0, 1] and snk.folded == 1
+    # without a sink every mode degrades to whole-backward ordering
+    lg, _ = run("accumulate", sink=False)
+    assert [e for e in lg if e[0] == "wait_event"] == [("wait_event", "s1", 1), ("wait_event", "s0", 2), ("wait_event", "s1", 3)]
+    # an exception inside a view still joins the streams and clears the hook
+    snk = Sink()
+    log.clear()
+    with pytest.raises(RuntimeError):
+        make(2).run(range(3), lambda v: v, lambda v: (_ for _ in ()).throw(RuntimeError("boom")), sink=snk, order="accumulate")
+    assert snk.before_accumulate is None and log[-2:] == [("wait_stream", "main", "s0"), ("wait_stream", "main", "s1")]
