@@ -23,9 +23,6 @@ namespace {
 #define TG_WAVES_PER_WG 1          // 1: one workgroup per 8x8 block (finest dispatch; K7 keeps 11 waves/CU by LDS); 4: one per tile
 #endif
 #define TG_WG_THREADS (64 * TG_WAVES_PER_WG)
-#ifndef CUBE_HW
-#define CUBE_HW 0
-#endif
 
 struct __attribute__((packed, aligned(4))) Texel3 { float x, y, z; };   // one global_load_dwordx3 per tap
 __device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, int off) {
@@ -45,18 +42,6 @@ struct CubeTap {
 
 __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, int R) {
     CubeTap t;
-#if CUBE_HW
-    // the hardware's cubemap helpers (same GL face convention; ties between |components| go to z, then y -- the software path
-    // below prefers x, then y)
-    t.face = (int)__builtin_amdgcn_cubeid(u0, u1, u2);
-    t.axis = t.face >> 1;
-    t.sm = (t.face & 1) ? -1.f : 1.f;
-    t.su = (t.axis == 0) ? -t.sm : ((t.axis == 1) ? 1.f : t.sm);
-    t.sv = (t.axis == 1) ? t.sm : -1.f;
-    t.sc = __builtin_amdgcn_cubesc(u0, u1, u2); t.tc = __builtin_amdgcn_cubetc(u0, u1, u2);
-    const float ma = fmaxf(0.5f * fabsf(__builtin_amdgcn_cubema(u0, u1, u2)), TG_MA_MIN);
-    t.rma = __builtin_amdgcn_rcpf(ma);
-#else
     const float a0 = fabsf(u0), a1 = fabsf(u1), a2 = fabsf(u2);
     float m, ua, ub;
     if (a0 >= a1 && a0 >= a2) { t.axis = 0; m = u0; t.sm = (u0 >= 0.f) ? 1.f : -1.f; ua = u2; t.su = -t.sm; ub = u1; t.sv = -1.f; }
@@ -66,7 +51,6 @@ __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, in
     const float ma = fmaxf(fabsf(m), TG_MA_MIN);
     t.rma = __builtin_amdgcn_rcpf(ma);
     t.sc = t.su * ua; t.tc = t.sv * ub;
-#endif
     const float halfR = 0.5f * (float)R;
     t.h = halfR * t.rma;
     const float col = (t.sc * t.rma + 1.0f) * halfR - 0.5f;
