@@ -110,8 +110,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  TEXGS_DIST_BACKEND=gloo is the single-GPU rehearsal of the N>1 path (tests): the ranks then share the
+    # visible device(s) round-robin and the bucket is reduced through host memory (RCCL refuses two ranks on one device).
+    backend = os.environ.get("TEXGS_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     force_dist = os.environ.get("TEXGS_FORCE_DIST") == "1" and "RANK" in os.environ   # 1-rank RCCL smoke of the N>1 code path
     if world > 1 or force_dist:
@@ -119,7 +123,10 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from texgs import synth, _lib
     from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, forward_raw, backward_raw
@@ -225,7 +232,7 @@ def main():
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     total_views = args.steps * args.views_per_step * world
@@ -346,7 +353,8 @@ def main():
                        "views_per_step_per_gpu": args.views_per_step, "global_views_per_step": args.views_per_step * world,
                        "num_rendered_D": s.D, "D_eff": D_eff, "parallelism": f"views sharded dp{world}",
                        "view_pipeline": f"{args.streams} HIP streams, order={args.order}" if args.streams > 1 else "serial",
-                       "grad_allreduce": "RCCL SUM of one flat f32 bucket per step" if world > 1 else "none (1 GPU)"},
+                       "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal)")
+                                          + " SUM of one flat f32 bucket per step") if world > 1 else "none (1 GPU)"},
             "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
             "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4),
                                         "source": "torch.cuda.Event per step on the op's stream, this rank"},

@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 8
+#define TEXGS_ABI_VERSION 9
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
-#define TEXGS_REC_FLOATS 32    /* per-Gaussian packed record: 128 B = one cache line                  */
+#define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
+#define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
 #define TEXGS_ACC_FLOATS 32    /* per-Gaussian moment accumulators of the backward: one 128-byte line  */
 
 /* Per-call configuration = GaussianRasterizationSettings (render/uv_tex_render.py:25-38). */
@@ -66,7 +67,9 @@ typedef struct TexGSInputs {
 
 /* Per-Gaussian state written by texgs_preprocess_forward (K1) and texgs_read_num_rendered (K2). */
 typedef struct TexGSGeom {
-    float*    rec;             /* f32[N,32]: xy(2) conic(-a/2,-b,-c/2) opacity g(2) | G(6) phi(3) viewdep(3) depth normal(3) | rcull thr */
+    float*    rec_test;        /* f32[N,8]:  xy(2) conic(-a/2,-b,-c/2) opacity rcull thr -- read for EVERY (8x8 block, instance) pair */
+    float*    rec_shade;       /* f32[N,20]: g(2) G(6) | phi(3) viewdep(3) | depth normal(3) pad(2) -- read only for instances
+                                  that can reach alpha >= 1/255 somewhere in the block (about a third of them)            */
     float*    depth;           /* f32[N] view-space z = the depth sort key (its bit pattern); 0xFFFFFFFF for culled Gaussians */
     int32_t*  radii;           /* i32[N] screen radius in px; 0 = culled (operator output `radii`)     */
     uint32_t* rect;            /* u32[N,2]: (minx | miny<<16), (maxx | maxy<<16) tile rectangle        */
@@ -99,6 +102,16 @@ typedef struct TexGSImage {
     uint32_t* n_contrib;       /* u32[H,W] 1-based position of the last contributor in the tile list   */
 } TexGSImage;
 
+#define TEXGS_ACC_MEANS3D 1
+#define TEXGS_ACC_MEANS2D 2
+#define TEXGS_ACC_SHS 4
+#define TEXGS_ACC_OPACITIES 8
+#define TEXGS_ACC_SCALES 16
+#define TEXGS_ACC_ROTATIONS 32
+#define TEXGS_ACC_UVS 64
+#define TEXGS_ACC_COLOR_OFFSET 128
+#define TEXGS_ACC_ALL 255
+
 /* Backward: upstream grads in, input grads out.  NULL dL_dout pointers mean "zero". */
 typedef struct TexGSGrads {
     const float* dL_dcolor;    /* f32[3,H,W] or NULL */
@@ -116,22 +129,30 @@ typedef struct TexGSGrads {
     float* dL_duvs;            /* f32[N,3]                                                             */
     float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
     float* dL_dcolor_offset;   /* f32[N,3] or NULL                                                     */
-    float*    tex_bins;        /* texture-gradient record lists, f32[texgs_tex_bin_count(R) * 6 * tex_bin_cap], or NULL.
+    float*    tex_bins;        /* texture-gradient record POOL, f32[tex_pool_chunks * TEXGS_TEXBIN_CHUNK_FLOATS], or NULL.
                                   The texture is cut into 32x32-texel blocks ("bins", 6 * ceil(R/32)^2 of them).  K7 appends
-                                  one 24-byte record {cell, fx, fy, dL/dtexel-colour rgb} per bilinear footprint to the
-                                  list of the bin the footprint is anchored in (plain coalesced stores, plane-major
-                                  [bin][field][slot]); the reduce kernel at the end of texgs_backward sums each list in
-                                  LDS and adds every texel to dL_dtexture once.  NULL (or cap 0) = fp32 atomics straight
-                                  into dL_dtexture (~20 G requests/s memory-side: 0.7 ms per C3 view).  Contents need no
-                                  initialisation.                                                                  */
-    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: list lengths, ALL-ZERO on entry and all-zero again on
-                                  return (the reduce clears what it read).  Word [count] receives atomicMax(list length)
-                                  of every list that overflowed tex_bin_cap (never cleared by the library: the caller
-                                  sizes tex_bin_cap from it); word [count+1] is per-call scratch (zero on entry/return). */
-    uint32_t  tex_bin_cap;     /* slots per bin.  A full bin is not an error: the excess footprints fall back to atomics. */
-    int32_t accumulate;        /* 0: K8 overwrites dL_dmeans3D..dL_duvs (and dL_dcolor_offset); 1: it ADDS into them
-                                  (fused gradient accumulation of a multi-view step; culled Gaussians write
-                                  nothing).  dL_dtexture is always accumulated into.                          */
+                                  one 20-byte record {fx | cell x, fy | cell y, dL/dtexel-colour rgb} per bilinear footprint
+                                  to the list of the bin the footprint is anchored in; a list is a chain of fixed-size chunks
+                                  (512 records, plane-major [5][512]) taken from this pool with one atomic counter, so the
+                                  pool holds what a view actually produces (~0.4 GB at C3) instead of a fixed capacity per
+                                  bin.  The reduce kernel at the end of texgs_backward_render sums each list in LDS and adds
+                                  every texel to dL_dtexture once.  NULL (or 0 chunks) = fp32 atomics straight into
+                                  dL_dtexture (~20 G requests/s memory-side: 0.7 ms per C3 view).  Contents need no
+                                  initialisation.  The 5 low mantissa bits of fx / fy carry the cell (fx, fy keep 18 bits). */
+    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 4]: list lengths, ALL-ZERO on entry and all-zero again on
+                                  return (the reduce clears what it read).  Word [count] receives max(chunks a call wanted)
+                                  (never cleared by the library: the caller sizes the pool from it); [count+1] = bits of
+                                  max |dL/dpixel colour| of the call in flight, [count+2] = pool head of the call in flight
+                                  (both zero on entry and on return); [count+3] = sticky error flag (0 = ok).             */
+    uint32_t* tex_bin_table;   /* u32[texgs_tex_bin_count(R) * tex_bin_slots]: chunk id (1-based) of the k-th chunk of every
+                                  list; ALL-ZERO on entry and all-zero again on return.                                   */
+    uint32_t  tex_pool_chunks; /* chunks in the pool.  An exhausted pool is not an error: the excess footprints fall back
+                                  to atomics (and word [count] tells the caller how many chunks the call wanted).         */
+    uint32_t  tex_bin_slots;   /* chunk-table entries per bin; footprints beyond slots * 512 records of one bin fall back
+                                  to atomics                                                                              */
+    int32_t accumulate;        /* bit mask (TEXGS_ACC_*): K8 ADDS into the per-Gaussian outputs whose bit is set (fused gradient
+                                  accumulation of a multi-view step, or straight into a leaf's existing .grad; culled Gaussians
+                                  write nothing there) and overwrites the others.  dL_dtexture is always accumulated into.   */
 } TexGSGrads;
 
 int         texgs_abi_version(void);
@@ -140,6 +161,9 @@ const char* texgs_last_error(void);
 size_t texgs_scan_temp_bytes(int32_t num_gaussians);
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
 size_t texgs_tex_bin_count(int32_t tex_res);
+#define TEXGS_TEXBIN_CHUNK_RECORDS 512
+#define TEXGS_TEXBIN_RECORD_FLOATS 5
+#define TEXGS_TEXBIN_CHUNK_FLOATS (TEXGS_TEXBIN_CHUNK_RECORDS * TEXGS_TEXBIN_RECORD_FLOATS)
 
 /* K1: frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold, depth sort key, and
  * D = sum of tiles_touched (device word).  Replaces the first half of _C.rasterize_gaussians. */

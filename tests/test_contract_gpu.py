@@ -286,32 +286,72 @@ def test_c5_full_size_vs_c_oracle(lib_built):
 
 
 def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
-    """The binned two-pass texture gradient (records -> per-bin LDS reduce) against its own fallbacks: bins too small
-    (most footprints overflow to atomics) and bins disabled (every footprint through atomics).  Same sums."""
+    """The binned two-pass texture gradient (records -> chunk pool -> per-bin LDS reduce) against its own fallbacks: a pool
+    of 4 chunks (most footprints overflow to atomics), one chunk-table slot per bin (everything beyond 512 records of a bin
+    overflows), and bins disabled (every footprint through atomics).  Same sums; cursors / tables left clean."""
     from texgs import rasterizer as RZ
     dev = torch.device("cuda:0")
-    scene = synth.make_scene(3000, 96, seed=12, scale_mean=0.03)       # R = 96: 3x3 bins per face, last column partial? no: 96 = 3*32
+    scene = synth.make_scene(3000, 96, seed=12, scale_mean=0.03)       # R = 96: 3x3 bins per face
     scene2 = synth.make_scene(3000, 80, seed=12, scale_mean=0.03)      # R = 80: partial bins at the right / bottom edge
     cam = synth.fibonacci_cameras(4, 240, 176)[3]
     target, nhat = synth.make_targets(176, 240, seed=4)
+    saved = (RZ.USE_TEX_BINS, RZ.TEX_POOL_CHUNKS, RZ.TEX_BIN_SLOTS)
     for sc in (scene, scene2):
         res = {}
-        for mode, (use, cap) in dict(bins=(True, 0), tiny=(True, 5), off=(False, 0)).items():
-            RZ.USE_TEX_BINS, RZ.TEX_BIN_CAP = use, cap
-            RZ._TEX_BINS.clear()
+        for mode, (use, pool, slots) in dict(bins=(True, 0, 128), tinypool=(True, 4, 128), oneslot=(True, 0, 1),
+                                             off=(False, 0, 128)).items():
+            RZ.USE_TEX_BINS, RZ.TEX_POOL_CHUNKS, RZ.TEX_BIN_SLOTS = use, pool, slots
+            RZ.release_scratch()
             try:
                 _, g = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)
-                _, g2 = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)   # cursors were left clean
+                _, g2 = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)   # cursors / tables were left clean
+                if use:
+                    torch.cuda.synchronize()
+                    (sc_,) = RZ._SCRATCH.values()
+                    nb = sc_.bins.nbins
+                    assert int(sc_.bins.cursor[:nb].abs().sum()) == 0 and int(sc_.bins.table.abs().sum()) == 0, mode
+                    assert int(sc_.bins.cursor[nb + 1]) == 0 and int(sc_.bins.cursor[nb + 2]) == 0 and int(sc_.bins.cursor[nb + 3]) == 0, mode
+                    if mode == "tinypool":
+                        assert int(sc_.bins.cursor[nb]) > 4      # the call wanted more chunks than the pool had
             finally:
-                RZ.USE_TEX_BINS, RZ.TEX_BIN_CAP = True, 0
-                RZ._TEX_BINS.clear()
+                RZ.USE_TEX_BINS, RZ.TEX_POOL_CHUNKS, RZ.TEX_BIN_SLOTS = saved
+                RZ.release_scratch()
             assert Hh.rel_err(g2["texture"], g["texture"]) < 1e-5, mode
             res[mode] = g
-        for mode in ("tiny", "off"):
+        for mode in ("tinypool", "oneslot", "off"):
             for name in ("texture", "uvs", "means3D"):
                 r = Hh.rel_err(res[mode][name], res["bins"][name])
                 Hh.report(f"texture_bins/{mode}_vs_bins/R{sc.texture.shape[1]}/{name}", rel_l2=r)
                 assert r < 1e-5, (mode, name, r)
+
+
+def test_texture_gradient_scale_is_per_call(lib_built):
+    """The reduce kernel's fixed-point scale is the max |dL/dpixel| of THE CALL (K7 leaves it in a scratch word, K8 clears
+    it): a backward with 1e6 x larger upstream gradients on the same stream / scratch must not coarsen the next one."""
+    from texgs import rasterizer as RZ
+    from texgs.rasterizer import GaussianRasterizationSettings, forward_raw, backward_raw
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(2500, 64, seed=31, scale_mean=0.03)
+    cam = synth.fibonacci_cameras(4, 208, 160)[2]
+    st = Hh.settings_for(cam, 2, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings)
+    t = lambda x: x.to(dev)
+    g = torch.Generator().manual_seed(5)
+    dimg = (torch.randn(3, 160, 208, generator=g) * 1e-5).to(dev)
+
+    def tex_grad(scale):
+        _, s = forward_raw(st, t(scene.means3D), t(scene.shs), t(scene.opacities), t(scene.scales), t(scene.rotations),
+                           t(scene.uvs), t(scene.gradient_uvs), t(scene.texture))
+        return backward_raw(s, dimg * scale, None, None, None)[7]
+    RZ.release_scratch()
+    ref = tex_grad(1.0).clone()
+    big = tex_grad(1e6)
+    again = tex_grad(1.0)
+    torch.cuda.synchronize()
+    assert Hh.rel_err(big, ref * 1e6) < 1e-5
+    # 2^-42 of the image-wide bound per record: with the scale of the 1e6 x call left behind, this would be off by ~1e-7 * 1e6
+    r = Hh.rel_err(again, ref)
+    Hh.report("texture_bins/scale_per_call", rel_l2_after_big_call=r)
+    assert r < 1e-6, r
 
 
 def test_retexture_path_from_cross_image(lib_built):

@@ -66,6 +66,10 @@ int validate_frame(const TexGSFrame* f) {
     if (!f) return fail_msg("frame is NULL");
     if (f->image_height <= 0 || f->image_width <= 0) return fail_msg("image size must be positive");
     if (f->image_width > 65535 * TEXGS_TILE || f->image_height > 65535 * TEXGS_TILE) return fail_msg("image too large");
+    {   // tile ids are sorted in at most three 8-bit digits and live in the high word of a 64-bit key
+        const long long tx = (f->image_width + TEXGS_TILE - 1) / TEXGS_TILE, ty = (f->image_height + TEXGS_TILE - 1) / TEXGS_TILE;
+        if (tx * ty > (1ll << 24)) return fail_msg("image too large: more than 2^24 tiles");
+    }
     if (f->sh_degree < 0 || f->sh_degree > 3) return fail_msg("sh_degree must be in [0,3]");
     if (f->num_gaussians < 0) return fail_msg("num_gaussians < 0");
     if (f->tex_res <= 0) return fail_msg("tex_res must be positive");
@@ -112,16 +116,22 @@ static int depth_sort_scan(const TexGSFrame* frame, TexGSGeom* geom, hipStream_t
 
 namespace {
 struct Readback { uint32_t* host = nullptr; hipEvent_t ev = nullptr; };
-thread_local Readback g_rb;       // one pinned word + event per host thread (the D readback), created on first use
+constexpr int RB_MAX_DEVICES = 64;
+thread_local Readback g_rb_dev[RB_MAX_DEVICES];   // one pinned word + event per (host thread, device): HIP events belong to the
+                                                  // device that was current when they were created
 }
 
-// D = sum of tiles_touched (K1 accumulates it): asynchronous copy into pinned memory, then depth sort + scan are
-// launched, and only then the host waits -- the device stays busy during the one unavoidable device->host sync.
+// D = sum of tiles_touched (K1 accumulates it): asynchronous copy into pinned memory, then K2 -- depth sort + scan, which
+// WRITE geom->offsets and geom->scan_temp -- is launched, and only then the host waits: the device stays busy during the one
+// unavoidable device->host sync.  (So this "read" also runs K2; the name is the lineage's step it replaces.)
 int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream) {
     if (!geom || !host_out) return fail_msg("NULL argument");
     *host_out = 0;
     if (num_gaussians <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RB_MAX_DEVICES) return fail_msg("hipGetDevice failed");
+    Readback& g_rb = g_rb_dev[dev];
     if (!g_rb.host) {
         if (hipHostMalloc((void**)&g_rb.host, 64, hipHostMallocDefault) != hipSuccess) return fail_msg("hipHostMalloc failed");
         if (hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming) != hipSuccess) return fail_msg("hipEventCreate failed");
@@ -187,16 +197,13 @@ int texgs_backward_render(const TexGSFrame* frame, const TexGSInputs* in, const 
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !bin || !img || !grads) return fail_msg("NULL argument");
     if (!grads->acc || !grads->dL_dtexture) return fail_msg("acc / dL_dtexture must be allocated (zero-filled)");
+    if (grads->tex_bin_slots > 2048u) return fail_msg("tex_bin_slots must be <= 2048 (2^20 records per bin: the reduce's fixed-point range)");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     if (bin->num_rendered > 0) {
         { ProfScope p(TEXGS_K_RENDER_BWD, s); launch_render_bwd(c, frame, in, geom, bin, img, grads, s); }
         if (int r = check(frame, s, "render_bwd")) return r;
-        bool reduce = grads->tex_bins && grads->tex_bin_cursor && grads->tex_bin_cap;
-#ifdef TEXGS_EXPERIMENTS
-        if (getenv("TEXGS_SKIP_REDUCE")) reduce = false;       // diagnostics: leave the cursors for inspection
-#endif
-        if (reduce) {
+        if (tex_bins_enabled(c, grads)) {
             { ProfScope p(TEXGS_K_TEXGRAD_REDUCE, s); launch_texgrad_reduce(c, grads, s); }
             if (int r = check(frame, s, "texgrad_reduce")) return r;
         }

@@ -297,8 +297,8 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 //   [0]        zeroed header: 4 x (gtable + total) of the depth passes | 64 bytes: [0] D total
 //   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)])
 // sort_temp (instance level, sized by sort_temp_bytes(capacity, T)):
-//   [0]        zeroed header: 2 x (gtable + total) of the tile passes
-//   then       2 x table, elem_tmp (u64[capacity])
+//   [0]        zeroed header: 3 x (gtable + total) of the tile passes
+//   then       3 x table, elem_tmp (u64[capacity])
 struct GaussScratch {
     uint32_t* tables;       // 4 passes
     uint32_t* total_D;
@@ -344,7 +344,10 @@ size_t scan_temp_bytes(int N) {
          + align256(((n + SC_PER - 1) / SC_PER) * 4 + 256);
 }
 
-inline size_t sort_tables_bytes() { return zero_header_bytes(2, 0) + align256(2 * (size_t)RS_MAX_BLOCKS * 256 * 4); }
+constexpr int TILE_PASSES_MAX = 3;      // tile ids up to 2^24 in digits of at most 8 bits (the count / scatter kernels index 256-entry LDS tables)
+inline size_t sort_tables_bytes() {
+    return zero_header_bytes(TILE_PASSES_MAX, 0) + align256(TILE_PASSES_MAX * (size_t)RS_MAX_BLOCKS * 256 * 4);
+}
 size_t sort_temp_bytes(uint32_t D, uint32_t T) {
     (void)T;
     return sort_tables_bytes() + align256((size_t)(D > 0 ? D : 1) * 8);
@@ -356,7 +359,7 @@ uint32_t* bin_total_ptr(const TexGSGeom* g, int N) { return gauss_scratch(g->sca
 int launch_bin_header(const TexGSGeom* g, int N, hipStream_t s) {
     return (int)hipMemsetAsync(g->scan_temp, 0, gauss_scratch(g->scan_temp, N).header_bytes, s);
 }
-int launch_sort_header(void* sort_temp, hipStream_t s) { return (int)hipMemsetAsync(sort_temp, 0, zero_header_bytes(2, 0), s); }
+int launch_sort_header(void* sort_temp, hipStream_t s) { return (int)hipMemsetAsync(sort_temp, 0, zero_header_bytes(TILE_PASSES_MAX, 0), s); }
 
 // Gaussian level: depth sort (4 passes) + exclusive scan of tiles_touched in rank order.  Needs K1's depth keys
 // (bits of view z; 0xFFFFFFFF for culled) in g->depth.  Independent of D: runs while the host waits for the D readback.
@@ -395,7 +398,9 @@ void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hi
                        g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges));
 }
 
-// Instance level: stable sort by tile (2 passes); the second writes keys_sorted / point_list.
+// Instance level: stable LSD sort by tile id in 1-3 digits of at most 8 bits (two for up to 65 536 tiles); the last pass
+// writes keys_sorted / point_list.  With three passes (more than 65 536 tiles, i.e. images beyond ~16 Mpixel) the middle pass
+// uses keys_unsorted as its output buffer: its K3 contents are then gone after the forward.
 int launch_sort(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStream_t s) {
     const uint32_t D = b->num_rendered;
     if (D == 0) return 0;
@@ -403,27 +408,30 @@ int launch_sort(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStrea
     uint32_t* tbl = reinterpret_cast<uint32_t*>(b->sort_temp);
     uint64_t* tmp = reinterpret_cast<uint64_t*>((char*)b->sort_temp + sort_tables_bytes());
     const int tb = tile_bits((uint32_t)(c.tiles_x * c.tiles_y));
-    const int b0 = (tb + 1) / 2, b1 = tb - b0;            // low digit, high digit (b1 may be 0 when T <= 2)
+    const int npass = (tb + 7) / 8;
+    if (npass > TILE_PASSES_MAX) return (int)hipErrorInvalidValue;       // validate_frame rejects such images first
     uint32_t blocks, per;
     pass_geometry(D, blocks, per);
-    const RadixTables t0 = tables_at(tbl, 0, 2, 0), t1 = tables_at(tbl, 1, 2, 0);
-    if (b1 == 0) {       // one pass: straight to the final arrays
-        hipLaunchKernelGGL(k_radix_count<uint64_t>, dim3(blocks), dim3(RS_THREADS), 0, s, (const uint64_t*)b->keys_unsorted,
-                           (const uint32_t*)nullptr, D, per, 32, (1u << b0) - 1u, t0);
-        hipLaunchKernelGGL((k_radix_scatter<uint64_t, 2>), dim3(blocks), dim3(RS_THREADS), 0, s, (const uint64_t*)b->keys_unsorted,
-                           (const uint32_t*)nullptr, b->keys_sorted, b->point_list, (const uint32_t*)nullptr, D, per, 32,
-                           (1u << b0) - 1u, b0, t0, (const uint32_t*)gs.key_b, (const uint32_t*)gs.val_b);
-    } else {
-        hipLaunchKernelGGL(k_radix_count<uint64_t>, dim3(blocks), dim3(RS_THREADS), 0, s, (const uint64_t*)b->keys_unsorted,
-                           (const uint32_t*)nullptr, D, per, 32, (1u << b0) - 1u, t0);
-        hipLaunchKernelGGL((k_radix_scatter<uint64_t, 1>), dim3(blocks), dim3(RS_THREADS), 0, s, (const uint64_t*)b->keys_unsorted,
-                           (const uint32_t*)nullptr, tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, D, per, 32,
-                           (1u << b0) - 1u, b0, t0, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_radix_count<uint64_t>, dim3(blocks), dim3(RS_THREADS), 0, s, (const uint64_t*)tmp,
-                           (const uint32_t*)nullptr, D, per, 32 + b0, (1u << b1) - 1u, t1);
-        hipLaunchKernelGGL((k_radix_scatter<uint64_t, 2>), dim3(blocks), dim3(RS_THREADS), 0, s, (const uint64_t*)tmp,
-                           (const uint32_t*)nullptr, b->keys_sorted, b->point_list, (const uint32_t*)nullptr, D, per, 32 + b0,
-                           (1u << b1) - 1u, b1, t1, (const uint32_t*)gs.key_b, (const uint32_t*)gs.val_b);
+    const uint64_t* src = b->keys_unsorted;
+    int shift = 32, left = tb;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int bits = (left + (npass - pass) - 1) / (npass - pass);      // even split, low digits first
+        const RadixTables t = tables_at(tbl, pass, TILE_PASSES_MAX, 0);
+        const uint32_t mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(k_radix_count<uint64_t>, dim3(blocks), dim3(RS_THREADS), 0, s, src, (const uint32_t*)nullptr, D, per,
+                           shift, mask, t);
+        if (pass == npass - 1) {
+            hipLaunchKernelGGL((k_radix_scatter<uint64_t, 2>), dim3(blocks), dim3(RS_THREADS), 0, s, src, (const uint32_t*)nullptr,
+                               b->keys_sorted, b->point_list, (const uint32_t*)nullptr, D, per, shift, mask, bits, t,
+                               (const uint32_t*)gs.key_b, (const uint32_t*)gs.val_b);
+        } else {
+            uint64_t* dst = (src == tmp) ? b->keys_unsorted : tmp;
+            hipLaunchKernelGGL((k_radix_scatter<uint64_t, 1>), dim3(blocks), dim3(RS_THREADS), 0, s, src, (const uint32_t*)nullptr, dst,
+                               (uint32_t*)nullptr, (const uint32_t*)nullptr, D, per, shift, mask, bits, t, (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr);
+            src = dst;
+        }
+        shift += bits; left -= bits;
     }
     return (int)hipGetLastError();
 }

@@ -16,7 +16,8 @@
 #define TG_MA_MIN        1e-20f
 #define TG_SH_C0         0.28209479177387814f
 
-// record slots (float index)
+// slots of the per-Gaussian fields whose gradients K8 assembles (float index; K1 stores them split into a test and a
+// shading record, texgs.h TexGSGeom)
 enum {
     R_XY = 0, R_CONIC = 2, R_OP = 5, R_G2 = 6, R_GM = 8, R_PHI = 14, R_VD = 17, R_DEPTH = 20, R_N = 21
 };
@@ -69,6 +70,7 @@ void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s);
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s);
 size_t tex_bin_count(int R);
+bool tex_bins_enabled(const CamConst& c, const TexGSGrads* gr);
 void launch_texgrad_reduce(const CamConst& c, TexGSGrads* gr, hipStream_t s);
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s);

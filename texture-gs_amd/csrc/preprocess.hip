@@ -5,8 +5,8 @@
 // correctly rounded '/' and sqrt, so the C oracle (oracle/texgs_ref.c, same operation order, also built
 // without contraction) reproduces keys / rects / radii bit for bit.
 //
-// One thread per Gaussian, 256 threads (4 wave64) per workgroup.  HBM-bound: reads 92+12K B, writes one
-// 128-B record (= one cache line) + 24 B of SoA state per Gaussian.
+// One thread per Gaussian, 256 threads (4 wave64) per workgroup.  HBM-bound: reads 92+12K B, writes a 32-B test record
+// + an 80-B shading record + 24 B of SoA state per Gaussian.
 #include "common.h"
 
 namespace {
@@ -234,7 +234,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
                  const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ uvs,
                  const float* __restrict__ juv, const float* __restrict__ coff,
-                 float4* __restrict__ rec, float* __restrict__ depth, int32_t* __restrict__ radii,
+                 float4* __restrict__ rec_test, float4* __restrict__ rec_shade, float* __restrict__ depth, int32_t* __restrict__ radii,
                  uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ total_D) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
     __shared__ uint32_t s_tt[TG_BLOCK / 64];
@@ -293,25 +293,26 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
     depth[i] = g.t[2];
     rect[i] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
-    float4* r = rec + (size_t)i * (TEXGS_REC_FLOATS / 4);
+    // The record is split by who reads it (render.hip): the TEST part (32 B) is fetched for every (8x8 block, instance) pair,
+    // the SHADING part (80 B) only for instances that survive the block cull.
     // conic pre-scaled for the blend kernels' falloff exponent: power = ah dx^2 + bh dx dy + ch dy^2 (render.hip gauss_power)
-    r[0] = make_float4(g.xy[0], g.xy[1], -0.5f * g.conic[0], -g.conic[1]);
-    r[1] = make_float4(-0.5f * g.conic[2], opac[i], g.gx, g.gy);
-    r[2] = make_float4(g.G[0], g.G[1], g.G[2], g.G[3]);
-    r[3] = make_float4(g.G[4], g.G[5], uvs[3 * i + 0], uvs[3 * i + 1]);
-    r[4] = make_float4(uvs[3 * i + 2], vd[0], vd[1], vd[2]);
-    r[5] = make_float4(g.t[2], g.n[0], g.n[1], g.n[2]);
-    // spare slots, conservative culling aids for the blend kernels (never change a decision, only skip sure misses):
+    // culling aids (never change a decision, only skip sure misses):
     //   thr   : alpha >= 1/255  <=>  power >= ln(1/(255*opacity)); lowered by a margin far above fp32 rounding
     //   rcull : pixel distance beyond which power < thr for every direction (largest eigenvalue of cov2D)
-    {
-        const float op = opac[i];
-        const float thr = (op > 0.0f) ? (-logf(255.0f * op) - 1e-3f) : 1.0f;          // > 0: nothing can pass
-        const float mid = 0.5f * (g.a + g.c);
-        const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - g.det));
-        const float rcull = (thr < 0.0f) ? (sqrtf(-2.0f * thr * lam) * 1.001f + 0.01f) : -1.0f;
-        r[6] = make_float4(rcull, thr, 0.f, 0.f);
-    }
+    const float op = opac[i];
+    const float thr = (op > 0.0f) ? (-logf(255.0f * op) - 1e-3f) : 1.0f;          // > 0: nothing can pass
+    const float cmid = 0.5f * (g.a + g.c);
+    const float clam = cmid + sqrtf(fmaxf(0.1f, cmid * cmid - g.det));
+    const float rcull = (thr < 0.0f) ? (sqrtf(-2.0f * thr * clam) * 1.001f + 0.01f) : -1.0f;
+    float4* rt = rec_test + (size_t)i * (TEXGS_REC_TEST_FLOATS / 4);
+    rt[0] = make_float4(g.xy[0], g.xy[1], -0.5f * g.conic[0], -g.conic[1]);
+    rt[1] = make_float4(-0.5f * g.conic[2], op, rcull, thr);
+    float4* rs = rec_shade + (size_t)i * (TEXGS_REC_SHADE_FLOATS / 4);
+    rs[0] = make_float4(g.gx, g.gy, g.G[0], g.G[1]);
+    rs[1] = make_float4(g.G[2], g.G[3], g.G[4], g.G[5]);
+    rs[2] = make_float4(uvs[3 * i + 0], uvs[3 * i + 1], uvs[3 * i + 2], vd[0]);
+    rs[3] = make_float4(vd[1], vd[2], g.t[2], g.n[0]);
+    rs[4] = make_float4(g.n[1], g.n[2], 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------ K8
@@ -338,17 +339,17 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
         __syncthreads();
     }
     const bool visible = live && radii[i] > 0;
-    if (live && !visible && !accumulate) {
-        d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
-        d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
-        d_op[i] = 0.f;
-        d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
-        d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
-        d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
-        if (d_coff) d_coff[3 * i] = d_coff[3 * i + 1] = d_coff[3 * i + 2] = 0.f;
+    if (live && !visible) {          // culled: zero rows for the outputs that are written, nothing for those that are added into
+        if (!(accumulate & TEXGS_ACC_MEANS3D)) d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
+        if (!(accumulate & TEXGS_ACC_MEANS2D)) d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
+        if (!(accumulate & TEXGS_ACC_OPACITIES)) d_op[i] = 0.f;
+        if (!(accumulate & TEXGS_ACC_SCALES)) d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
+        if (!(accumulate & TEXGS_ACC_ROTATIONS)) d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
+        if (!(accumulate & TEXGS_ACC_UVS)) d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
+        if (d_coff && !(accumulate & TEXGS_ACC_COLOR_OFFSET)) d_coff[3 * i] = d_coff[3 * i + 1] = d_coff[3 * i + 2] = 0.f;
     }
     if (visible) {
-#define OUT(P, V) do { if (accumulate) (P) += (V); else (P) = (V); } while (0)
+#define OUT(BIT, P, V) do { if (accumulate & (BIT)) (P) += (V); else (P) = (V); } while (0)
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     geo_forward(g, F, C, i, means, scales, rots, juv);
@@ -389,9 +390,9 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     for (int k = 0; k < 9; ++k) dR[k] = 0.f;
 
     // (1,2) pass-through
-    OUT(d_op[i], A[R_OP]);
-    OUT(d_uvs[3 * i + 0], A[R_PHI]); OUT(d_uvs[3 * i + 1], A[R_PHI + 1]); OUT(d_uvs[3 * i + 2], A[R_PHI + 2]);
-    if (d_coff) { OUT(d_coff[3 * i + 0], A[R_VD]); OUT(d_coff[3 * i + 1], A[R_VD + 1]); OUT(d_coff[3 * i + 2], A[R_VD + 2]); }
+    OUT(TEXGS_ACC_OPACITIES, d_op[i], A[R_OP]);
+    OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 0], A[R_PHI]); OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 1], A[R_PHI + 1]); OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 2], A[R_PHI + 2]);
+    if (d_coff) { OUT(TEXGS_ACC_COLOR_OFFSET, d_coff[3 * i + 0], A[R_VD]); OUT(TEXGS_ACC_COLOR_OFFSET, d_coff[3 * i + 1], A[R_VD + 1]); OUT(TEXGS_ACC_COLOR_OFFSET, d_coff[3 * i + 2], A[R_VD + 2]); }
 
     // (3) conic -> cov2D (a,b,c)
     const float dA = A[R_CONIC], dB = A[R_CONIC + 1], dC = A[R_CONIC + 2];
@@ -448,7 +449,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
 
     // (6) mean2D: record slot is dL/d(pixel xy); operator returns dL/d(ndc xy)
     const float dndx = A[R_XY] * 0.5f * (float)C.W, dndy = A[R_XY + 1] * 0.5f * (float)C.H;
-    OUT(d_means2D[3 * i + 0], dndx); OUT(d_means2D[3 * i + 1], dndy); if (!accumulate) d_means2D[3 * i + 2] = 0.f;
+    OUT(TEXGS_ACC_MEANS2D, d_means2D[3 * i + 0], dndx); OUT(TEXGS_ACC_MEANS2D, d_means2D[3 * i + 1], dndy); if (!(accumulate & TEXGS_ACC_MEANS2D)) d_means2D[3 * i + 2] = 0.f;
     {
         const float dhx = dndx * g.pw, dhy = dndy * g.pw;
         const float dhw = -(dndx * g.hx + dndy * g.hy) * g.pw * g.pw;
@@ -523,15 +524,15 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
     // (8) t = [m,1] @ V
 #pragma unroll
     for (int k = 0; k < 3; ++k) dm[k] += dt[0] * F.V[k * 4 + 0] + dt[1] * F.V[k * 4 + 1] + dt[2] * F.V[k * 4 + 2];
-    OUT(d_means[3 * i + 0], dm[0]); OUT(d_means[3 * i + 1], dm[1]); OUT(d_means[3 * i + 2], dm[2]);
-    OUT(d_scales[3 * i + 0], dscale[0]); OUT(d_scales[3 * i + 1], dscale[1]); OUT(d_scales[3 * i + 2], dscale[2]);
+    OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 0], dm[0]); OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 1], dm[1]); OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 2], dm[2]);
+    OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 0], dscale[0]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 1], dscale[1]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 2], dscale[2]);
 
     // (5) R(q) -> q
     const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
-    OUT(d_rots[4 * i + 0], 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]));
-    OUT(d_rots[4 * i + 1], 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]));
-    OUT(d_rots[4 * i + 2], 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]));
-    OUT(d_rots[4 * i + 3], 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]));
+    OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 0], 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]));
+    OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 1], 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]));
+    OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 2], 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]));
+    OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 3], 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]));
 #undef OUT
     }   // visible
     if (d_shs) {            // dL/dSH: zero rows for culled Gaussians / inactive degree, then one coalesced block store
@@ -539,7 +540,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
             if (live) for (int k = 0; k < row; ++k) s_sh[threadIdx.x * row + k] = 0.f;
         }
         __syncthreads();
-        if (accumulate) { for (int k = threadIdx.x; k < count; k += TG_BLOCK) { const float v = s_sh[k]; if (v != 0.f) d_shs[first + k] += v; } }
+        if (accumulate & TEXGS_ACC_SHS) { for (int k = threadIdx.x; k < count; k += TG_BLOCK) { const float v = s_sh[k]; if (v != 0.f) d_shs[first + k] += v; } }
         else            { for (int k = threadIdx.x; k < count; k += TG_BLOCK) d_shs[first + k] = s_sh[k]; }
     }
 }
@@ -561,7 +562,8 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     const size_t lds = (in->shs && c.sh_degree > 0) ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset,
-                       reinterpret_cast<float4*>(g->rec), g->depth, g->radii, reinterpret_cast<uint2*>(g->rect),
+                       reinterpret_cast<float4*>(g->rec_test), reinterpret_cast<float4*>(g->rec_shade), g->depth, g->radii,
+                       reinterpret_cast<uint2*>(g->rect),
                        g->tiles_touched, bin_total_ptr(g, c.N));
 }
 
@@ -574,7 +576,7 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
                        gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate,
-                       (gr->tex_bins && gr->tex_bin_cursor && gr->tex_bin_cap) ? gr->tex_bin_cursor + tex_bin_count(c.R) + 1 : nullptr);
+                       tex_bins_enabled(c, gr) ? gr->tex_bin_cursor + tex_bin_count(c.R) + 1 : nullptr);
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

@@ -1,28 +1,34 @@
 // K6 render forward, K7 render backward, and the texture-gradient bin reduce -- gfx950 (CDNA4), wave64.
 //
-// One wave = one 8x8 pixel block of a 16x16 tile; the waves of a tile share nothing (no block barrier anywhere), so the
-// workgroup size is a pure scheduling choice (TG_WAVES_PER_WG).  Per chunk of 64 depth-sorted instances lane l keeps
-// instance l's record in registers: the per-pixel *sequential* loops (alpha test, transmittance) get the tested Gaussian by
-// v_readlane broadcast; contributing (pixel, Gaussian) pairs are compacted (ballot + mbcnt) into a per-wave LDS list and
-// the *dense* texture work (UV Taylor step, cubemap address, 4 taps, colour / gradients) runs 64 pairs at a time with
-// every lane busy, reading the pair's Gaussian fields from a per-wave LDS copy of the chunk's records.
+// One wave = one 8x8 pixel block of a 16x16 tile = FOUR 4x4 quadrants, one per DPP row of 16 lanes; the waves of a tile
+// share nothing (no block barrier anywhere; one wave per workgroup = finest dispatch).
+//
+// Work flows through three levels, each denser than the one before (SURVEY.md A.4 / A.5 is the contract):
+//   raw batches    64 instances of the tile's depth-sorted list at a time, lane = instance: only the 32-byte TEST record
+//                  (xy, conic, opacity, cull radius / threshold) is fetched, and an exact concave-maximum test decides
+//                  whether the instance can reach alpha >= 1/255 anywhere in the 8x8 block.  Survivors (about a third) are
+//                  queued in depth order.
+//   chunks         64 SURVIVORS at a time, lane = survivor: the 80-byte SHADING record is fetched only now, the chunk is
+//                  laid out as planes in LDS, and the same exact test per 4x4 quadrant builds four per-quadrant lists.
+//   lock-step test every quadrant (16 lanes, lane = pixel) walks ITS OWN list: one iteration tests up to four different
+//                  Gaussians, one per quadrant (a Gaussian covers ~17 of the 64 pixels of a block: one Gaussian per
+//                  iteration ran with 27 % of the lanes).  The tested Gaussian's parameters come from the LDS planes with
+//                  row-broadcast reads, software-prefetched one iteration ahead; transmittance stays in the pixel's lane.
+//   dense phase    contributing (pixel, Gaussian) pairs are compacted (ballot + mbcnt) into a per-wave LDS list and the
+//                  texture work (UV Taylor step, cubemap address, 4 taps, colour / gradients) runs 64 pairs at a time.
 //
 // Texture gradient (K7): every fp32 global atomic on this part executes memory-side at ~20 G requests/s and the ~19 M
-// bilinear footprints of a C3 view cost 0.69 ms that way (profiles/r02_ablation.md).  Instead K7 APPENDS a 24-byte
-// record {cell, fx, fy, dL/dtexel-colour (3)} per footprint with plain coalesced stores to the list of the 32x32-texel
-// texture block ("bin") the footprint is anchored in -- one returning atomic per (wave round, distinct bin) on the
-// bin's cursor -- and k_texgrad_reduce then sums each bin's list in LDS and adds every texel of the block to
-// dL_dtexture once.  No MFMA: there is no dense contraction on this path.
+// bilinear footprints of a C3 view cost 0.69 ms that way (profiles/r02_ablation.md).  Instead K7 APPENDS a 20-byte
+// record {fx | cell x, fy | cell y, dL/dtexel-colour (3)} per footprint with plain coalesced stores to the list of the
+// 32x32-texel texture block ("bin") the footprint is anchored in -- one returning atomic per (wave round, distinct bin) on
+// the bin's cursor; a list is a chain of 512-record chunks from one pool -- and k_texgrad_reduce then sums each bin's list
+// in LDS and adds every texel of the block to dL_dtexture once.  No MFMA: there is no dense contraction on this path.
 #include "common.h"
 #include "wave_ops.h"
-#include <stdlib.h>
 
 namespace {
 
-#ifndef TG_WAVES_PER_WG
-#define TG_WAVES_PER_WG 1          // 1: one workgroup per 8x8 block (finest dispatch; K7 keeps 11 waves/CU by LDS); 4: one per tile
-#endif
-#define TG_WG_THREADS (64 * TG_WAVES_PER_WG)
+typedef unsigned long long ull;
 
 struct __attribute__((packed, aligned(4))) Texel3 { float x, y, z; };   // one global_load_dwordx3 per tap
 __device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, int off) {
@@ -75,18 +81,19 @@ __device__ __forceinline__ float gauss_power(float ah, float bh, float ch, float
 }
 __device__ __forceinline__ float gauss_alpha_raw(float op, float power) { return op * __expf(power); }
 
-// Per-wave cull, lane-parallel (lane = one instance of the chunk): can the instance reach alpha >= 1/255 at ANY point of the
-// wave's 8x8 pixel block?  power(d) = ah dx^2 + bh dx dy + ch dy^2 is concave with its maximum 0 at the splat centre, so its
-// maximum over the block's rectangle is 0 if the centre is inside, else it sits on one of the four edges, where it is a 1-D
-// concave parabola maximised at the clamped stationary point.  Exact for the continuous rectangle, hence conservative for
-// the pixel centres; `thr` already carries a margin far above fp32 rounding.  (The bounding-disc test alone let through
-// twice as many instances as ever produced an item: edge-on splats are needles, not discs.)
+// Cull, lane-parallel (lane = one instance): can the instance reach alpha >= 1/255 at ANY point of the pixel rectangle
+// [x0, x0 + ext] x [y0, y0 + ext] (ext = 7: the wave's 8x8 block, ext = 3: one 4x4 quadrant)?  power(d) = ah dx^2 + bh dx dy +
+// ch dy^2 is concave with its maximum 0 at the splat centre, so its maximum over the rectangle is 0 if the centre is inside,
+// else it sits on one of the four edges, where it is a 1-D concave parabola maximised at the clamped stationary point.
+// Exact for the continuous rectangle, hence conservative for the pixel centres; `thr` already carries a margin far above
+// fp32 rounding.  (The bounding-disc test alone let through twice as many instances as ever produced an item: edge-on
+// splats are needles, not discs.)  A false positive costs a test, never a result.
 __device__ __forceinline__ bool block_reachable(float gx, float gy, float ah, float bh, float ch, float thr, float rcull,
-                                                float x0, float y0) {
-    const float x1 = x0 + 7.0f, y1 = y0 + 7.0f;
+                                                float x0, float y0, float ext) {
+    const float x1 = x0 + ext, y1 = y0 + ext;
     if (!(rcull >= 0.f && (gx + rcull >= x0) && (gx - rcull <= x1) && (gy + rcull >= y0) && (gy - rcull <= y1))) return false;
     const float dx0 = gx - x1, dx1 = gx - x0, dy0 = gy - y1, dy1 = gy - y0;     // d = centre - pixel ranges over [dx0,dx1] x [dy0,dy1]
-    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;     // centre inside the block
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;     // centre inside the rectangle
     const float ihc = -0.5f * __builtin_amdgcn_rcpf(ch), iha = -0.5f * __builtin_amdgcn_rcpf(ah);
     auto edge_x = [&](float dx) {       // dx fixed, dy free in [dy0, dy1]
         const float dy = fminf(dy1, fmaxf(dy0, bh * dx * ihc));
@@ -105,96 +112,131 @@ struct PixArgs {
     const uint2* ranges;
     const uint32_t* tile_order;
     const uint32_t* point_list;
-    const float4* rec;
+    const float4* rec_test;     // [N][2]: (xy, ah, bh) | (ch, opacity, rcull, thr)
+    const float4* rec_shade;    // [N][5]: (g, G0, G1) | (G2..G5) | (phi, vd0) | (vd1, vd2, depth, n0) | (n1, n2, -, -)
     const float* texture;
     const float* bg;
 };
 
-// workgroup -> (tile, 8x8 block).  Tiles are launched longest-list-first (tile_order).  With one wave per workgroup the
-// four blocks of a tile get ids that are equal mod 8, so they run on the same XCD (workgroup b is observed on XCD b % 8:
-// speed only) and share its L2 for the tile's records.
+// workgroup (= one wave) -> (tile, 8x8 block).  Tiles are launched longest-list-first (tile_order).  The four blocks of a
+// tile get ids that are equal mod 8, so they run on the same XCD (workgroup b is observed on XCD b % 8: speed only) and
+// share its L2 for the tile's records.
 __device__ __forceinline__ bool wave_block(const PixArgs& a, int& tile, int& wave) {
-#if TG_WAVES_PER_WG == 4
-    if ((int)blockIdx.x >= a.num_tiles) return false;
-    const int rank = (int)blockIdx.x;
-    tile = (int)a.tile_order[blockIdx.x];
-    wave = (int)(threadIdx.x >> 6);
-#else
     const int b = (int)blockIdx.x, k = b >> 3;
     wave = k & 3;
     const int rank = ((k >> 2) << 3) | (b & 7);
     if (rank >= a.num_tiles) return false;
     tile = (int)a.tile_order[rank];
-#endif
-    (void)rank;
     return true;
 }
-inline int blend_grid(int num_tiles) {
-#if TG_WAVES_PER_WG == 4
-    return num_tiles;
-#else
-    return 4 * ((num_tiles + 7) & ~7);
-#endif
-}
+inline int blend_grid(int num_tiles) { return 4 * ((num_tiles + 7) & ~7); }
 
-#define RLF(V, J) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), (J)))
 // HIP's __ballot(int) materialises the predicate as 0/1 in a VGPR and compares it again (v_cndmask + v_cmp per ballot);
 // the builtin takes the lane mask the compares already produced.
 #define TG_BALLOT(P) __builtin_amdgcn_ballot_w64((bool)(P))
+__device__ __forceinline__ int mbcnt64(ull m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---- per-wave LDS layout shared by K6 and K7 ----
+#define TG_RING 128          // survivor queue (raw list positions), power of two >= 127
+#define TG_DUMMY 64          // plane slot of the all-zero dummy survivor (alpha 0: never contributes); list padding points here
+struct Planes {              // the chunk's 64 survivors, plane-major [field group][survivor]: row-broadcast reads are conflict-free
+    float4 A[65];            // xy, ah, bh                      (test)
+    float4 B[65];            // ch, opacity, list position, -    (test)
+    float4 C[65];            // depth, normal                    (K6 blend, K7 stage B)
+    float4 D[65];            // g, G0, G1                        (dense phase)
+    float4 E[65];            // G2..G5
+    float4 F[65];            // phi, vd0
+    float2 G[66];            // vd1, vd2
+};
+
+// item key: survivor slot (7 bits) | pixel lane << 8 | pixel x offset in the block << 14 | y offset << 17
+#define KEY_J(K)   ((int)((K) & 127u))
+#define KEY_PL(K)  ((int)(((K) >> 8) & 63u))
+#define KEY_OX(K)  ((int)(((K) >> 14) & 7u))
+#define KEY_OY(K)  ((int)(((K) >> 17) & 7u))
+
+// lane -> pixel of the 8x8 block: DPP row q = lane >> 4 is the 4x4 quadrant (q & 1, q >> 1), lanes of a row in row-major order
+__device__ __forceinline__ void lane_pixel(int lane, int& ox, int& oy) {
+    ox = (((lane >> 4) & 1) << 2) | (lane & 3);
+    oy = (((lane >> 5) & 1) << 2) | ((lane >> 2) & 3);
+}
+
+// Chunk load, lane = survivor: shading record from HBM (the test record again: an L2 hit), planes to LDS.
+__device__ __forceinline__ void load_chunk(const PixArgs& a, Planes& P, int lane, bool live, uint32_t id, uint32_t pos,
+                                           float4& T0, float4& T1) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 S0 = z, S1 = z, S2 = z, S3 = z, S4 = z;
+    T0 = z; T1 = make_float4(0.f, 0.f, -1.f, 1.f);
+    if (live) {
+        const float4* __restrict__ tp = a.rec_test + 2 * (size_t)id;
+        const float4* __restrict__ sp = a.rec_shade + 5 * (size_t)id;
+        T0 = tp[0]; T1 = tp[1]; S0 = sp[0]; S1 = sp[1]; S2 = sp[2]; S3 = sp[3]; S4 = sp[4];
+    }
+    P.A[lane] = T0;
+    P.B[lane] = make_float4(T1.x, T1.y, __uint_as_float(pos), 0.f);
+    P.C[lane] = make_float4(S3.z, S3.w, S4.x, S4.y);
+    P.D[lane] = S0; P.E[lane] = S1; P.F[lane] = S2;
+    P.G[lane] = make_float2(S3.x, S3.y);
+}
+__device__ __forceinline__ void init_dummy(Planes& P, int lane) {
+    if (lane == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        P.A[TG_DUMMY] = z; P.B[TG_DUMMY] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f); P.C[TG_DUMMY] = z;
+        P.D[TG_DUMMY] = z; P.E[TG_DUMMY] = z; P.F[TG_DUMMY] = z; P.G[TG_DUMMY] = make_float2(0.f, 0.f);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ K6
-// Forward blend.  Per chunk of 64 instances:
-//   (sequential) every lane walks the chunk for its own pixel; the tested Gaussian's (xy, conic, opacity) arrive by
-//       v_readlane broadcast -- no LDS traffic or LDS latency in the dependent chain; ~30 VALU per test.  Depth,
-//       normal and alpha accumulate here (w = alpha*T needs no texture).
-//   (dense)      contributing (pixel, j, w) triples are compacted with ballot + mbcnt into a 128-entry per-wave LDS
-//       ring; whenever 64 are queued all 64 lanes pop one each, read the item's Gaussian fields (xy, g, G, phi, viewdep:
-//       four float4) from the per-wave LDS copy of the chunk's records, do the UV Taylor step, cubemap addressing and
-//       4 dwordx3 tap loads with full lane occupancy and 64 fetches in flight, then add w*colour into the pixel's LDS
-//       accumulator (fixed point, integer atomics).  The colour sum is order-independent, so this equals the in-order blend.
-// (Only ~8 of 64 pixels of a wave contribute to a given Gaussian: with the texture path inside the sequential loop it
-//  ran at ~12 % lane efficiency.  Fetching the item's 16 fields with ds_bpermute from lane j's registers made 42 % of
-//  the wave time an LDS-issue stall: profiles/r01_v7_summary.txt.)
+// Forward blend.  Depth, normal and alpha accumulate in the lock-step test loop (w = alpha*T needs no texture); the colour
+// of every contributing (pixel, Gaussian) pair is added by the dense phase into the pixel's LDS accumulator as Q32.32
+// fixed point with integer atomics -- the sum is order-independent, so it equals the in-order blend and is bit-reproducible.
 #define FQ_CAP 128
-#ifndef FWD_WAVES_PER_SIMD
-#define FWD_WAVES_PER_SIMD 5       // 81 VGPRs.  (6 = 80 VGPRs was measured: same solo time, slower next to another view's K7)
-#endif
+struct __attribute__((aligned(16))) FwdLds {
+    Planes p;                           // 6768 B
+    uint2 q[FQ_CAP];                    // 1024: dense-phase queue {w, key}
+    ull col[64 * 3];                    // 1536: Q32.32 colour sums of the wave's pixels
+    uint32_t ring[TG_RING];             //  512
+    uint8_t list[4][64];                //  256: per-quadrant survivor lists, padded with TG_DUMMY
+};                                      // 10096 B -> 16 waves per CU
 
-__global__ void __launch_bounds__(TG_WG_THREADS, FWD_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, 4)
 k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_norm,
              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-    __shared__ uint2 s_qall[TG_WAVES_PER_WG][FQ_CAP];
-    __shared__ unsigned long long s_colall[TG_WAVES_PER_WG][64 * 3];   // Q32.32 colour sums (see drain)
-    __shared__ float4 s_recall[TG_WAVES_PER_WG][4 * 64];     // (xy, g) | G0-3 | G4-5, phi0-1 | phi2, viewdep
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ FwdLds L;
+    const int lane = (int)threadIdx.x;
     int tile, wave;
     if (!wave_block(a, tile, wave)) return;
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int wave_px = tile_x * TEXGS_TILE + ((wave & 1) << 3), wave_py = tile_y * TEXGS_TILE + ((wave >> 1) << 3);
-    const int px = wave_px + (lane & 7), py = wave_py + (lane >> 3);
+    int ox, oy;
+    lane_pixel(lane, ox, oy);
+    const int px = wave_px + ox, py = wave_py + oy;
     const bool inside = (px < a.W) && (py < a.H);
     const float pxf = (float)px, pyf = (float)py;
+    const float wpx = (float)wave_px, wpy = (float)wave_py;
     const uint2 range = a.ranges[tile];
     const int todo = (int)(range.y - range.x);
     const float* __restrict__ tex = a.texture;
-    uint2* s_q = s_qall[wv];
-    unsigned long long* s_c = s_colall[wv];
-    float4* s_rec = s_recall[wv];
+    const uint32_t keybase = ((uint32_t)lane << 8) | ((uint32_t)ox << 14) | ((uint32_t)oy << 17);
+    const uint8_t* mylist = L.list[lane >> 4];
 
-    s_c[lane * 3 + 0] = 0ull; s_c[lane * 3 + 1] = 0ull; s_c[lane * 3 + 2] = 0ull;   // own pixel; only this wave touches it
+    L.col[lane * 3 + 0] = 0ull; L.col[lane * 3 + 1] = 0ull; L.col[lane * 3 + 2] = 0ull;   // own pixel; only this wave touches it
+    init_dummy(L.p, lane);
     __builtin_amdgcn_wave_barrier();
 
     bool done = !inside;
-    unsigned long long done_mask = TG_BALLOT(!inside);        // the same, as a wave-level lane mask (scalar registers)
+    ull done_mask = TG_BALLOT(!inside);        // the same, as a wave-level lane mask (scalar registers)
     float T = 1.0f;
     float Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, Al = 0.f;
     uint32_t last = 0;
-    int qhead = 0, qtail = 0;                                  // wave-uniform
+    int qhead = 0, qtail = 0;                  // wave-uniform
 
     // The dense phase is software-pipelined by one batch: drain(n) first FINISHES the previous batch (its 4 taps were
     // loaded a whole batch interval ago: colour, Q32.32 accumulate), then STARTS the new one (queue pop, record fields, UV
     // Taylor step, cubemap address, tap loads issued) and returns without waiting for them.
-    int pn = 0;                                    // lanes of the batch in flight (wave-uniform)
+    int pn = 0;                                // lanes of the batch in flight (wave-uniform)
     int p_pl = 0;
     float p_w = 0.f, p_fx = 0.f, p_fy = 0.f, p_vd0 = 0.f, p_vd1 = 0.f, p_vd2 = 0.f;
     Texel3 p00 = {0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
@@ -208,79 +250,114 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             // w * colour (>= 0) goes to the owning pixel's accumulator as Q32.32 fixed point with an INTEGER LDS atomic:
             // ds_add_f32 retires ~3 cycles per LANE on gfx950 (193 cycles per wave instruction, scripts/ubench/lds_atomics.hip),
             // ds_add_u64 6 cycles per instruction.  2^-32 resolution (45 items: < 1e-8), exact and order-independent below 2^31.
-            unsigned long long* cp = s_c + p_pl * 3;
-            atomicAdd(cp + 0, (unsigned long long)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t0 + p_vd0 + 0.5f), 2.0e9f) * 4294967296.0f));
-            atomicAdd(cp + 1, (unsigned long long)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t1 + p_vd1 + 0.5f), 2.0e9f) * 4294967296.0f));
-            atomicAdd(cp + 2, (unsigned long long)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t2 + p_vd2 + 0.5f), 2.0e9f) * 4294967296.0f));
+            ull* cp = L.col + p_pl * 3;
+            atomicAdd(cp + 0, (ull)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t0 + p_vd0 + 0.5f), 2.0e9f) * 4294967296.0f));
+            atomicAdd(cp + 1, (ull)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t1 + p_vd1 + 0.5f), 2.0e9f) * 4294967296.0f));
+            atomicAdd(cp + 2, (ull)(fminf(p_w * fmaxf(0.f, TG_SH_C0 * t2 + p_vd2 + 0.5f), 2.0e9f) * 4294967296.0f));
         }
         pn = 0;
     };
     auto drain = [&](int n_) {
         finish();
         uint2 e_ = make_uint2(0u, 0u);
-        if (lane < n_) e_ = s_q[(qhead + lane) & (FQ_CAP - 1)];
-        const int pl_ = (int)(e_.y >> 8) & 63, jj_ = (int)(e_.y & 63u);
-        const float4 p0 = s_rec[jj_], p1 = s_rec[64 + jj_], p2 = s_rec[128 + jj_], p3 = s_rec[192 + jj_];
-        const float dpx = (float)(wave_px + (pl_ & 7)) - p0.x, dpy = (float)(wave_py + (pl_ >> 3)) - p0.y;
-        const float den = 1.0f + p0.z * dpx + p0.w * dpy;
+        if (lane < n_) e_ = L.q[(qhead + lane) & (FQ_CAP - 1)];
+        const int jj_ = KEY_J(e_.y);
+        const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj_]);
+        const float4 d_ = L.p.D[jj_], e4 = L.p.E[jj_], f_ = L.p.F[jj_];
+        const float2 g2 = L.p.G[jj_];
+        const float dpx = (float)(wave_px + KEY_OX(e_.y)) - xy.x, dpy = (float)(wave_py + KEY_OY(e_.y)) - xy.y;
+        const float den = 1.0f + d_.x * dpx + d_.y * dpy;
         const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-        const float u0 = p2.z + (p1.x * dpx + p1.y * dpy) * inv;
-        const float u1 = p2.w + (p1.z * dpx + p1.w * dpy) * inv;
-        const float u2 = p3.x + (p2.x * dpx + p2.y * dpy) * inv;
+        const float u0 = f_.x + (d_.z * dpx + d_.w * dpy) * inv;
+        const float u1 = f_.y + (e4.x * dpx + e4.y * dpy) * inv;
+        const float u2 = f_.z + (e4.z * dpx + e4.w * dpy) * inv;
         const CubeTap ct = cube_address(u0, u1, u2, a.R);
         if (lane < n_) {
             p00 = load_texel(tex, ct.o00); p01 = load_texel(tex, ct.o01);
             p10 = load_texel(tex, ct.o10); p11 = load_texel(tex, ct.o11);
         }
-        p_w = __uint_as_float(e_.x); p_pl = pl_; p_fx = ct.fx; p_fy = ct.fy; p_vd0 = p3.y; p_vd1 = p3.z; p_vd2 = p3.w;
+        p_w = __uint_as_float(e_.x); p_pl = KEY_PL(e_.y); p_fx = ct.fx; p_fy = ct.fy; p_vd0 = f_.w; p_vd1 = g2.x; p_vd2 = g2.y;
         pn = n_;
     };
 
-    // (Double-buffering the records in registers -- chunk c+1 in flight while chunk c is blended -- was measured: no gain,
-    // +28 VGPRs.  The kernel is bound by VALU issue at its occupancy, not by the index -> record load latency.)
-    for (int base = 0; base < todo; base += 64) {
-        if (~done_mask == 0ull) break;
-        const int cnt = min(64, todo - base);
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
-        if (lane < cnt) {
-            const uint32_t id = a.point_list[range.x + base + lane];
-            const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6];
+    int r = 0, nq = 0, qh = 0;                 // next raw list position, survivors queued, queue head (all wave-uniform)
+    uint32_t nid = (lane < todo) ? a.point_list[range.x + lane] : 0u;      // Gaussian ids of the raw batch at r, one batch ahead
+    bool all_done = (~done_mask == 0ull);
+    while (!all_done) {
+        // ---- raw batches: 8x8 cull on the 32-byte test records, survivors queued in list order
+        while (nq < 64 && r < todo) {
+            const int idx = r + lane;
+            const uint32_t id = nid;
+            r += 64;
+            nid = (r + lane < todo) ? a.point_list[range.x + r + lane] : 0u;
+            bool reach = false;
+            if (idx < todo) {
+                const float4* __restrict__ tp = a.rec_test + 2 * (size_t)id;
+                const float4 t0 = tp[0], t1 = tp[1];
+                reach = block_reachable(t0.x, t0.y, t0.z, t0.w, t1.x, t1.w, t1.z, wpx, wpy, 7.0f);
+            }
+            const ull m = TG_BALLOT(reach);
+            if (reach) L.ring[(qh + nq + mbcnt64(m)) & (TG_RING - 1)] = (uint32_t)idx;
+            nq += __popcll(m);
         }
-        // dense-phase copy of the chunk (the previous chunk's items were all drained before this point)
-        s_rec[lane] = make_float4(r0.x, r0.y, r1.z, r1.w); s_rec[64 + lane] = r2; s_rec[128 + lane] = r3; s_rec[192 + lane] = r4;
+        if (nq == 0) break;
+        // ---- chunk: up to 64 survivors, lane = survivor
+        const int take = min(64, nq);
         __builtin_amdgcn_wave_barrier();
-        // per-wave cull, lane-parallel: can instance `lane` reach alpha >= 1/255 anywhere in this wave's 8x8 block?
-        unsigned long long todo_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
-        // One exit per tested instance: alpha is evaluated for every candidate that survived the block cull (84 % of them blend
-        // somewhere in the block; a power-threshold prefilter ahead of the alpha test was slower).  Wave-level decisions are
-        // PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask and the combination is scalar
-        // ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip.
-        auto test = [&](int j, float& power, float& alpha, float4& geo) {
-            const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
-            const float cc = RLF(r1.x, j), op = RLF(r1.y, j);
-            geo = make_float4(RLF(r5.x, j), RLF(r5.y, j), RLF(r5.z, j), RLF(r5.w, j));       // depth, normal
-            power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-            alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(op, power));
-        };
-        auto blend = [&](int j, float power, float alpha, const float4& geo) -> bool {          // true: every pixel is done
-            const unsigned long long m_ok = TG_BALLOT(power <= 0.0f) & ~done_mask & TG_BALLOT(alpha >= TG_ALPHA_MIN);
-            if (m_ok == 0ull) return false;
+        uint32_t pos = 0xFFFFFFFFu, id = 0u;
+        if (lane < take) {
+            pos = L.ring[(qh + lane) & (TG_RING - 1)];
+            id = a.point_list[range.x + pos];
+        }
+        qh = (qh + take) & (TG_RING - 1); nq -= take;
+        float4 T0, T1;
+        load_chunk(a, L.p, lane, lane < take, id, pos, T0, T1);     // (every item of the previous chunk was started by a drain: its fields are in registers)
+        reinterpret_cast<uint32_t*>(&L.list[0][0])[lane] = 0x40404040u;      // pad all four lists with TG_DUMMY
+        __builtin_amdgcn_wave_barrier();
+        int len[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool rowdone = ((done_mask >> (16 * q)) & 0xFFFFull) == 0xFFFFull;
+            const bool rq = (lane < take) && !rowdone &&
+                block_reachable(T0.x, T0.y, T0.z, T0.w, T1.x, T1.w, T1.z, wpx + (float)((q & 1) << 2), wpy + (float)((q >> 1) << 2), 3.0f);
+            const ull m = TG_BALLOT(rq);
+            len[q] = __popcll(m);
+            if (rq) L.list[q][mbcnt64(m)] = (uint8_t)lane;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lock-step test loop: iteration t tests list entry t of every quadrant.  Parameters of iteration t + 1 and the
+        // list entry of t + 2 are in flight while t is evaluated.
+        int tmax = max(max(len[0], len[1]), max(len[2], len[3]));
+        int cj = mylist[0], nj = mylist[1], nnj = mylist[2];
+        float4 cA = L.p.A[cj], cB = L.p.B[cj], cC = L.p.C[cj];
+        float4 nA = L.p.A[nj], nB = L.p.B[nj], nC = L.p.C[nj];
+        for (int t = 0; t < tmax; ++t) {
+            const float4 A = cA, B = cB, Cc = cC;
+            const int j = cj;
+            cj = nj; cA = nA; cB = nB; cC = nC;
+            nj = nnj;
+            nA = L.p.A[nj]; nB = L.p.B[nj]; nC = L.p.C[nj];
+            nnj = mylist[min(t + 3, 63)];
+            // One exit per tested instance: alpha is evaluated for every candidate that survived the culls.  Wave-level decisions
+            // are PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask and the combination is
+            // scalar ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip.
+            const float power = gauss_power(A.z, A.w, B.x, A.x - pxf, A.y - pyf);
+            const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(B.y, power));
+            const ull m_ok = TG_BALLOT(power <= 0.0f) & ~done_mask & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+            if (m_ok == 0ull) continue;
             bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
             const float Tn = T * (1.0f - alpha);
-            const unsigned long long m_kill = m_ok & TG_BALLOT(Tn < TG_T_EPS);
+            const ull m_kill = m_ok & TG_BALLOT(Tn < TG_T_EPS);
             if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
             done_mask |= m_kill;
-            const unsigned long long bal = m_ok & ~m_kill;
+            const ull bal = m_ok & ~m_kill;
             if (bal != 0ull) {
                 if (ok) {
                     const float w = alpha * T;
-                    Dp += w * geo.x; N0 += w * geo.y; N1 += w * geo.z; N2 += w * geo.w; Al += w;
+                    Dp += w * Cc.x; N0 += w * Cc.y; N1 += w * Cc.z; N2 += w * Cc.w; Al += w;
                     T = Tn;
-                    last = (uint32_t)(base + j + 1);
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    s_q[(qtail + rank) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), ((uint32_t)lane << 8) | (uint32_t)j);
+                    last = __float_as_uint(B.z) + 1u;
+                    L.q[(qtail + mbcnt64(bal)) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), keybase | (uint32_t)j);
                 }
                 qtail += __popcll(bal);
                 if (qtail - qhead >= 64) {
@@ -289,17 +366,16 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
                     qhead += 64;
                 }
             }
-            return ~done_mask == 0ull;
-        };
-        while (todo_mask != 0ull) {
-            const int j = __ffsll((long long)todo_mask) - 1;
-            todo_mask &= todo_mask - 1ull;
-            float p, al;
-            float4 g;
-            test(j, p, al, g);
-            if (blend(j, p, al, g)) break;
+            if (m_kill != 0ull) {               // some pixels finished: quadrants whose 16 pixels are all done stop walking their lists
+                if (~done_mask == 0ull) { all_done = true; break; }
+                int tm = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (((done_mask >> (16 * q)) & 0xFFFFull) != 0xFFFFull) tm = max(tm, len[q]);
+                tmax = tm;
+            }
         }
-        // items reference this chunk's LDS copy: finish them before the next chunk is loaded
+        // items reference this chunk's LDS planes: start them before the next chunk is loaded
         if (qtail - qhead > 0) {
             __builtin_amdgcn_wave_barrier();
             drain(qtail - qhead);
@@ -312,9 +388,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
         const double q = 1.0 / 4294967296.0;
-        out_color[pix] = (float)((double)s_c[lane * 3 + 0] * q) + T * a.bg[0];
-        out_color[HW + pix] = (float)((double)s_c[lane * 3 + 1] * q) + T * a.bg[1];
-        out_color[2 * HW + pix] = (float)((double)s_c[lane * 3 + 2] * q) + T * a.bg[2];
+        out_color[pix] = (float)((double)L.col[lane * 3 + 0] * q) + T * a.bg[0];
+        out_color[HW + pix] = (float)((double)L.col[lane * 3 + 1] * q) + T * a.bg[1];
+        out_color[2 * HW + pix] = (float)((double)L.col[lane * 3 + 2] * q) + T * a.bg[2];
         out_depth[pix] = Dp;
         out_norm[pix] = N0; out_norm[HW + pix] = N1; out_norm[2 * HW + pix] = N2;
         out_alpha[pix] = Al;
@@ -324,78 +400,89 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 }
 
 // ------------------------------------------------------------------------------------------------ K7
-// Backward replay, per chunk of 64 instances, back to front:
-//   stage A  sequential, ~30 VALU / test: falloff, alpha, T /= (1-alpha); contributing (pixel, j) pairs are
-//            compacted (ballot + mbcnt) into an LDS item list {T, alpha_raw, q, key}; per-j ballots stay in VGPRs.
+// Backward replay, back to front.  Per chunk of 64 survivors, in segments of at most BQ_CAP items / BWD_MAX_IT iterations:
+//   stage A  lock-step over the four quadrant lists (see the file header), ~45 VALU per iteration: falloff, alpha,
+//            T /= (1 - alpha); contributing (pixel, Gaussian) pairs are compacted (ballot + mbcnt) into the LDS item list
+//            {T, -, alpha_raw, key}; the iteration's ballot and first item stay in the registers of lane <iteration>.
 //   stage B  dense, 64 items per round: UV Taylor step, cubemap address, 4 dwordx3 tap loads, colour; stores per item
 //            s = colour . dL/dcolour + geometry channels . their gradients (what stage C1 sums) and dL/dcolour (3),
 //            dL/duv (3), 1/den, dL/dden; appends the item's texture-gradient record to its texture bin (see the file header).
-//   stage C1 sequential, per pixel: dL/dalpha_i = T_i s_i - (sum of s_k alpha_k T_k behind i + bg term) / (1 - alpha_i), one
-//            running sum per pixel; leaves w and dL/dpower in the item.
-//   stage C2 dense over TASKS (<= 16 consecutive items of one Gaussian, 4 tasks per round): the 28 per-Gaussian moment
-//            terms of every item, a 16-lane transposing butterfly (DPP only, wave_ops.h), and the 16 lanes add the
-//            Gaussian's 128-byte accumulator row as two 64-byte runs.
-#ifndef BQ_CAP
+//   stage C1 per pixel, iteration by iteration: dL/dalpha_i = T_i s_i - (sum of s_k alpha_k T_k behind i + bg term) / (1 - alpha_i),
+//            one running sum per pixel; leaves w and dL/dpower in the item.
+//   stage C2 dense over TASKS = the items of one (iteration, quadrant) = up to 16 consecutive items of ONE Gaussian, four
+//            tasks per round (one per DPP row): the 28 per-Gaussian moment terms of every item, a 16-lane transposing butterfly
+//            (DPP only, wave_ops.h), and the 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.
 #define BQ_CAP 128
-#endif
-#ifndef BWD_WAVES_PER_SIMD
-#define BWD_WAVES_PER_SIMD 2
-#endif
-
-#ifdef K7_STATS        // diagnostics build (scripts/k7_stats.py): dynamic work counters of K7, summed over the launch
-__device__ unsigned long long g_k7_stats[16];
-#define K7_COUNT(i, n) (k7s[i] += (unsigned)(n))
-#else
-#define K7_COUNT(i, n) ((void)0)
-#endif
-#ifndef K7_ABL
-#define K7_ABL 0      // timing-only ablations (scripts/bench_variants.sh): 1 = no stage C1, 2 = no stage C2, 4 = no stage B
-#endif
+#define BWD_MAX_IT 16
+#define TB_CHUNK_LOG 9
+#define TB_CHUNK (1u << TB_CHUNK_LOG)             // records per pool chunk (= TEXGS_TEXBIN_CHUNK_RECORDS)
+#define TB_NONE 0xFFFFFFFFu                       // chunk-table value: "no chunk, use atomics" (pool exhausted)
+static_assert(TB_CHUNK == TEXGS_TEXBIN_CHUNK_RECORDS, "chunk size");
 struct TexBinArgs {
-    float*    rec;         // [nbins][6][cap]: cell | fx | fy | dL/dtexel-colour r, g, b   (plane-major inside a bin)
-    uint32_t* cursor;      // [nbins] records appended so far (may exceed cap: the excess went to dL_dtexture directly)
-    uint32_t* stats;       // [0] max list length (for the host), [1] bits of max |dL/dpixel colour| of this call
-    uint32_t  cap;
+    float*    pool;        // [pool_chunks][5][TB_CHUNK]: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b (plane-major inside a chunk)
+    uint32_t* cursor;      // [nbins] records appended so far (may exceed slots * TB_CHUNK: the excess went to dL_dtexture directly)
+    uint32_t* table;       // [nbins][slots] chunk id + 1 of the list's k-th chunk; 0 = not allocated yet
+    uint32_t* stats;       // [0] max chunks wanted by a call (for the host), [1] bits of max |dL/dpixel colour| of this call,
+                           // [2] pool head of this call, [3] sticky error flag
+    uint32_t  pool_chunks, slots;
     int       nb;          // bins per face row = ceil(R / 32)
 };
 
-// footprints that cannot be binned (clamped at a face border, or the bin is full): straight into dL_dtexture
-__device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, const CubeTap& ct, float w00, float w01, float w10,
-                                               float w11, float x0, float x1, float x2) {
-    unsafeAtomicAdd(dtex + ct.o00, w00 * x0); unsafeAtomicAdd(dtex + ct.o00 + 1, w00 * x1); unsafeAtomicAdd(dtex + ct.o00 + 2, w00 * x2);
-    unsafeAtomicAdd(dtex + ct.o01, w01 * x0); unsafeAtomicAdd(dtex + ct.o01 + 1, w01 * x1); unsafeAtomicAdd(dtex + ct.o01 + 2, w01 * x2);
-    unsafeAtomicAdd(dtex + ct.o10, w10 * x0); unsafeAtomicAdd(dtex + ct.o10 + 1, w10 * x1); unsafeAtomicAdd(dtex + ct.o10 + 2, w10 * x2);
-    unsafeAtomicAdd(dtex + ct.o11, w11 * x0); unsafeAtomicAdd(dtex + ct.o11 + 1, w11 * x1); unsafeAtomicAdd(dtex + ct.o11 + 2, w11 * x2);
+struct __attribute__((aligned(16))) BwdLds {
+    float4 items[BQ_CAP * 3 + 3];       // 6192: 3 float4 per item {T -> w, s -> dL/dpower, alpha_raw, key} {dc, du0} {du1, du2, inv, dden}; + one all-zero item
+    Planes p;                           // 6768
+    float4 dpix[64];                    // 1024: dL/d(r, g, b, alpha) of the wave's pixels
+    float4 dgeo[64];                    // 1024: dL/d(depth, normal)
+    uint32_t ring[TG_RING];             //  512
+    uint32_t task[64];                  //  256
+    uint8_t list[4][64];                //  256
+};                                      // 16032 B -> 10 waves per CU
+
+// footprints that cannot be binned (clamped at a face border, pool exhausted, list beyond its table): straight into dL_dtexture
+__device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, int o00, int o01, int o10, int o11, float w00, float w01,
+                                               float w10, float w11, float x0, float x1, float x2) {
+    unsafeAtomicAdd(dtex + o00, w00 * x0); unsafeAtomicAdd(dtex + o00 + 1, w00 * x1); unsafeAtomicAdd(dtex + o00 + 2, w00 * x2);
+    unsafeAtomicAdd(dtex + o01, w01 * x0); unsafeAtomicAdd(dtex + o01 + 1, w01 * x1); unsafeAtomicAdd(dtex + o01 + 2, w01 * x2);
+    unsafeAtomicAdd(dtex + o10, w10 * x0); unsafeAtomicAdd(dtex + o10 + 1, w10 * x1); unsafeAtomicAdd(dtex + o10 + 2, w10 * x2);
+    unsafeAtomicAdd(dtex + o11, w11 * x0); unsafeAtomicAdd(dtex + o11 + 1, w11 * x1); unsafeAtomicAdd(dtex + o11 + 2, w11 * x2);
 }
 
-__global__ void __launch_bounds__(TG_WG_THREADS, BWD_WAVES_PER_SIMD)
+// chunk id of a list position whose first record belongs to another wave: that wave publishes it right after its cursor atomic
+// returned and never waits before doing so, hence the wait is short and cannot deadlock; bounded all the same (a spin that
+// runs out raises the sticky error flag and the footprint goes through atomics)
+__device__ __forceinline__ uint32_t wait_chunk(const uint32_t* p, uint32_t* err) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0u) return v;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return TB_NONE;
+}
+
+__global__ void __launch_bounds__(64, 2)
 k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
              float* __restrict__ acc, float* __restrict__ dtex) {
-    // 3 float4 per item: {T -> w, s -> dL/dpower, alpha_raw, key} {dc, du0} {du1, du2, inv, dden}; + one all-zero item (stage C2's idle lanes)
-    __shared__ float4 s_items_all[TG_WAVES_PER_WG][BQ_CAP * 3 + 3];
-    __shared__ float4 s_dpix_all[TG_WAVES_PER_WG][64];            // dL/d(r, g, b, alpha) of the wave's pixels
-    __shared__ float4 s_recs_all[TG_WAVES_PER_WG][6 * 64];        // the chunk's records, plane-major [k][lane]
-    __shared__ float s_dgeo_all[TG_WAVES_PER_WG][64 * 4];         // dL/d(depth, normal) of the wave's pixels
-    __shared__ uint32_t s_task_all[TG_WAVES_PER_WG][BQ_CAP / 16 + 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ BwdLds L;
+    const int lane = (int)threadIdx.x;
     int tile, wave;
     if (!wave_block(a, tile, wave)) return;
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int wave_px = tile_x * TEXGS_TILE + ((wave & 1) << 3), wave_py = tile_y * TEXGS_TILE + ((wave >> 1) << 3);
-    const int px = wave_px + (lane & 7), py = wave_py + (lane >> 3);
+    int ox, oy;
+    lane_pixel(lane, ox, oy);
+    const int px = wave_px + ox, py = wave_py + oy;
     const bool inside = (px < a.W) && (py < a.H);
     const float pxf = (float)px, pyf = (float)py;
+    const float wpx = (float)wave_px, wpy = (float)wave_py;
     const uint2 range = a.ranges[tile];
     const int todo = (int)(range.y - range.x);
     const int HW = a.W * a.H, pix = py * a.W + px;
     const float* __restrict__ tex = a.texture;
-    float4* s_items = s_items_all[wv];
-    float4* s_recs = s_recs_all[wv];
-    float4* s_dpix = s_dpix_all[wv];
-    float* s_dgeo = s_dgeo_all[wv];
-    uint32_t* s_task = s_task_all[wv];
+    const uint32_t keybase = ((uint32_t)lane << 8) | ((uint32_t)ox << 14) | ((uint32_t)oy << 17);
+    const uint8_t* mylist = L.list[lane >> 4];
 
     float Tfin = 1.f; int last = 0;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
@@ -407,116 +494,145 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         if (dL_dalpha) dpix[7] = dL_dalpha[pix];
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
-    if (lane < 3) s_items[BQ_CAP * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_dpix[lane] = make_float4(dpix[0], dpix[1], dpix[2], dpix[7]);
-    *reinterpret_cast<float4*>(&s_dgeo[lane * 4]) = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
-    if (tb.rec != nullptr) {
-        // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale.
-        // Positive floats order like their bit patterns; the plain read first keeps 10^4 waves off one hot word.
+    if (lane < 3) L.items[BQ_CAP * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.dpix[lane] = make_float4(dpix[0], dpix[1], dpix[2], dpix[7]);
+    L.dgeo[lane] = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
+    init_dummy(L.p, lane);
+    if (tb.pool != nullptr) {
+        // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale of THIS
+        // call (K8 clears the word after the reduce).  Positive floats order like their bit patterns; the plain read first
+        // keeps 10^4 waves off one hot word.
         const int mbits = wave_max_i(__float_as_int(fmaxf(fabsf(dpix[0]), fmaxf(fabsf(dpix[1]), fabsf(dpix[2])))));
         if (lane == 0 && (uint32_t)mbits > __hip_atomic_load(tb.stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(tb.stats + 1, (uint32_t)mbits);
     }
-    const int wave_last = min(wave_max_i(last), todo);
+    // last contributor of each quadrant (row maximum) and of the block
+    int rl = last;
+    rl = max(rl, __shfl_xor(rl, 1, 64)); rl = max(rl, __shfl_xor(rl, 2, 64));
+    rl = max(rl, __shfl_xor(rl, 4, 64)); rl = max(rl, __shfl_xor(rl, 8, 64));
+    int rowlast[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rowlast[q] = min(__builtin_amdgcn_readlane(rl, 16 * q), todo);
+    const int wave_last = max(max(rowlast[0], rowlast[1]), max(rowlast[2], rowlast[3]));
     __builtin_amdgcn_wave_barrier();
 
     float T = Tfin;
     float behind = Tfin * bgdot;      // sum of s_k alpha_k T_k over the contributors BEHIND the current one, + the background term
-    uint32_t my_it0_sink = 0u;
-#ifdef K7_STATS
-    unsigned k7s[16] = {0};
-#endif
 
-    const int nchunks = (wave_last + 63) >> 6;
-    for (int c = nchunks - 1; c >= 0; --c) {
-        const int base = c << 6;
-        const int jtop = min(64, wave_last - base);           // instances [0, jtop) of this chunk matter
-        // ---- lane l <- instance l of the chunk
-        uint32_t id = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2v = r0, r3v = r0, r4v = r0, r5 = r0, r6 = make_float4(-1.f, 1.f, 0.f, 0.f);
-        if (lane < jtop) {
-            id = a.point_list[range.x + base + lane];
-            const float4* __restrict__ r = a.rec + (size_t)id * (TEXGS_REC_FLOATS / 4);
-            r0 = r[0]; r1 = r[1]; r2v = r[2]; r3v = r[3]; r4v = r[4]; r5 = r[5]; r6 = r[6];
+    int r = wave_last, nq = 0, qh = 0;            // raw instances [0, r) are still to be culled, from the back
+    uint32_t nid = (r - 1 - lane >= 0) ? a.point_list[range.x + (r - 1 - lane)] : 0u;
+    for (;;) {
+        // ---- raw batches, back to front: 8x8 cull on the test records, survivors queued in reverse list order
+        while (nq < 64 && r > 0) {
+            const int idx = r - 1 - lane;
+            const uint32_t idb = nid;
+            r -= 64;
+            nid = (r - 1 - lane >= 0) ? a.point_list[range.x + (r - 1 - lane)] : 0u;
+            bool reach = false;
+            if (idx >= 0) {
+                const float4* __restrict__ tp = a.rec_test + 2 * (size_t)idb;
+                const float4 t0 = tp[0], t1 = tp[1];
+                reach = block_reachable(t0.x, t0.y, t0.z, t0.w, t1.x, t1.w, t1.z, wpx, wpy, 7.0f);
+            }
+            const ull m = TG_BALLOT(reach);
+            if (reach) L.ring[(qh + nq + mbcnt64(m)) & (TG_RING - 1)] = (uint32_t)idx;
+            nq += __popcll(m);
         }
-        // stage A broadcasts from registers (v_readlane: no LDS latency in its dependent chain); stages B and C fetch the
-        // per-Gaussian fields from this LDS copy (stage C: 6 broadcast ds_read_b128 instead of ~29 v_readlane whose SGPR
-        // results collide with gfx9's one-SGPR-per-VALU constant-bus limit; stage B: per-lane gather)
+        if (nq == 0) break;
+        // ---- chunk: up to 64 survivors, lane = survivor (descending list position)
+        const int take = min(64, nq);
         __builtin_amdgcn_wave_barrier();
-        s_recs[0 * 64 + lane] = r0; s_recs[1 * 64 + lane] = r1; s_recs[2 * 64 + lane] = r2v;
-        s_recs[3 * 64 + lane] = r3v; s_recs[4 * 64 + lane] = r4v; s_recs[5 * 64 + lane] = r5;
+        uint32_t pos = 0xFFFFFFFFu, id = 0u;
+        if (lane < take) {
+            pos = L.ring[(qh + lane) & (TG_RING - 1)];
+            id = a.point_list[range.x + pos];
+        }
+        qh = (qh + take) & (TG_RING - 1); nq -= take;
+        float4 T0, T1;
+        load_chunk(a, L.p, lane, lane < take, id, pos, T0, T1);
+        reinterpret_cast<uint32_t*>(&L.list[0][0])[lane] = 0x40404040u;
         __builtin_amdgcn_wave_barrier();
-        // per-wave cull (see K6): instances that cannot reach alpha >= 1/255 inside this wave's 8x8 block are never visited
-        const unsigned long long cull_mask = TG_BALLOT(block_reachable(r0.x, r0.y, r0.z, r0.w, r1.x, r6.y, r6.x, (float)wave_px, (float)wave_py));
-        K7_COUNT(0, 1); K7_COUNT(1, jtop); K7_COUNT(2, __popcll(cull_mask));      // chunks, instances, instances after the cull
-        uint32_t touched_lo = 0u, touched_hi = 0u;           // lane j keeps the stage-A ballot of instance j
-        unsigned long long amask = cull_mask;                 // instances still to be tested (stage A), high to low
-        while (amask != 0ull) {
+        int len[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool rq = (lane < take) && ((int)pos < rowlast[q]) &&
+                block_reachable(T0.x, T0.y, T0.z, T0.w, T1.x, T1.w, T1.z, wpx + (float)((q & 1) << 2), wpy + (float)((q >> 1) << 2), 3.0f);
+            const ull m = TG_BALLOT(rq);
+            len[q] = __popcll(m);
+            if (rq) L.list[q][mbcnt64(m)] = (uint8_t)lane;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int tmax = max(max(len[0], len[1]), max(len[2], len[3]));
+        int t = 0;
+        while (t < tmax) {
             // ================================================================ stage A
-            int n_items = 0;
-            unsigned long long seg_mask = 0ull;                 // instances of this segment that produced items
-            while (amask != 0ull) {
-                const int j = 63 - __clzll((long long)amask);
-                const unsigned long long jbit = 1ull << j;
-                K7_COUNT(3, 1);                                   // stage-A iterations
-                // one exit: alpha for every candidate that survived the block cull (84 % of them produce items anyway; a
-                // power-threshold prefilter before the alpha test was slower), all six broadcasts up front
-                const float gx_ = RLF(r0.x, j), gy_ = RLF(r0.y, j), ca = RLF(r0.z, j), cb = RLF(r0.w, j);
-                const float cc = RLF(r1.x, j), op = RLF(r1.y, j);
-                const float power = gauss_power(ca, cb, cc, gx_ - pxf, gy_ - pyf);
-                const float araw = gauss_alpha_raw(op, power);
-                const float alpha = fminf(TG_ALPHA_MAX, araw);
-                const bool ok = (base + j < last) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-                const unsigned long long bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(base + j < last) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
-                const int nb = __popcll(bal);
-                if (nb == 0) { amask &= ~jbit; continue; }
-                if (n_items + nb > BQ_CAP) break;                   // segment full; j is re-tested in the next one
-                amask &= ~jbit;
-                seg_mask |= jbit;
-                K7_COUNT(4, 1); K7_COUNT(5, nb); K7_COUNT(6, (nb + 15) >> 4);      // instances with items, items, C2 tasks
-                if (lane == j) { touched_lo = (uint32_t)bal; touched_hi = (uint32_t)(bal >> 32); }
-                if (ok) {
-                    T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    s_items[(n_items + rank) * 3] = make_float4(T, 0.f, araw, __uint_as_float(((uint32_t)lane << 8) | (uint32_t)j));
+            int n_items = 0, n_it = 0;
+            uint32_t it_lo = 0u, it_hi = 0u, it_first = 0u;      // lane k: ballot and first item of the segment's k-th productive iteration
+            {
+                int cj = mylist[t], nj = mylist[min(t + 1, 63)], nnj = mylist[min(t + 2, 63)];
+                float4 cA = L.p.A[cj], cB = L.p.B[cj];
+                float4 nA = L.p.A[nj], nB = L.p.B[nj];
+                while (t < tmax && n_it < BWD_MAX_IT) {
+                    const float power = gauss_power(cA.z, cA.w, cB.x, cA.x - pxf, cA.y - pyf);
+                    const float araw = gauss_alpha_raw(cB.y, power);
+                    const float alpha = fminf(TG_ALPHA_MAX, araw);
+                    const bool before = __float_as_uint(cB.z) < (uint32_t)last;
+                    const bool ok = before && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                    const ull bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(before) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+                    const int nb = __popcll(bal);
+                    if (nb != 0) {
+                        if (n_items + nb > BQ_CAP) break;               // segment full; this iteration is re-tested in the next one
+                        if (lane == n_it) { it_lo = (uint32_t)bal; it_hi = (uint32_t)(bal >> 32); it_first = (uint32_t)n_items; }
+                        if (ok) {
+                            T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
+                            L.items[(n_items + mbcnt64(bal)) * 3] = make_float4(T, 0.f, araw, __uint_as_float(keybase | (uint32_t)cj));
+                        }
+                        n_items += nb; ++n_it;
+                    }
+                    ++t;
+                    cj = nj; cA = nA; cB = nB;
+                    nj = nnj;
+                    nA = L.p.A[nj]; nB = L.p.B[nj];
+                    nnj = mylist[min(t + 2, 63)];
                 }
-                n_items += nb;
             }
             __builtin_amdgcn_wave_barrier();
+            if (n_items == 0) continue;
             // ================================================================ stage B
             // A segment holds at most two rounds of 64 items.  Both rounds' FRONT halves run first (addresses, the 4 tap
-            // loads, bin grouping, the cursor atomic: 8 loads + 2 returning atomics in flight), then both BACK halves
-            // (colour / gradient math, record stores).  K7's time falls as a + b / (waves per CU) with a large b: its waves
-            // mostly wait on memory, so the loads of round 1 are issued before anything waits on those of round 0.
+            // loads, bin grouping, the cursor atomic: 8 loads + 2 returning atomics in flight), then the chunk bookkeeping of
+            // the record lists (ALLOC for both rounds before either WAITS: a wave never waits on itself), then both BACK halves
+            // (colour / gradient math, record stores).
             struct Round {                                        // what the back half needs, as few registers as possible
-                bool have, binned;
-                int e, pl, jj, my_leader, my_rank, axis;
-                uint32_t bin, cell, slot0;
+                bool have, binned, leader;
+                int e, pl, jj, my_leader, my_rank, my_n, axis;
+                uint32_t bin, slot0, slot, chunk;
+                uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
                 int o00, dox, doy;                                // tap offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
                 float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
                 float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
                 Texel3 t00, t01, t10, t11;
             };
-            auto front = [&](int r, Round& R) {
-                R.e = r + lane;
+            auto front = [&](int rbase, Round& R) {
+                R.e = rbase + lane;
                 R.have = R.e < n_items;
                 float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
-                if (R.have) it = s_items[R.e * 3];
+                if (R.have) it = L.items[R.e * 3];
                 const uint32_t key = __float_as_uint(it.w);
-                R.pl = (int)(key >> 8) & 63;
-                const int jj = (int)(key & 63u);
+                R.pl = KEY_PL(key);
+                const int jj = KEY_J(key);
                 R.jj = jj;
-                const float4 q0 = s_recs[0 * 64 + jj], q1 = s_recs[1 * 64 + jj], r2 = s_recs[2 * 64 + jj],
-                             r3 = s_recs[3 * 64 + jj], r4 = s_recs[4 * 64 + jj];
+                const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj]);
+                const float4 d_ = L.p.D[jj], e4 = L.p.E[jj], f_ = L.p.F[jj];
+                const float2 g2 = L.p.G[jj];
                 R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
-                R.vd0 = r4.y; R.vd1 = r4.z; R.vd2 = r4.w;
+                R.vd0 = f_.w; R.vd1 = g2.x; R.vd2 = g2.y;
                 // UV Taylor step, cubemap address, tap loads
-                const float dpx = (float)(wave_px + (R.pl & 7)) - q0.x, dpy = (float)(wave_py + (R.pl >> 3)) - q0.y;
-                const float den = 1.0f + q1.z * dpx + q1.w * dpy;
+                const float dpx = (float)(wave_px + KEY_OX(key)) - xy.x, dpy = (float)(wave_py + KEY_OY(key)) - xy.y;
+                const float den = 1.0f + d_.x * dpx + d_.y * dpy;
                 R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-                R.nu0 = r2.x * dpx + r2.y * dpy; R.nu1 = r2.z * dpx + r2.w * dpy; R.nu2 = r3.x * dpx + r3.y * dpy;
-                const CubeTap ct = cube_address(r3.z + R.nu0 * R.inv, r3.w + R.nu1 * R.inv, r4.x + R.nu2 * R.inv, a.R);
+                R.nu0 = d_.z * dpx + d_.w * dpy; R.nu1 = e4.x * dpx + e4.y * dpy; R.nu2 = e4.z * dpx + e4.w * dpy;
+                const CubeTap ct = cube_address(f_.x + R.nu0 * R.inv, f_.y + R.nu1 * R.inv, f_.z + R.nu2 * R.inv, a.R);
                 const Texel3 tz = {0.f, 0.f, 0.f};
                 R.t00 = tz; R.t01 = tz; R.t10 = tz; R.t11 = tz;
                 if (R.have) {
@@ -528,29 +644,60 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const float km = ct.h * ct.rma * ct.sm;
                 R.kc = ct.sc * km; R.kd = ct.tc * km;
                 R.o00 = ct.o00; R.dox = ct.o01 - ct.o00; R.doy = ct.o10 - ct.o00;
-                R.cell = (uint32_t)(((ct.y0 & 31) << 8) | (ct.x0 & 31));
+                // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
+                R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
+                R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
                 // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
                 // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
-                R.binned = R.have && tb.rec != nullptr && ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1;   // not clamped at a face border
+                R.binned = R.have && tb.pool != nullptr && ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1;   // not clamped at a face border
                 R.bin = (uint32_t)((ct.face * tb.nb + (ct.y0 >> 5)) * tb.nb + (ct.x0 >> 5));
-                bool leader = false;
-                R.my_leader = lane; R.my_rank = 0;
-                int my_n = 0;
-                unsigned long long pend = TG_BALLOT(R.binned);
+                R.leader = false;
+                R.my_leader = lane; R.my_rank = 0; R.my_n = 0;
+                ull pend = TG_BALLOT(R.binned);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
-                    const unsigned long long m = TG_BALLOT(R.binned && R.bin == b0);
-                    K7_COUNT(9, 1);                               // bin-grouping iterations
+                    const ull m = TG_BALLOT(R.binned && R.bin == b0);
                     if ((m >> lane) & 1ull) {
                         R.my_leader = l0;
-                        R.my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (lane == l0) { leader = true; my_n = __popcll(m); }
+                        R.my_rank = mbcnt64(m);
+                        if (lane == l0) { R.leader = true; R.my_n = __popcll(m); }
                     }
                     pend &= ~m;
                 }
                 R.slot0 = 0u;
-                if (leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)my_n);
+                if (R.leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)R.my_n);
+            };
+            // the group whose records contain a chunk's FIRST record owns that chunk's allocation: pool head + publish
+            auto alloc = [&](Round& R) {
+                if (R.leader) {
+                    const uint32_t first = R.slot0, lastr = R.slot0 + (uint32_t)R.my_n - 1u;
+                    const uint32_t k0 = first >> TB_CHUNK_LOG, k1 = lastr >> TB_CHUNK_LOG;
+                    uint32_t* trow = tb.table + (size_t)R.bin * tb.slots;
+                    if ((first & (TB_CHUNK - 1u)) == 0u && k0 < tb.slots) {
+                        const uint32_t h = atomicAdd(tb.stats + 2, 1u);
+                        __hip_atomic_store(trow + k0, (h < tb.pool_chunks) ? h + 1u : TB_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (k1 != k0 && k1 < tb.slots) {
+                        const uint32_t h = atomicAdd(tb.stats + 2, 1u);
+                        __hip_atomic_store(trow + k1, (h < tb.pool_chunks) ? h + 1u : TB_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            };
+            auto resolve = [&](Round& R) {
+                uint32_t c0 = TB_NONE, c1 = TB_NONE;
+                if (R.leader) {
+                    const uint32_t k0 = R.slot0 >> TB_CHUNK_LOG, k1 = (R.slot0 + (uint32_t)R.my_n - 1u) >> TB_CHUNK_LOG;
+                    const uint32_t* trow = tb.table + (size_t)R.bin * tb.slots;
+                    if (k0 < tb.slots) c0 = wait_chunk(trow + k0, tb.stats + 3);
+                    c1 = c0;
+                    if (k1 != k0) c1 = (k1 < tb.slots) ? wait_chunk(trow + k1, tb.stats + 3) : TB_NONE;
+                }
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0);
+                const uint32_t l0 = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)c0);
+                const uint32_t l1 = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)c1);
+                R.slot = s0 + (uint32_t)R.my_rank;
+                R.chunk = ((R.slot >> TB_CHUNK_LOG) == (s0 >> TB_CHUNK_LOG)) ? l0 : l1;
             };
             auto back = [&](Round& R) {
                 const Texel3 &t00 = R.t00, &t01 = R.t01, &t10 = R.t10, &t11 = R.t11;
@@ -559,7 +706,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 float x0 = 0.f, x1 = 0.f, x2 = 0.f;
                 if (R.have) {
                     const float w = R.w;
-                    const float4 dp = s_dpix[R.pl];
+                    const float4 dp = L.dpix[R.pl];
                     const float d0 = dp.x, d1 = dp.y, d2 = dp.z;
                     const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + R.vd0 + 0.5f;
                     const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + R.vd1 + 0.5f;
@@ -583,110 +730,107 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
                     // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
                     // recurrence needs from this pair, formed here where all 64 lanes work
-                    const float4 c5 = s_recs[5 * 64 + R.jj];
-                    const float4 dg = *reinterpret_cast<const float4*>(&s_dgeo[R.pl * 4]);
-                    s_items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
-                    s_items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
-                    s_items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
+                    const float4 c5 = L.p.C[R.jj];
+                    const float4 dg = L.dgeo[R.pl];
+                    L.items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
+                    L.items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
+                    L.items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
                 }
                 // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
-                // a face border / the bin is full (still correct, just slow)
-                const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0) + (uint32_t)R.my_rank;
-                if (R.binned && slot < tb.cap) {
-                    float* __restrict__ rp = tb.rec + (size_t)R.bin * tb.cap * 6 + slot;
-                    rp[0] = __uint_as_float(R.cell);
-                    rp[tb.cap] = R.fx; rp[2 * (size_t)tb.cap] = R.fy;
-                    rp[3 * (size_t)tb.cap] = x0; rp[4 * (size_t)tb.cap] = x1; rp[5 * (size_t)tb.cap] = x2;
+                // a face border / the pool or the bin's chunk table is exhausted (still correct, just slow)
+                if (R.binned && R.chunk != TB_NONE) {
+                    float* __restrict__ rp = tb.pool + (size_t)(R.chunk - 1u) * TEXGS_TEXBIN_CHUNK_FLOATS + (R.slot & (TB_CHUNK - 1u));
+                    rp[0] = __uint_as_float(R.fxw); rp[TB_CHUNK] = __uint_as_float(R.fyw);
+                    rp[2 * TB_CHUNK] = x0; rp[3 * TB_CHUNK] = x1; rp[4 * TB_CHUNK] = x2;
                 } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
-                    CubeTap ct;
-                    ct.o00 = R.o00; ct.o01 = R.o00 + R.dox; ct.o10 = R.o00 + R.doy; ct.o11 = R.o00 + R.dox + R.doy;
-                    scatter_direct(dtex, ct, w00, w01, w10, w11, x0, x1, x2);
+                    scatter_direct(dtex, R.o00, R.o00 + R.dox, R.o00 + R.doy, R.o00 + R.dox + R.doy, w00, w01, w10, w11, x0, x1, x2);
                 }
             };
             static_assert(BQ_CAP <= 128, "stage B is unrolled for at most two rounds per segment");
-            K7_COUNT(7, 1); K7_COUNT(8, (n_items + 63) >> 6);                       // segments, stage-B rounds
-            if (n_items > 0 && !(K7_ABL & 4)) {
+            {
                 Round R0, R1;
                 front(0, R0);
                 if (n_items > 64) front(64, R1);
+                if (tb.pool != nullptr) {
+                    alloc(R0);
+                    if (n_items > 64) alloc(R1);
+                    resolve(R0);
+                    if (n_items > 64) resolve(R1);
+                } else { R0.chunk = TB_NONE; R1.chunk = TB_NONE; R0.slot = 0u; R1.slot = 0u; }
                 back(R0);
                 if (n_items > 64) back(R1);
             }
             __builtin_amdgcn_wave_barrier();
-            // ================================================================ stage C1: per-pixel recurrence (sequential in j)
+            // ================================================================ stage C1: per-pixel recurrence, iteration by iteration
             // dL/dalpha_i = T_i s_i - (B_i + T_final bg . dL/dcolour) / (1 - alpha_i),  B_i = sum over the contributors k BEHIND i
             // of s_k alpha_k T_k: one running sum per pixel (`behind`), back to front.  s_i (colour . dL/dcolour + geometry
             // channels) comes ready-made from stage B; this loop leaves w = alpha T and P = dL/dpower in the item.
-            int it0 = 0;
-            uint32_t my_it0 = 0u;                                  // lane j: first item of Gaussian j in this segment
-            if (K7_ABL != 0) my_it0_sink += (uint32_t)n_items + touched_lo;
-            if (!(K7_ABL & 1)) {
-                unsigned long long sm = seg_mask;
-                while (sm != 0ull) {
-                    const int jj = 63 - __clzll((long long)sm);
-                    sm &= ~(1ull << jj);
-                    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)touched_lo, jj);
-                    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)touched_hi, jj);
-                    if (lane == jj) my_it0 = (uint32_t)it0;
-                    if ((((unsigned long long)bhi << 32 | blo) >> lane) & 1ull) {
-                        const int it = it0 + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
-                        const float4 i0 = s_items[it * 3];
-                        const float Ti = i0.x, s_i = i0.y, araw = i0.z;
-                        const float alpha = fminf(TG_ALPHA_MAX, araw);
-                        const float w = alpha * Ti;
-                        const float dL_dalpha_ = Ti * s_i - behind * __builtin_amdgcn_rcpf(1.0f - alpha);
-                        behind = __fmaf_rn(s_i, w, behind);
-                        // {w, P}: P = dL/dpower straight through the 0.99 clamp (lineage)
-                        *reinterpret_cast<float2*>(&s_items[it * 3]) = make_float2(w, araw * dL_dalpha_);
-                    }
-                    it0 += __popcll(((unsigned long long)bhi << 32) | blo);
+            for (int k = 0; k < n_it; ++k) {
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)it_lo, k);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)it_hi, k);
+                const int it0 = __builtin_amdgcn_readlane((int)it_first, k);
+                if (((((ull)bhi << 32) | blo) >> lane) & 1ull) {
+                    const int it = it0 + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                    const float4 i0 = L.items[it * 3];
+                    const float Ti = i0.x, s_i = i0.y, araw = i0.z;
+                    const float alpha = fminf(TG_ALPHA_MAX, araw);
+                    const float w = alpha * Ti;
+                    const float dL_dalpha_ = Ti * s_i - behind * __builtin_amdgcn_rcpf(1.0f - alpha);
+                    behind = __fmaf_rn(s_i, w, behind);
+                    // {w, P}: P = dL/dpower straight through the 0.99 clamp (lineage)
+                    *reinterpret_cast<float2*>(&L.items[it * 3]) = make_float2(w, araw * dL_dalpha_);
                 }
             }
             // ================================================================ stage C2: per-Gaussian moment sums, 16 lanes per task
-            // A task = up to 16 consecutive items of ONE Gaussian (its items are contiguous in the list).  Four tasks per
-            // round: every lane forms the 28 moment terms of its item, a transposing butterfly over the 16 lanes (bank-masked
-            // DPP for lane^4 / lane^8, quad_perm for lane^1 / lane^2) leaves two of the 32 row slots in each lane, and the
-            // 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.  (The wave-wide version of this --
-            // one 64-lane butterfly per (wave, Gaussian) with ~17 of 64 lanes live -- was 42 % of K7's instructions.)
-            if (!(K7_ABL & 2)) {
-                const uint32_t nb_mine = ((seg_mask >> lane) & 1ull) ? (uint32_t)(__popc(touched_lo) + __popc(touched_hi)) : 0u;
-                const uint32_t ntask = (nb_mine + 15u) >> 4;
-                uint32_t incl = ntask;                            // inclusive prefix over the lanes (any fixed order works)
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-                const int total = __builtin_amdgcn_readlane((int)incl, 63);
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t t = 0; t < ntask; ++t)             // task word: j | first item << 6 | item count << 14
-                    s_task[incl - ntask + t] = (uint32_t)lane | ((my_it0 + 16u * t) << 6) | (min(16u, nb_mine - 16u * t) << 14);
-                __builtin_amdgcn_wave_barrier();
+            // task list: lane (k, q) = (iteration k, quadrant q) of the segment looks at its row of the iteration's ballot
+            int ntask;
+            {
+                const int itk = lane >> 2, qq = lane & 3;
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)it_lo);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)it_hi);
+                const uint32_t f0 = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)it_first);
+                const ull b = ((ull)bhi << 32) | blo;
+                const int c = __popc((uint32_t)(b >> (16 * qq)) & 0xFFFFu);
+                const int below = __popcll(b & ((1ull << (16 * qq)) - 1ull));
+                const bool havet = (itk < n_it) && (c > 0);
+                const ull tm = TG_BALLOT(havet);
+                ntask = __popcll(tm);
+                if (havet) L.task[mbcnt64(tm)] = (f0 + (uint32_t)below) | ((uint32_t)c << 8);       // first item | item count << 8
+            }
+            __builtin_amdgcn_wave_barrier();
+            // Four tasks per round: every lane forms the 28 moment terms of its item, a transposing butterfly over the 16 lanes
+            // (bank-masked DPP for lane^4 / lane^8, quad_perm for lane^1 / lane^2) leaves two of the 32 row slots in each lane,
+            // and the 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.
+            {
                 const int sub = lane & 15;
-                for (int q0 = 0; q0 < total; q0 += 4) {
-                    K7_COUNT(10, 1);                              // C2 rounds (4 tasks each)
-                    const int q = q0 + (lane >> 4);
-                    const uint32_t task = (q < total) ? s_task[q] : 0u;
-                    const int jt = (int)(task & 63u);
-                    const bool have = (uint32_t)sub < (task >> 14);
+                for (int q0 = 0; q0 < ntask; q0 += 4) {
+                    const int qi = q0 + (lane >> 4);
+                    const bool live = qi < ntask;
+                    const uint32_t task = live ? L.task[qi] : 0u;
+                    const int first = live ? (int)(task & 255u) : BQ_CAP;
+                    const bool have = (uint32_t)sub < (task >> 8);
                     // lanes without an item read the all-zero item behind the list: every moment below comes out 0 with no
                     // branch and no 32-register clear (the butterfly needs all 64 lanes anyway)
-                    const int item = have ? (int)((task >> 6) & 255u) + sub : BQ_CAP;
-                    // Gaussian index of the task: lane jt holds instance jt's (all 64 lanes are active here: bpermute reads 0
-                    // from an inactive source lane)
+                    const int item = have ? first + sub : BQ_CAP;
+                    // the task's Gaussian: survivor slot from its first item's key, index from the lane that holds that survivor
+                    // (all 64 lanes are active here: bpermute reads 0 from an inactive source lane)
+                    const int jt = KEY_J(__float_as_uint(L.items[first * 3].w));
                     const uint32_t gid = (uint32_t)__builtin_amdgcn_ds_bpermute(jt << 2, (int)id);
                     float part[32];
-                    const float2 gxy = *reinterpret_cast<const float2*>(&s_recs[jt]);
+                    const float2 gxy = *reinterpret_cast<const float2*>(&L.p.A[jt]);
                     {
-                        const float4 i0 = s_items[item * 3], i1 = s_items[item * 3 + 1], i2 = s_items[item * 3 + 2];
+                        const float4 i0 = L.items[item * 3], i1 = L.items[item * 3 + 1], i2 = L.items[item * 3 + 2];
                         const uint32_t key = __float_as_uint(i0.w);
-                        const int pl = (int)(key >> 8) & 63;
+                        const int pl = KEY_PL(key);
                         const float w = i0.x, P = i0.y;
-                        const float dx = gxy.x - (float)(wave_px + (pl & 7)), dy = gxy.y - (float)(wave_py + (pl >> 3));   // xy - pixel
+                        const float dx = gxy.x - (float)(wave_px + KEY_OX(key)), dy = gxy.y - (float)(wave_py + KEY_OY(key));   // xy - pixel
                         // RAW MOMENTS about the splat centre (TexGSGrads.acc layout, texgs.h); K8, which has conic / opacity /
                         // G / g in registers anyway, turns them into dL/d(xy, conic, opacity, G, g, ...)
                         const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
                         const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
                         const float dpx = -dx, dpy = -dy;                       // pixel - xy
                         const float Pdx = P * dx, Pdy = P * dy;
-                        const float4 dg = *reinterpret_cast<const float4*>(&s_dgeo[pl * 4]);
+                        const float4 dg = L.dgeo[pl];
                         part[M_P] = P; part[M_P + 1] = Pdx; part[M_P + 2] = Pdy;
                         part[M_P + 3] = Pdx * dx; part[M_P + 4] = Pdx * dy; part[M_P + 5] = Pdy * dy;
                         part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
@@ -702,7 +846,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     }
                     float lo, hi;
                     reduce32_rows16(part, lane, lo, hi);          // lane holds slots transposed_index(lane & 15) and 16 + that
-                    if (q < total) {
+                    if (live) {
                         float* row = acc + (size_t)gid * TEXGS_ACC_FLOATS + transposed_index(sub);
                         if (lo != 0.f) unsafeAtomicAdd(row, lo);
                         if (hi != 0.f) unsafeAtomicAdd(row + 16, hi);
@@ -712,28 +856,29 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             __builtin_amdgcn_wave_barrier();
         }
     }
-#ifdef K7_STATS
-    K7_COUNT(11, 1);
-    if (lane == 0) for (int i = 0; i < 16; ++i) if (k7s[i]) atomicAdd(&g_k7_stats[i], (unsigned long long)k7s[i]);
-#endif
-    if (K7_ABL != 0 && s_items[lane * 3].x == 12345.678f) acc[0] = (float)my_it0_sink;    // ablation builds: keep the LDS traffic alive
 }
 
 // ------------------------------------------------------------------------------------------------ texture-gradient reduce
 // One workgroup per 32x32-texel bin: sum the bin's records into a 33x33-texel LDS tile (footprints anchored in the bin
 // reach one texel past its right / bottom edge, still inside the face), then add every non-zero texel of the tile to
 // dL_dtexture[6,R,R,3] once -- 99 consecutive dwords per tile row, i.e. coalesced memory-side requests; neighbouring
-// bins overlap in that one-texel seam, hence atomics.  Leaves the cursor at 0 for the next call.
+// bins overlap in that one-texel seam, hence atomics.  Leaves the cursor and the bin's chunk-table entries at 0 for the
+// next call.
 // The tile is 64-bit FIXED POINT: LDS float atomics retire ~3 cycles per lane on gfx950 (ds_add_f32: 193 cycles per wave
 // instruction, ds_add_u64: 6; scripts/ubench/lds_atomics.hip), which made the first version of this kernel 1.8 ms.  Scale:
-// every record value is bounded by C0 * max|dL/dpixel colour| (K7 leaves that maximum in stats[1]) and is mapped to
-// < 2^42, so 2^20 records per bin cannot overflow; resolution 2^-42 of the image-wide bound, sums exact and
-// order-independent (the texture gradient of the binned path is bit-reproducible run to run).
+// every record value is bounded by C0 * max|dL/dpixel colour| OF THIS CALL (K7 leaves that maximum in stats[1], K8 clears it)
+// and is mapped to < 2^42; a list holds at most slots * 512 <= 2^20 records, so it cannot overflow; resolution 2^-42 of the
+// image-wide bound, sums exact and order-independent (the texture gradient of the binned path is bit-reproducible run to run).
 #define TB_EDGE 33
 __global__ void __launch_bounds__(256)
 k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __shared__ long long s_tile[TB_EDGE * TB_EDGE * 3];          // [row][col][channel], 2^42-scaled fixed point
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (b == 0 && tid == 0) {                                  // pool bookkeeping: what this call wanted, head back to 0
+        const uint32_t h = tb.stats[2];
+        if (h > tb.stats[0]) tb.stats[0] = h;
+        tb.stats[2] = 0u;
+    }
     const uint32_t filled = tb.cursor[b];
     if (filled == 0u) return;                                  // uniform per workgroup
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) s_tile[k] = 0ll;
@@ -743,38 +888,41 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     (void)frexpf(bound, &e);                                   // bound < 2^e
     const double up = (double)ldexpf(1.0f, 42 - e);
     const float down = ldexpf(1.0f, e - 42);
-    const uint32_t cnt = min(filled, tb.cap);
-    const float* __restrict__ rp = tb.rec + (size_t)b * tb.cap * 6;
-    const size_t cap = tb.cap;
+    const uint32_t nrec = min(filled, tb.slots << TB_CHUNK_LOG);
+    const uint32_t nch = (nrec + TB_CHUNK - 1u) >> TB_CHUNK_LOG;
+    uint32_t* trow = tb.table + (size_t)b * tb.slots;
     // float -> int64 without the 11-instruction generic conversion: |v| < 2^42, so v + 1.5 * 2^52 (exact in double) carries
     // round(v) in its mantissa; subtracting the bias as integers leaves the two's-complement value
     const double magic = 6755399441055744.0;
     const long long magic_bits = __double_as_longlong(magic);
-    auto add_record = [&](uint32_t cell, float fx, float fy, float x0, float x1, float x2) {
+    auto add_record = [&](uint32_t fxw, uint32_t fyw, float x0, float x1, float x2) {
+        const float fx = __uint_as_float(fxw & ~31u), fy = __uint_as_float(fyw & ~31u);
         const double dx0 = (double)x0 * up, dx1 = (double)x1 * up, dx2 = (double)x2 * up;
         const double w00 = (double)((1.f - fx) * (1.f - fy)), w01 = (double)(fx * (1.f - fy));
         const double w10 = (double)((1.f - fx) * fy), w11 = (double)(fx * fy);
-        unsigned long long* t = reinterpret_cast<unsigned long long*>(s_tile) + ((cell >> 8) * TB_EDGE + (cell & 0xFFu)) * 3;
-#define TB_ADD(P, V) atomicAdd((P), (unsigned long long)(__double_as_longlong((V) + magic) - magic_bits))
+        ull* t = reinterpret_cast<ull*>(s_tile) + ((fyw & 31u) * TB_EDGE + (fxw & 31u)) * 3;
+#define TB_ADD(P, V) atomicAdd((P), (ull)(__double_as_longlong((V) + magic) - magic_bits))
         TB_ADD(t + 0, w00 * dx0); TB_ADD(t + 1, w00 * dx1); TB_ADD(t + 2, w00 * dx2);
         TB_ADD(t + 3, w01 * dx0); TB_ADD(t + 4, w01 * dx1); TB_ADD(t + 5, w01 * dx2);
         TB_ADD(t + TB_EDGE * 3 + 0, w10 * dx0); TB_ADD(t + TB_EDGE * 3 + 1, w10 * dx1); TB_ADD(t + TB_EDGE * 3 + 2, w10 * dx2);
         TB_ADD(t + TB_EDGE * 3 + 3, w11 * dx0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * dx1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * dx2);
 #undef TB_ADD
     };
-    // two records per thread in flight (12 loads).  Measured and dropped: 4 / 8 in flight, two tile copies for even / odd lanes, a
-    // planar [channel][row][col] tile, plain read-modify-write of the tile interior on the way out (profiles/README.md): the
-    // kernel sits at 2x its HBM floor (the records, 0.45 GB at C3) with 66 % LDS bank-conflict cycles on the random atomics
-    uint32_t i = (uint32_t)tid;
-    for (; i + 256u < cnt; i += 512u) {
-        const uint32_t i2 = i + 256u;
-        const uint32_t ca = __float_as_uint(rp[i]), cb = __float_as_uint(rp[i2]);
-        const float fxa = rp[cap + i], fya = rp[2 * cap + i], xa0 = rp[3 * cap + i], xa1 = rp[4 * cap + i], xa2 = rp[5 * cap + i];
-        const float fxb = rp[cap + i2], fyb = rp[2 * cap + i2], xb0 = rp[3 * cap + i2], xb1 = rp[4 * cap + i2], xb2 = rp[5 * cap + i2];
-        add_record(ca, fxa, fya, xa0, xa1, xa2);
-        add_record(cb, fxb, fyb, xb0, xb1, xb2);
+    // one chunk = 512 records = two per thread, both in flight (10 loads); the chunk ids of the list come from the bin's table row
+    for (uint32_t k = 0; k < nch; ++k) {
+        const uint32_t c = trow[k];
+        if (c == 0u || c == TB_NONE) continue;                 // uniform: that part of the list went through atomics
+        const uint32_t cnt = min(TB_CHUNK, nrec - (k << TB_CHUNK_LOG));
+        const float* __restrict__ rp = tb.pool + (size_t)(c - 1u) * TEXGS_TEXBIN_CHUNK_FLOATS;
+        const uint32_t i = (uint32_t)tid, i2 = i + 256u;
+        const bool ha = i < cnt, hb = i2 < cnt;
+        uint32_t fxa = 0u, fya = 0u, fxb = 0u, fyb = 0u;
+        float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f, xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
+        if (ha) { fxa = __float_as_uint(rp[i]); fya = __float_as_uint(rp[TB_CHUNK + i]); xa0 = rp[2 * TB_CHUNK + i]; xa1 = rp[3 * TB_CHUNK + i]; xa2 = rp[4 * TB_CHUNK + i]; }
+        if (hb) { fxb = __float_as_uint(rp[i2]); fyb = __float_as_uint(rp[TB_CHUNK + i2]); xb0 = rp[2 * TB_CHUNK + i2]; xb1 = rp[3 * TB_CHUNK + i2]; xb2 = rp[4 * TB_CHUNK + i2]; }
+        if (ha) add_record(fxa, fya, xa0, xa1, xa2);
+        if (hb) add_record(fxb, fyb, xb0, xb1, xb2);
     }
-    if (i < cnt) add_record(__float_as_uint(rp[i]), rp[cap + i], rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i], rp[5 * cap + i]);
     __syncthreads();
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
@@ -786,10 +934,8 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles, hence atomics
         unsafeAtomicAdd(dtex + ((size_t)(face * R + y) * R) * 3 + xq, (float)q * down);
     }
-    if (tid == 0) {
-        tb.cursor[b] = 0u;
-        if (filled > tb.cap) atomicMax(tb.stats, filled);      // overflowed: tell the host how long the list wanted to be
-    }
+    for (uint32_t k = (uint32_t)tid; k < nch; k += 256u) trow[k] = 0u;
+    if (tid == 0) tb.cursor[b] = 0u;
 }
 
 inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
@@ -799,7 +945,8 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
     a.ranges = reinterpret_cast<const uint2*>(b->ranges);
     a.point_list = b->point_list;
     a.tile_order = b->tile_order;
-    a.rec = reinterpret_cast<const float4*>(g->rec);
+    a.rec_test = reinterpret_cast<const float4*>(g->rec_test);
+    a.rec_shade = reinterpret_cast<const float4*>(g->rec_shade);
     a.texture = in->texture;
     a.bg = f->bg;
     return a;
@@ -808,11 +955,14 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
 inline TexBinArgs make_bins(const CamConst& c, const TexGSGrads* gr) {
     TexBinArgs tb;
     tb.nb = (c.R + 31) >> 5;
-    const bool on = gr->tex_bins != nullptr && gr->tex_bin_cursor != nullptr && gr->tex_bin_cap > 0;
-    tb.rec = on ? gr->tex_bins : nullptr;
+    const bool on = gr->tex_bins != nullptr && gr->tex_bin_cursor != nullptr && gr->tex_bin_table != nullptr &&
+                    gr->tex_pool_chunks > 0 && gr->tex_bin_slots > 0;
+    tb.pool = on ? gr->tex_bins : nullptr;
     tb.cursor = on ? gr->tex_bin_cursor : nullptr;
+    tb.table = on ? gr->tex_bin_table : nullptr;
     tb.stats = on ? gr->tex_bin_cursor + tex_bin_count(c.R) : nullptr;
-    tb.cap = on ? gr->tex_bin_cap : 0u;
+    tb.pool_chunks = on ? gr->tex_pool_chunks : 0u;
+    tb.slots = on ? gr->tex_bin_slots : 0u;      // <= 2048 (checked in abi.hip): <= 2^20 records per list, the reduce's fixed point cannot overflow
     return tb;
 }
 
@@ -825,34 +975,22 @@ size_t tex_bin_count(int R) {
 
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
-    PixArgs a = make_pix(c, f, in, g, b);
-#ifdef TEXGS_EXPERIMENTS     // critical-path experiments: blend only the K longest tile lists (results are wrong by construction)
-    if (getenv("TEXGS_MAXTILES_FWD")) a.num_tiles = min(a.num_tiles, atoi(getenv("TEXGS_MAXTILES_FWD")));
-#endif
-    hipLaunchKernelGGL(k_render_fwd, dim3(blend_grid(a.num_tiles)), dim3(TG_WG_THREADS), 0, s, a, img->out_color, img->out_depth,
+    const PixArgs a = make_pix(c, f, in, g, b);
+    hipLaunchKernelGGL(k_render_fwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
                        img->out_norm, img->out_alpha, img->final_T, img->n_contrib);
 }
 
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
-    PixArgs a = make_pix(c, f, in, g, b);
-#ifdef TEXGS_EXPERIMENTS
-    if (getenv("TEXGS_MAXTILES_BWD")) a.num_tiles = min(a.num_tiles, atoi(getenv("TEXGS_MAXTILES_BWD")));
-#endif
-    hipLaunchKernelGGL(k_render_bwd, dim3(blend_grid(a.num_tiles)), dim3(TG_WG_THREADS), 0, s, a, make_bins(c, gr), img->final_T,
+    const PixArgs a = make_pix(c, f, in, g, b);
+    hipLaunchKernelGGL(k_render_bwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, make_bins(c, gr), img->final_T,
                        img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture);
 }
 
+bool tex_bins_enabled(const CamConst& c, const TexGSGrads* gr) { return make_bins(c, gr).pool != nullptr; }
+
 void launch_texgrad_reduce(const CamConst& c, TexGSGrads* gr, hipStream_t s) {
     const TexBinArgs tb = make_bins(c, gr);
-    if (!tb.rec) return;
+    if (!tb.pool) return;
     hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(256), 0, s, c.R, tb, gr->dL_dtexture);
 }
-
-#ifdef K7_STATS
-extern "C" int texgs_debug_k7_stats(unsigned long long* out16, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_k7_stats), 16 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) { unsigned long long z[16] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_k7_stats), z, sizeof(z)); }
-    return (int)e;
-}
-#endif

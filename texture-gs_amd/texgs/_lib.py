@@ -6,10 +6,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 ERR_CAPACITY = 1000
 TILE = 16
-REC_FLOATS = 32
+REC_TEST_FLOATS = 8
+REC_SHADE_FLOATS = 20
+TEXBIN_CHUNK_RECORDS = 512
+TEXBIN_RECORD_FLOATS = 5
+TEXBIN_CHUNK_FLOATS = TEXBIN_CHUNK_RECORDS * TEXBIN_RECORD_FLOATS
 ACC_FLOATS = 32
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -28,7 +32,7 @@ class Inputs(C.Structure):
 
 
 class Geom(C.Structure):
-    _fields_ = [("rec", _fp), ("depth", _fp), ("radii", _fp), ("rect", _fp), ("tiles_touched", _fp),
+    _fields_ = [("rec_test", _fp), ("rec_shade", _fp), ("depth", _fp), ("radii", _fp), ("rect", _fp), ("tiles_touched", _fp),
                 ("offsets", _fp), ("scan_temp", _fp), ("scan_temp_bytes", C.c_size_t)]
 
 
@@ -46,7 +50,8 @@ class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
                 ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
-                ("dL_dcolor_offset", _fp), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_cap", C.c_uint32),
+                ("dL_dcolor_offset", _fp), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_table", _fp),
+                ("tex_pool_chunks", C.c_uint32), ("tex_bin_slots", C.c_uint32),
                 ("accumulate", C.c_int32)]
 
 

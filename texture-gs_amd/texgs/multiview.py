@@ -88,8 +88,22 @@ class GradBucket:
                 p.grad = self.flat[off:off + n].view_as(p)
 
     def all_reduce(self, dist, average_over: int = 0):
-        """SUM over ranks (one collective).  average_over > 0 divides by that count afterwards (mean-of-views)."""
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        """SUM over ranks (one collective).  average_over > 0 divides by that count afterwards (mean-of-views).
+
+        Backend "nccl" (= RCCL over xGMI) reduces the device buffer in place.  Any other backend (gloo: the CPU tests, and
+        the single-GPU rehearsal where two ranks share one device -- RCCL refuses that) goes through a pinned host copy."""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        else:
+            if self.flat.is_cuda:
+                if getattr(self, "_host", None) is None:
+                    self._host = torch.empty(self.flat.shape, dtype=torch.float32).pin_memory()
+                self._host.copy_(self.flat, non_blocking=True)
+                torch.cuda.current_stream(self.flat.device).synchronize()
+                dist.all_reduce(self._host, op=dist.ReduceOp.SUM)
+                self.flat.copy_(self._host, non_blocking=True)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if average_over:
             self.flat.div_(float(average_over))
         return self.flat
@@ -121,6 +135,20 @@ class ViewPipeline:
             raise ValueError("depth must be >= 1")
         self.device = torch.device(device)
         self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)] if depth > 1 else []
+
+    def close(self):
+        """Free the backward scratch (moment accumulators, texture-gradient bins) cached for this pipeline's streams."""
+        from . import rasterizer
+        for s in self.streams:
+            s.synchronize()
+            rasterizer.release_scratch(self.device, s.cuda_stream)
+        self.streams = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def run(self, views, forward_fn, backward_fn=None, sink=None, order="accumulate"):
         """order (what of view i+1 waits for view i when both add into `sink`):

@@ -17,8 +17,12 @@ from . import _lib
 
 import os as _os
 USE_TEX_BINS = _os.environ.get("TEXGS_TEX_BINS", "1") != "0"       # binned two-pass texture gradient
-TEX_BIN_CAP = int(_os.environ.get("TEXGS_BIN_CAP", "0"))           # fixed slots per bin (tests); 0 = adaptive
-TEX_BIN_BYTES_MAX = int(float(_os.environ.get("TEXGS_BIN_GB_MAX", "16")) * (1 << 30))
+TEX_POOL_CHUNKS = int(_os.environ.get("TEXGS_POOL_CHUNKS", "0"))   # fixed pool size in chunks (tests); 0 = adaptive
+TEX_BIN_SLOTS = int(_os.environ.get("TEXGS_BIN_SLOTS", "128"))     # chunk-table entries per bin (x 512 records)
+DIRECT_LEAF_GRADS = _os.environ.get("TEXGS_DIRECT_LEAF_GRADS", "1") != "0"   # add into a leaf's existing .grad in place
+TEX_POOL_BYTES_MAX = int(float(_os.environ.get("TEXGS_BIN_GB_MAX", "4")) * (1 << 30))
+# per-Gaussian gradient outputs in the order / bit positions of TEXGS_ACC_* (texgs.h)
+_ACC_BITS = dict(means3D=1, means2D=2, shs=4, opacities=8, scales=16, rotations=32, uvs=64, color_offset=128)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -52,47 +56,86 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
 
 
 _CAPACITY_HINT = {}
-_TEX_BINS = {}
-_ACC_SCRATCH = {}       # (device, N, stream) -> f32[N,32] moment accumulators, all-zero between calls (K8 clears what it read)
+# Backward scratch, ONE entry per (device, HIP stream): the moment accumulators (grow-only, sliced [:N]; all-zero between
+# calls: K8 clears what it read) and the texture-gradient bins of the last resolution used on that stream.  A stream runs
+# its views in order, so its scratch is never shared by two views in flight.  release_scratch() drops entries (ViewPipeline
+# does that for its streams when it is closed / collected).
+_SCRATCH = {}
+
+
+class _StreamScratch:
+    __slots__ = ("acc", "bins")
+
+    def __init__(self):
+        self.acc = None
+        self.bins = None
+
+
+def release_scratch(device=None, stream=None):
+    """Free the backward scratch cached for (device, stream); None = every device / every stream."""
+    for key in list(_SCRATCH):
+        if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == int(stream)):
+            del _SCRATCH[key]
+
+
+def scratch_bytes():
+    """Bytes currently held by the cached backward scratch (diagnostics / tests)."""
+    total = 0
+    for sc in _SCRATCH.values():
+        if sc.acc is not None:
+            total += sc.acc.numel() * 4
+        if sc.bins is not None:
+            total += sc.bins.nbytes()
+    return total
 
 
 class _TexBins:
-    """Persistent scratch of the binned texture gradient for one (device, R, stream): record lists + cursors
-    (TexGSGrads.tex_bins / tex_bin_cursor).  The cursors are all-zero between calls (the reduce kernel clears them), the
-    records need no initialisation.  `cap` (slots per bin) adapts: a list that overflowed leaves its wanted length in
-    the word after the cursors (atomicMax); it is copied to pinned host memory asynchronously every few calls and
-    looked at only when that copy has completed -- the backward never waits for it.  A full bin is not an error (the
-    excess goes through atomics), so a stale `cap` costs speed, never correctness."""
+    """Scratch of the binned texture gradient for one (device, R, stream): the record POOL (fixed-size chunks taken with one
+    atomic counter), the per-bin cursors + four status words, and the per-bin chunk table (TexGSGrads.tex_bins /
+    tex_bin_cursor / tex_bin_table).  Cursors and table are all-zero between calls (the reduce kernel clears what it read),
+    the pool needs no initialisation.  The pool size adapts: every call leaves the number of chunks it wanted in the word
+    after the cursors; it is copied to pinned host memory asynchronously every few calls and looked at only when that copy
+    has completed -- the backward never waits for it.  An exhausted pool is not an error (the excess goes through
+    atomics), so a stale size costs speed, never correctness."""
 
     def __init__(self, lib, device, R):
         self.device, self.R = device, R
         self.nbins = int(lib.texgs_tex_bin_count(R))
-        self.cursor = torch.zeros(self.nbins + 2, dtype=torch.int32, device=device)
-        self.cap = 0
-        self.rec = None
-        self._resize(TEX_BIN_CAP or 8192)
-        self.host_max = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.slots = max(1, min(TEX_BIN_SLOTS, 2048))
+        self.cursor = torch.zeros(self.nbins + 4, dtype=torch.int32, device=device)
+        self.table = torch.zeros(self.nbins * self.slots, dtype=torch.int32, device=device)
+        self.chunks = 0
+        self.pool = None
+        # first guess: every bin gets two chunks (a partial one is always there) -- 0.15 GB at R = 1024
+        self._resize(TEX_POOL_CHUNKS or 2 * self.nbins)
+        self.host_stat = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.event = None
         self.calls = 0
 
-    def _resize(self, cap):
-        cap = max(4, min(int(cap), TEX_BIN_BYTES_MAX // (24 * self.nbins)))
-        if cap != self.cap:
-            self.rec = None
-            self.rec = torch.empty(self.nbins * 6 * cap, dtype=torch.float32, device=self.device)
-            self.cap = cap
+    def nbytes(self):
+        return (self.pool.numel() + self.cursor.numel() + self.table.numel()) * 4
+
+    def _resize(self, chunks):
+        chunks = max(4, min(int(chunks), TEX_POOL_BYTES_MAX // (4 * _lib.TEXBIN_CHUNK_FLOATS)))
+        if chunks != self.chunks:
+            self.pool = None
+            self.pool = torch.empty(chunks * _lib.TEXBIN_CHUNK_FLOATS, dtype=torch.float32, device=self.device)
+            self.chunks = chunks
 
     def before_call(self):
         if self.event is not None and self.event.query():
             self.event = None
-            longest = int(self.host_max[0])
-            if not TEX_BIN_CAP and longest > self.cap:
-                self._resize(1 << int(math.ceil(math.log2(longest * 1.25))))
+            wanted, err = int(self.host_stat[0]), int(self.host_stat[3])
+            if err:
+                raise RuntimeError("texture-gradient bins: a chunk hand-off timed out inside k_render_bwd (sticky flag); "
+                                   "the affected footprints went through atomics -- please report")
+            if not TEX_POOL_CHUNKS and wanted > self.chunks:
+                self._resize(int(wanted * 1.25) + 64)
 
     def after_call(self):
         self.calls += 1
-        if self.event is None and not TEX_BIN_CAP and (self.calls <= 4 or self.calls % 16 == 0):
-            self.host_max.copy_(self.cursor[self.nbins:self.nbins + 1], non_blocking=True)
+        if self.event is None and (self.calls <= 4 or self.calls % 16 == 0):
+            self.host_stat.copy_(self.cursor[self.nbins:self.nbins + 4], non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(self.device))
 
@@ -169,7 +212,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         # per-Gaussian state
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
-        rec = torch.empty(max(N, 1), _lib.REC_FLOATS, **f32)
+        rec = torch.empty(max(N, 1), _lib.REC_TEST_FLOATS, **f32)           # test records: xy, conic, opacity, cull aids
+        rec_shade = torch.empty(max(N, 1), _lib.REC_SHADE_FLOATS, **f32)
         depth = torch.empty(max(N, 1), **f32)
         radii = torch.empty(N, **i32)          # K1 writes every entry (0 for culled)
         rect = torch.empty(max(N, 1), 2, **i32)
@@ -177,7 +221,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         offsets = torch.empty(max(N, 1), **i32)
         scan_bytes = lib.texgs_scan_temp_bytes(N)
         scan_temp = torch.empty(scan_bytes, dtype=torch.uint8, device=device)
-        geom = _lib.Geom(_ptr(rec), _ptr(depth), _ptr(radii), _ptr(rect), _ptr(tiles_touched), _ptr(offsets),
+        geom = _lib.Geom(_ptr(rec), _ptr(rec_shade), _ptr(depth), _ptr(radii), _ptr(rect), _ptr(tiles_touched), _ptr(offsets),
                          _ptr(scan_temp), scan_bytes)
         # everything is allocated BEFORE the one device->host sync, the D-sized buffers from a capacity hint
         # (largest D seen on this device x 1.25): texgs_forward then runs K1 -> sync -> K3..K6 with no host work between
@@ -220,7 +264,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
-    s.tensors = dict(keep=keep, rec=rec, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
+    s.tensors = dict(keep=keep, rec=rec, rec_shade=rec_shade, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
                      offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s,
                      point_list=point_list, ranges=ranges, tile_order=tile_order,
                      final_T=final_T, n_contrib=n_contrib,
@@ -235,9 +279,10 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     `before_accumulate` (optional callable): invoked between K7 + bin reduce and K8 -- the point where a multi-view
     pipeline makes this stream wait for the previous view's K8 (texgs.multiview.ViewPipeline).
 
-    `sinks` (optional): dict name -> existing float32 gradient buffer of the input's shape.  If EVERY per-Gaussian
-    output has a sink the kernels ADD into them (fused multi-view accumulation, TexGSGrads.accumulate = 1); a texture
-    sink is used independently (dL_dtexture is always accumulated into).  Outputs written into a sink come back as None."""
+    `sinks` (optional): dict name -> existing float32 gradient buffer of the input's shape.  K8 ADDS into the sink of
+    every per-Gaussian output that has one (TexGSGrads.accumulate bit mask: fused multi-view accumulation, or a leaf's
+    existing .grad) and writes the others into one fresh allocation; a texture sink is used the same way (dL_dtexture is
+    always accumulated into).  Outputs written into a sink come back as None."""
     lib = _lib.load()
     means3D = s.tensors["keep"][0]
     device = means3D.device
@@ -254,41 +299,44 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     H, W = s.H, s.W
     dc, dd, dn, da = g(dL_dcolor, (3, H, W)), g(dL_ddepth, (1, H, W)), g(dL_dnorm, (3, H, W)), g(dL_dalpha, (1, H, W))
     with torch.cuda.device(device):
-        akey = (device.index, N, stream)
-        acc = _ACC_SCRATCH.pop(akey, None)
-        if acc is None:
-            acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
+        skey = (device.index, int(stream))
+        sc = _SCRATCH.pop(skey, None) or _StreamScratch()     # re-cached only after a successful call (an exception drops it)
+        if sc.acc is None or sc.acc.shape[0] < max(N, 1):
+            sc.acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
+        acc = sc.acc
         sinks = sinks or {}
         has_coff = s.tensors["keep"][8] is not None
-        per_gauss = ["means3D", "means2D", "opacities", "scales", "rotations", "uvs"] + (["shs"] if K > 0 else []) \
-            + (["color_offset"] if has_coff else [])
-        fused = all(n in sinks for n in per_gauss)
-
-        def out(name, *shape):
-            if fused:
-                t = sinks[name]
-                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == math.prod(shape), name
-                return t
-            return torch.empty(*shape, **f32)
-        d_means3D = out("means3D", N, 3)
-        d_means2D = out("means2D", N, 3)
-        d_shs = out("shs", N, K, 3) if K > 0 else None
-        d_op = out("opacities", N, 1)
-        d_scales = out("scales", N, 3)
-        d_rot = out("rotations", N, 4)
-        d_uvs = out("uvs", N, 3)
-        d_coff = out("color_offset", N, 3) if has_coff else None
+        shapes = dict(means3D=(N, 3), means2D=(N, 3), opacities=(N, 1), scales=(N, 3), rotations=(N, 4), uvs=(N, 3))
+        if K > 0:
+            shapes["shs"] = (N, K, 3)
+        if has_coff:
+            shapes["color_offset"] = (N, 3)
+        # one allocation for every per-Gaussian output without a sink
+        fresh = [n for n in shapes if n not in sinks]
+        flat = torch.empty(sum(math.prod(shapes[n]) for n in fresh), **f32) if fresh else None
+        outs, off, mask = {}, 0, 0
+        for n, shp in shapes.items():
+            if n in sinks:
+                t = sinks[n]
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == math.prod(shp), n
+                outs[n] = t
+                mask |= _ACC_BITS[n]
+            else:
+                cnt = math.prod(shp)
+                outs[n] = flat[off:off + cnt].view(shp)
+                off += cnt
         tex_sink = sinks.get("texture")
         d_tex = tex_sink if tex_sink is not None else torch.zeros(6, R, R, 3, **f32)
-        bkey = (device.index, R, stream)
         bins = None
         if USE_TEX_BINS:
-            bins = _TEX_BINS.pop(bkey, None) or _TexBins(lib, device, R)
+            bins = sc.bins if (sc.bins is not None and sc.bins.R == R) else _TexBins(lib, device, R)
+            sc.bins = None
             bins.before_call()
-        grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(d_means3D), _ptr(d_means2D),
-                           _ptr(d_shs), _ptr(d_op), _ptr(d_scales), _ptr(d_rot), _ptr(d_uvs), _ptr(d_tex), _ptr(d_coff),
-                           _ptr(bins.rec) if bins else None, _ptr(bins.cursor) if bins else None, bins.cap if bins else 0,
-                           1 if fused else 0)
+        grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(outs["means3D"]), _ptr(outs["means2D"]),
+                           _ptr(outs.get("shs")), _ptr(outs["opacities"]), _ptr(outs["scales"]), _ptr(outs["rotations"]),
+                           _ptr(outs["uvs"]), _ptr(d_tex), _ptr(outs.get("color_offset")),
+                           _ptr(bins.pool) if bins else None, _ptr(bins.cursor) if bins else None,
+                           _ptr(bins.table) if bins else None, bins.chunks if bins else 0, bins.slots if bins else 0, mask)
         if before_accumulate is None:
             _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                           C.byref(s.img), C.byref(grads), stream), "texgs_backward")
@@ -298,30 +346,36 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
             before_accumulate()
             _lib.check(lib.texgs_backward_preprocess(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom),
                                                      C.byref(grads), stream), "texgs_backward_preprocess")
-    _ACC_SCRATCH[akey] = acc                 # only re-cached after a successful call (an exception drops it)
     if bins is not None:
         bins.after_call()
-        _TEX_BINS[bkey] = bins               # only re-cached after a successful call (an exception drops it)
-    if fused:
-        d_means3D = d_means2D = d_shs = d_op = d_scales = d_rot = d_uvs = d_coff = None
-    if tex_sink is not None:
-        d_tex = None
-    s.tensors["d_color_offset"] = d_coff
-    return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex
+        sc.bins = bins
+    _SCRATCH[skey] = sc
+    res = {n: (None if n in sinks else outs[n]) for n in shapes}
+    s.tensors["d_color_offset"] = res.get("color_offset")
+    return (res["means3D"], res["means2D"], res.get("shs"), res["opacities"], res["scales"], res["rotations"], res["uvs"],
+            None if tex_sink is not None else d_tex)
+
+
+def _leaf_grad_sink(t):
+    """A leaf's existing, contiguous float32 .grad of the right shape (the kernels then add into it directly: no zero-filled
+    temporary, no AccumulateGrad pass), else None."""
+    if t is None or not (t.is_leaf and t.requires_grad):
+        return None
+    gr = t.grad
+    if gr is None or gr.dtype != torch.float32 or not gr.is_contiguous() or gr.shape != t.shape or gr.device != t.device:
+        return None
+    return gr
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None,
                 grad_sink=None):
-        ctx.sinks = None
         ctx.grad_sink = grad_sink
         ctx.set_materialize_grads(False)     # outputs without an upstream gradient arrive as None, not as zero-filled tensors
-        if grad_sink is not None:        # fused accumulation: inputs that ARE registered leaves get their .grad slice
-            named = dict(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales,
+        # the inputs by name: the backward looks at them again (bucket slices / leaf .grad buffers to accumulate into)
+        ctx.named = dict(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales,
                          rotations=rotations, uvs=uvs, texture=texture, color_offset=color_offset)
-            ctx.sinks = {k: g for k, g in ((k, grad_sink.sink_for(v)) for k, v in named.items() if v is not None)
-                         if g is not None}
         outs, state = forward_raw(st, means3D.detach(), None if shs is None else shs.detach(),
                                   opacities.detach(), scales.detach(), rotations.detach(), uvs.detach(),
                                   gradient_uvs.detach(), texture.detach(),
@@ -347,12 +401,24 @@ class _RasterizeGaussians(torch.autograd.Function):
             if t._version != v:
                 raise RuntimeError("an input of the rasterizer was modified in place between its forward and backward "
                                    "(the backward re-reads inputs through saved pointers); clone it before modifying")
+        # where the gradients go: (1) the slices of a texgs.multiview.GradBucket (fused multi-view accumulation) when one is
+        # attached; (2) otherwise, for an input that is a LEAF whose .grad already exists, that .grad itself -- the kernels add
+        # into it, which is what AccumulateGrad would do with a temporary (a 75 MB zero-fill + add for the texture); (3) fresh
+        # tensors handed back to autograd for everything else.
+        sinks, bucket = {}, False
+        if ctx.grad_sink is not None:
+            sinks = {k: g for k, g in ((k, ctx.grad_sink.sink_for(v)) for k, v in ctx.named.items() if v is not None)
+                     if g is not None}
+            bucket = bool(sinks)
+        if not bucket and DIRECT_LEAF_GRADS:
+            sinks = {k: g for k, g in ((k, _leaf_grad_sink(v)) for k, v in ctx.named.items()) if g is not None}
         d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex = backward_raw(
-            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=ctx.sinks,
-            before_accumulate=getattr(ctx.grad_sink, "before_accumulate", None) if ctx.sinks else None)
+            s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=sinks or None,
+            before_accumulate=getattr(ctx.grad_sink, "before_accumulate", None) if bucket else None)
         d_coff = s.tensors.get("d_color_offset")
         ctx.state = None
         ctx.versions = None
+        ctx.named = None
         if d_op is not None:
             d_op = d_op.reshape(ctx.op_shape)
         return (d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, None, d_tex, None, d_coff, None)
