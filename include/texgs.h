@@ -100,6 +100,17 @@ typedef struct TexGSImage {
     float*    out_alpha;       /* f32[1,H,W]                                                           */
     float*    final_T;         /* f32[H,W]                                                             */
     uint32_t* n_contrib;       /* u32[H,W] 1-based position of the last contributor in the tile list   */
+    uint32_t* tex_bin_count;   /* u32[texgs_tex_bin_count(R)] or NULL.  Non-NULL = "a backward will follow": K6 (which zero-fills it
+                                  first) counts the bilinear footprints per 32x32-texel texture bin, the exact sizes of the
+                                  record lists texgs_backward_render builds.  NULL: forward-only call, or a backward that
+                                  sends every texture-gradient footprint through atomics.                              */
+    /* K6 -> K7 hand-off, all three non-NULL when a backward will follow (else all NULL): K6 culls every tile list against each
+       of the tile's four 8x8 pixel blocks anyway; it leaves the survivors so that K7 replays them instead of culling again. */
+    uint32_t* survivors;       /* u32[2 * 4 * capacity] {Gaussian id, list position} pairs; block (tile, w) owns entries
+                                  [4 * ranges[tile].first + w * len, ... + len), len = the tile's list length; capacity = the
+                                  element count keys_sorted / point_list were sized for                                     */
+    uint16_t* surv_qmask;      /* u16[4 * capacity] bit q: the survivor reaches 4x4 quadrant q of its block                  */
+    uint32_t* surv_count;      /* u32[4 * T] survivors written per block                                                     */
 } TexGSImage;
 
 #define TEXGS_ACC_MEANS3D 1
@@ -129,27 +140,22 @@ typedef struct TexGSGrads {
     float* dL_duvs;            /* f32[N,3]                                                             */
     float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
     float* dL_dcolor_offset;   /* f32[N,3] or NULL                                                     */
-    float*    tex_bins;        /* texture-gradient record POOL, f32[tex_pool_chunks * TEXGS_TEXBIN_CHUNK_FLOATS], or NULL.
+    float*    tex_bins;        /* texture-gradient records, f32[5 * tex_rec_cap] (plane-major), or NULL.
                                   The texture is cut into 32x32-texel blocks ("bins", 6 * ceil(R/32)^2 of them).  K7 appends
                                   one 20-byte record {fx | cell x, fy | cell y, dL/dtexel-colour rgb} per bilinear footprint
-                                  to the list of the bin the footprint is anchored in; a list is a chain of fixed-size chunks
-                                  (512 records, plane-major [5][512]) taken from this pool with one atomic counter, so the
-                                  pool holds what a view actually produces (~0.4 GB at C3) instead of a fixed capacity per
-                                  bin.  The reduce kernel at the end of texgs_backward_render sums each list in LDS and adds
-                                  every texel to dL_dtexture once.  NULL (or 0 chunks) = fp32 atomics straight into
-                                  dL_dtexture (~20 G requests/s memory-side: 0.7 ms per C3 view).  Contents need no
-                                  initialisation.  The 5 low mantissa bits of fx / fy carry the cell (fx, fy keep 18 bits). */
-    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 4]: list lengths, ALL-ZERO on entry and all-zero again on
-                                  return (the reduce clears what it read).  Word [count] receives max(chunks a call wanted)
-                                  (never cleared by the library: the caller sizes the pool from it); [count+1] = bits of
-                                  max |dL/dpixel colour| of the call in flight, [count+2] = pool head of the call in flight
-                                  (both zero on entry and on return); [count+3] = sticky error flag (0 = ok).             */
-    uint32_t* tex_bin_table;   /* u32[texgs_tex_bin_count(R) * tex_bin_slots]: chunk id (1-based) of the k-th chunk of every
-                                  list; ALL-ZERO on entry and all-zero again on return.                                   */
-    uint32_t  tex_pool_chunks; /* chunks in the pool.  An exhausted pool is not an error: the excess footprints fall back
-                                  to atomics (and word [count] tells the caller how many chunks the call wanted).         */
-    uint32_t  tex_bin_slots;   /* chunk-table entries per bin; footprints beyond slots * 512 records of one bin fall back
-                                  to atomics                                                                              */
+                                  to the list of the bin the footprint is anchored in; the lists are contiguous and exactly
+                                  sized from TexGSImage.tex_bin_count (~0.37 GB for a C3 view).  The reduce kernel at the end
+                                  of texgs_backward_render sums each list in LDS and adds every texel to dL_dtexture once.
+                                  NULL (or no counts, or cap 0) = fp32 atomics straight into dL_dtexture (~20 G requests/s
+                                  memory-side: 0.7 ms per C3 view).  Contents need no initialisation.  The 5 low mantissa
+                                  bits of fx / fy carry the cell (fx, fy keep 18 bits, rounded).                         */
+    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: list fill counters, ALL-ZERO on entry and all-zero again on
+                                  return (the reduce clears what it read).  Word [count] receives max(records a call needed)
+                                  (never cleared by the library: the caller sizes tex_rec_cap from it); [count+1] = bits of
+                                  max |dL/dpixel colour| of the call in flight (zero on entry; K8 clears it).             */
+    uint32_t* tex_bin_base;    /* u32[texgs_tex_bin_count(R) + 1]: scratch, list offsets of this call (no initialisation)    */
+    uint32_t  tex_rec_cap;     /* records tex_bins holds.  Too small is not an error: footprints that do not fit fall back
+                                  to atomics.                                                                            */
     int32_t accumulate;        /* bit mask (TEXGS_ACC_*): K8 ADDS into the per-Gaussian outputs whose bit is set (fused gradient
                                   accumulation of a multi-view step, or straight into a leaf's existing .grad; culled Gaussians
                                   write nothing there) and overwrites the others.  dL_dtexture is always accumulated into.   */
@@ -161,9 +167,7 @@ const char* texgs_last_error(void);
 size_t texgs_scan_temp_bytes(int32_t num_gaussians);
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
 size_t texgs_tex_bin_count(int32_t tex_res);
-#define TEXGS_TEXBIN_CHUNK_RECORDS 512
 #define TEXGS_TEXBIN_RECORD_FLOATS 5
-#define TEXGS_TEXBIN_CHUNK_FLOATS (TEXGS_TEXBIN_CHUNK_RECORDS * TEXGS_TEXBIN_RECORD_FLOATS)
 
 /* K1: frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold, depth sort key, and
  * D = sum of tiles_touched (device word).  Replaces the first half of _C.rasterize_gaussians. */

@@ -44,7 +44,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
         for fname, _ in cls._fields_:
             lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
-    lines.append('printf("consts %d %d %d %d %d %d %d\\n", TEXGS_ABI_VERSION, TEXGS_TILE, TEXGS_REC_TEST_FLOATS, TEXGS_REC_SHADE_FLOATS, TEXGS_ACC_FLOATS, TEXGS_TEXBIN_CHUNK_RECORDS, TEXGS_TEXBIN_RECORD_FLOATS);')
+    lines.append('printf("consts %d %d %d %d %d %d\\n", TEXGS_ABI_VERSION, TEXGS_TILE, TEXGS_REC_TEST_FLOATS, TEXGS_REC_SHADE_FLOATS, TEXGS_ACC_FLOATS, TEXGS_TEXBIN_RECORD_FLOATS);')
     lines.append('return 0; }')
     src = tmp_path / "layout.c"
     src.write_text("\n".join(lines))
@@ -57,7 +57,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"][0]) == getattr(cls, fname).offset, (cname, fname)
     assert [int(x) for x in got["consts"]] == [_lib.ABI_VERSION, _lib.TILE, _lib.REC_TEST_FLOATS, _lib.REC_SHADE_FLOATS,
-                                               _lib.ACC_FLOATS, _lib.TEXBIN_CHUNK_RECORDS, _lib.TEXBIN_RECORD_FLOATS]
+                                               _lib.ACC_FLOATS, _lib.TEXBIN_RECORD_FLOATS]
 
 
 def test_header_is_plain_c(tmp_path):

@@ -286,43 +286,78 @@ def test_c5_full_size_vs_c_oracle(lib_built):
 
 
 def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
-    """The binned two-pass texture gradient (records -> chunk pool -> per-bin LDS reduce) against its own fallbacks: a pool
-    of 4 chunks (most footprints overflow to atomics), one chunk-table slot per bin (everything beyond 512 records of a bin
-    overflows), and bins disabled (every footprint through atomics).  Same sums; cursors / tables left clean."""
+    """The binned two-pass texture gradient (K6 counts -> offsets -> K7 records -> per-bin LDS reduce) against its own
+    fallbacks: a record buffer of 2000 slots (most footprints overflow to atomics) and bins disabled (every footprint
+    through atomics).  Same sums; cursors left clean; the counted list sizes are exactly what K7 appends."""
     from texgs import rasterizer as RZ
     dev = torch.device("cuda:0")
     scene = synth.make_scene(3000, 96, seed=12, scale_mean=0.03)       # R = 96: 3x3 bins per face
     scene2 = synth.make_scene(3000, 80, seed=12, scale_mean=0.03)      # R = 80: partial bins at the right / bottom edge
     cam = synth.fibonacci_cameras(4, 240, 176)[3]
     target, nhat = synth.make_targets(176, 240, seed=4)
-    saved = (RZ.USE_TEX_BINS, RZ.TEX_POOL_CHUNKS, RZ.TEX_BIN_SLOTS)
+    saved = (RZ.USE_TEX_BINS, RZ.TEX_REC_CAP)
     for sc in (scene, scene2):
         res = {}
-        for mode, (use, pool, slots) in dict(bins=(True, 0, 128), tinypool=(True, 4, 128), oneslot=(True, 0, 1),
-                                             off=(False, 0, 128)).items():
-            RZ.USE_TEX_BINS, RZ.TEX_POOL_CHUNKS, RZ.TEX_BIN_SLOTS = use, pool, slots
+        for mode, (use, cap) in dict(bins=(True, 0), tiny=(True, 2000), off=(False, 0)).items():
+            RZ.USE_TEX_BINS, RZ.TEX_REC_CAP = use, cap
             RZ.release_scratch()
             try:
                 _, g = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)
-                _, g2 = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)   # cursors / tables were left clean
+                _, g2 = Hh.hip_run(sc, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)   # cursors were left clean
                 if use:
                     torch.cuda.synchronize()
                     (sc_,) = RZ._SCRATCH.values()
                     nb = sc_.bins.nbins
-                    assert int(sc_.bins.cursor[:nb].abs().sum()) == 0 and int(sc_.bins.table.abs().sum()) == 0, mode
-                    assert int(sc_.bins.cursor[nb + 1]) == 0 and int(sc_.bins.cursor[nb + 2]) == 0 and int(sc_.bins.cursor[nb + 3]) == 0, mode
-                    if mode == "tinypool":
-                        assert int(sc_.bins.cursor[nb]) > 4      # the call wanted more chunks than the pool had
+                    assert int(sc_.bins.cursor[:nb].abs().sum()) == 0 and int(sc_.bins.cursor[nb + 1]) == 0, mode
+                    wanted = int(sc_.bins.cursor[nb])
+                    assert wanted == int(sc_.bins.base[nb]) > 2000          # list sizes of the last call: what K6 counted
             finally:
-                RZ.USE_TEX_BINS, RZ.TEX_POOL_CHUNKS, RZ.TEX_BIN_SLOTS = saved
+                RZ.USE_TEX_BINS, RZ.TEX_REC_CAP = saved
                 RZ.release_scratch()
             assert Hh.rel_err(g2["texture"], g["texture"]) < 1e-5, mode
             res[mode] = g
-        for mode in ("tinypool", "oneslot", "off"):
+        for mode in ("tiny", "off"):
             for name in ("texture", "uvs", "means3D"):
                 r = Hh.rel_err(res[mode][name], res["bins"][name])
                 Hh.report(f"texture_bins/{mode}_vs_bins/R{sc.texture.shape[1]}/{name}", rel_l2=r)
                 assert r < 1e-5, (mode, name, r)
+
+
+def test_texture_gradient_counts_and_no_count_path(lib_built):
+    """K6's per-bin footprint counts are deterministic; a forward-only call keeps neither them nor the survivor lists (its
+    backward is refused); a backward without the counts (every footprint through atomics) equals the binned one."""
+    from texgs import rasterizer as RZ
+    from texgs.rasterizer import GaussianRasterizationSettings, forward_raw, backward_raw
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(4000, 128, seed=41, scale_mean=0.03)
+    cam = synth.fibonacci_cameras(4, 256, 192)[1]
+    st = Hh.settings_for(cam, 3, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings)
+    t = lambda x: x.to(dev)
+    args = [t(scene.means3D), t(scene.shs), t(scene.opacities), t(scene.scales), t(scene.rotations), t(scene.uvs),
+            t(scene.gradient_uvs), t(scene.texture)]
+    _, s1 = forward_raw(st, *args)
+    _, s2 = forward_raw(st, *args)
+    _, s0 = forward_raw(st, *args, for_backward=False)
+    torch.cuda.synchronize()
+    c1, c2 = s1.tensors["tex_bin_count"], s2.tensors["tex_bin_count"]
+    assert torch.equal(c1, c2) and int(c1.sum()) > 10000
+    assert s0.tensors["tex_bin_count"] is None and s0.tensors["survivors"] is None
+    g = torch.Generator().manual_seed(2)
+    dimg = (torch.randn(3, 192, 256, generator=g) * 1e-4).to(dev)
+    with pytest.raises(RuntimeError, match="for_backward=False"):
+        backward_raw(s0, dimg, None, None, None)
+    RZ.release_scratch()
+    a = backward_raw(s1, dimg, None, None, None)[7]
+    torch.cuda.synchronize()
+    (sc_,) = RZ._SCRATCH.values()
+    assert int(sc_.bins.cursor[sc_.bins.nbins]) == int(c1.sum())       # the lists of that call were exactly the counts
+    s2.tensors["tex_bin_count"] = None                                   # no counts: every footprint through atomics
+    s2.img.tex_bin_count = None
+    b = backward_raw(s2, dimg, None, None, None)[7]
+    torch.cuda.synchronize()
+    r = Hh.rel_err(a, b)
+    Hh.report("texture_bins/counted_vs_atomics", rel_l2=r, records=int(c1.sum()))
+    assert r < 1e-5
 
 
 def test_texture_gradient_scale_is_per_call(lib_built):

@@ -155,6 +155,10 @@ int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const T
     if (!in->texture) return fail_msg("texture is NULL");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
+    if (img->tex_bin_count) {       // K6 counts the texture-gradient footprints per bin into it
+        hipError_t e = hipMemsetAsync(img->tex_bin_count, 0, sizeof(uint32_t) * tex_bin_count(c.R), s);
+        if (e != hipSuccess) return fail("tex_bin_count memset", e);
+    }
     { ProfScope p(TEXGS_K_RENDER_FWD, s); launch_render_fwd(c, frame, in, geom, bin, img, s); }
     return check(frame, s, "render_fwd");
 }
@@ -197,14 +201,16 @@ int texgs_backward_render(const TexGSFrame* frame, const TexGSInputs* in, const 
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !bin || !img || !grads) return fail_msg("NULL argument");
     if (!grads->acc || !grads->dL_dtexture) return fail_msg("acc / dL_dtexture must be allocated (zero-filled)");
-    if (grads->tex_bin_slots > 2048u) return fail_msg("tex_bin_slots must be <= 2048 (2^20 records per bin: the reduce's fixed-point range)");
+    if (!img->survivors || !img->surv_qmask || !img->surv_count)
+        return fail_msg("the forward of this call left no survivor lists (TexGSImage.survivors / surv_qmask / surv_count were NULL): "
+                        "run the forward with them to be able to run its backward");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     if (bin->num_rendered > 0) {
         { ProfScope p(TEXGS_K_RENDER_BWD, s); launch_render_bwd(c, frame, in, geom, bin, img, grads, s); }
         if (int r = check(frame, s, "render_bwd")) return r;
-        if (tex_bins_enabled(c, grads)) {
-            { ProfScope p(TEXGS_K_TEXGRAD_REDUCE, s); launch_texgrad_reduce(c, grads, s); }
+        if (tex_bins_enabled(c, img, grads)) {
+            { ProfScope p(TEXGS_K_TEXGRAD_REDUCE, s); launch_texgrad_reduce(c, img, grads, s); }
             if (int r = check(frame, s, "texgrad_reduce")) return r;
         }
     }

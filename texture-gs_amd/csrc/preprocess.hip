@@ -576,7 +576,7 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
                        gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate,
-                       tex_bins_enabled(c, gr) ? gr->tex_bin_cursor + tex_bin_count(c.R) + 1 : nullptr);
+                       (gr->tex_bins && gr->tex_bin_cursor) ? gr->tex_bin_cursor + tex_bin_count(c.R) + 1 : nullptr);
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

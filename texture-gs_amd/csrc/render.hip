@@ -21,8 +21,11 @@
 // bilinear footprints of a C3 view cost 0.69 ms that way (profiles/r02_ablation.md).  Instead K7 APPENDS a 20-byte
 // record {fx | cell x, fy | cell y, dL/dtexel-colour (3)} per footprint with plain coalesced stores to the list of the
 // 32x32-texel texture block ("bin") the footprint is anchored in -- one returning atomic per (wave round, distinct bin) on
-// the bin's cursor; a list is a chain of 512-record chunks from one pool -- and k_texgrad_reduce then sums each bin's list
-// in LDS and adds every texel of the block to dL_dtexture once.  No MFMA: there is no dense contraction on this path.
+// the bin's cursor -- and k_texgrad_reduce then sums each bin's list in LDS and adds every texel of the block to dL_dtexture
+// once.  The lists are EXACTLY sized: K6 counts the footprints per bin while it renders (one non-returning atomic per
+// (round, distinct bin)), a one-workgroup scan turns the counts into offsets, and the records of a view are one
+// contiguous array (~0.37 GB at C3) -- no per-bin capacity, no chunk tables, nothing to wait for.
+// No MFMA: there is no dense contraction on this path.
 #include "common.h"
 #include "wave_ops.h"
 
@@ -116,6 +119,11 @@ struct PixArgs {
     const float4* rec_shade;    // [N][5]: (g, G0, G1) | (G2..G5) | (phi, vd0) | (vd1, vd2, depth, n0) | (n1, n2, -, -)
     const float* texture;
     const float* bg;
+    // K6 -> K7 hand-off (NULL in a forward-only call): the survivors of every 8x8 block's cull, in list order.  Block (tile, w)
+    // owns entries [4 * range.x + w * len, ... + len) (len = the tile's list length: an upper bound of its survivors).
+    uint2*    surv;          // {Gaussian id, list position}
+    uint16_t* surv_qm;       // bit q: the survivor can reach quadrant q
+    uint32_t* surv_cnt;      // [4 * tiles] survivors written per block
 };
 
 // workgroup (= one wave) -> (tile, 8x8 block).  Tiles are launched longest-list-first (tile_order).  The four blocks of a
@@ -137,6 +145,11 @@ inline int blend_grid(int num_tiles) { return 4 * ((num_tiles + 7) & ~7); }
 __device__ __forceinline__ int mbcnt64(ull m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+
+// Texture bin (32x32-texel block) of a bilinear footprint, and whether the footprint is binned at all (not clamped at a face
+// border: such footprints go straight to dL_dtexture).  K6 counts with this, K7 appends with this: same inputs, same answer.
+__device__ __forceinline__ uint32_t tap_bin(const CubeTap& ct, int nb) { return (uint32_t)((ct.face * nb + (ct.y0 >> 5)) * nb + (ct.x0 >> 5)); }
+__device__ __forceinline__ bool tap_binned(const CubeTap& ct) { return ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1; }
 
 // ---- per-wave LDS layout shared by K6 and K7 ----
 #define TG_RING 128          // survivor queue (raw list positions), power of two >= 127
@@ -199,11 +212,13 @@ struct __attribute__((aligned(16))) FwdLds {
     ull col[64 * 3];                    // 1536: Q32.32 colour sums of the wave's pixels
     uint32_t ring[TG_RING];             //  512
     uint8_t list[4][64];                //  256: per-quadrant survivor lists, padded with TG_DUMMY
-};                                      // 10096 B -> 16 waves per CU
+    uint32_t cbin[8], ccnt[8];          //   64: footprint-count cache (a block's footprints fall into a handful of texture bins)
+};                                      // 10160 B -> 16 waves per CU
 
 __global__ void __launch_bounds__(64, 4)
 k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_norm,
-             float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+             float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+             uint32_t* __restrict__ bin_count) {
     __shared__ FwdLds L;
     const int lane = (int)threadIdx.x;
     int tile, wave;
@@ -221,8 +236,10 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     const float* __restrict__ tex = a.texture;
     const uint32_t keybase = ((uint32_t)lane << 8) | ((uint32_t)ox << 14) | ((uint32_t)oy << 17);
     const uint8_t* mylist = L.list[lane >> 4];
+    const int nbins_row = (a.R + 31) >> 5;
 
     L.col[lane * 3 + 0] = 0ull; L.col[lane * 3 + 1] = 0ull; L.col[lane * 3 + 2] = 0ull;   // own pixel; only this wave touches it
+    if (lane < 8) { L.cbin[lane] = 0xFFFFFFFFu; L.ccnt[lane] = 0u; }
     init_dummy(L.p, lane);
     __builtin_amdgcn_wave_barrier();
 
@@ -276,26 +293,59 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             p00 = load_texel(tex, ct.o00); p01 = load_texel(tex, ct.o01);
             p10 = load_texel(tex, ct.o10); p11 = load_texel(tex, ct.o11);
         }
+        if (bin_count != nullptr) {
+            // a backward will follow: count this round's footprints per texture bin (sizes of K7's record lists).  Lanes are
+            // grouped by bin with ballots; the group's size goes to a small per-wave LDS cache (8 entries, hashed by bin) that is
+            // flushed with one atomic per entry on a conflict and at the end: global atomics execute memory-side (~700 k of
+            // them per view cost 80 us), a block's footprints fall into a handful of bins.
+            const bool binned = (lane < n_) && tap_binned(ct);
+            const uint32_t bin = tap_bin(ct, nbins_row);
+            ull pend = TG_BALLOT(binned);
+            while (pend != 0ull) {
+                const int l0 = __ffsll((long long)pend) - 1;
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
+                const ull m = TG_BALLOT(binned && bin == b0);
+                if (lane == l0) {
+                    const uint32_t n = (uint32_t)__popcll(m), e = (b0 ^ (b0 >> 5)) & 7u, ob = L.cbin[e];
+                    if (ob == b0) L.ccnt[e] += n;
+                    else {
+                        if (ob != 0xFFFFFFFFu) atomicAdd(bin_count + ob, L.ccnt[e]);
+                        L.cbin[e] = b0; L.ccnt[e] = n;
+                    }
+                }
+                pend &= ~m;
+            }
+        }
         p_w = __uint_as_float(e_.x); p_pl = KEY_PL(e_.y); p_fx = ct.fx; p_fy = ct.fy; p_vd0 = f_.w; p_vd1 = g2.x; p_vd2 = g2.y;
         pn = n_;
     };
 
+    const size_t sbase = 4 * (size_t)range.x + (size_t)wave * (size_t)todo;       // this block's survivor entries (K6 -> K7)
+    int nsurv = 0;
     int r = 0, nq = 0, qh = 0;                 // next raw list position, survivors queued, queue head (all wave-uniform)
-    uint32_t nid = (lane < todo) ? a.point_list[range.x + lane] : 0u;      // Gaussian ids of the raw batch at r, one batch ahead
+    // the raw batch at r is loaded ONE BATCH AHEAD (ids two ahead): its test records are in flight while the previous batch is culled
+    // and while a chunk is blended
+    const float4 zt0 = make_float4(0.f, 0.f, 0.f, 0.f), zt1 = make_float4(0.f, 0.f, -1.f, 1.f);      // rcull < 0: never reachable
+    float4 nt0 = zt0, nt1 = zt1;
+    if (lane < todo) {
+        const float4* __restrict__ tp = a.rec_test + 2 * (size_t)a.point_list[range.x + lane];
+        nt0 = tp[0]; nt1 = tp[1];
+    }
+    uint32_t nid = (64 + lane < todo) ? a.point_list[range.x + 64 + lane] : 0u;      // Gaussian ids of the batch at r + 64
     bool all_done = (~done_mask == 0ull);
     while (!all_done) {
         // ---- raw batches: 8x8 cull on the 32-byte test records, survivors queued in list order
         while (nq < 64 && r < todo) {
             const int idx = r + lane;
-            const uint32_t id = nid;
+            const float4 t0 = nt0, t1 = nt1;
             r += 64;
-            nid = (r + lane < todo) ? a.point_list[range.x + r + lane] : 0u;
-            bool reach = false;
-            if (idx < todo) {
-                const float4* __restrict__ tp = a.rec_test + 2 * (size_t)id;
-                const float4 t0 = tp[0], t1 = tp[1];
-                reach = block_reachable(t0.x, t0.y, t0.z, t0.w, t1.x, t1.w, t1.z, wpx, wpy, 7.0f);
+            nt0 = zt0; nt1 = zt1;
+            if (r + lane < todo) {
+                const float4* __restrict__ tp = a.rec_test + 2 * (size_t)nid;
+                nt0 = tp[0]; nt1 = tp[1];
             }
+            nid = (r + 64 + lane < todo) ? a.point_list[range.x + r + 64 + lane] : 0u;
+            const bool reach = block_reachable(t0.x, t0.y, t0.z, t0.w, t1.x, t1.w, t1.z, wpx, wpy, 7.0f);
             const ull m = TG_BALLOT(reach);
             if (reach) L.ring[(qh + nq + mbcnt64(m)) & (TG_RING - 1)] = (uint32_t)idx;
             nq += __popcll(m);
@@ -315,14 +365,21 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         reinterpret_cast<uint32_t*>(&L.list[0][0])[lane] = 0x40404040u;      // pad all four lists with TG_DUMMY
         __builtin_amdgcn_wave_barrier();
         int len[4];
+        uint32_t qbits = 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool rowdone = ((done_mask >> (16 * q)) & 0xFFFFull) == 0xFFFFull;
-            const bool rq = (lane < take) && !rowdone &&
+            const bool geo = (lane < take) &&
                 block_reachable(T0.x, T0.y, T0.z, T0.w, T1.x, T1.w, T1.z, wpx + (float)((q & 1) << 2), wpy + (float)((q >> 1) << 2), 3.0f);
+            qbits |= geo ? (1u << q) : 0u;
+            const bool rq = geo && !rowdone;
             const ull m = TG_BALLOT(rq);
             len[q] = __popcll(m);
             if (rq) L.list[q][mbcnt64(m)] = (uint8_t)lane;
+        }
+        if (a.surv != nullptr) {                // a backward will follow: it replays exactly these survivors, back to front
+            if (lane < take) { a.surv[sbase + nsurv + lane] = make_uint2(id, pos); a.surv_qm[sbase + nsurv + lane] = (uint16_t)qbits; }
+            nsurv += take;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- lock-step test loop: iteration t tests list entry t of every quadrant.  Parameters of iteration t + 1 and the
@@ -385,6 +442,8 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     }
     finish();
     __builtin_amdgcn_wave_barrier();
+    if (bin_count != nullptr && lane < 8 && L.cbin[lane] != 0xFFFFFFFFu) atomicAdd(bin_count + L.cbin[lane], L.ccnt[lane]);
+    if (a.surv_cnt != nullptr && lane == 0) a.surv_cnt[4 * tile + wave] = (uint32_t)nsurv;
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
         const double q = 1.0 / 4294967296.0;
@@ -400,7 +459,8 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 }
 
 // ------------------------------------------------------------------------------------------------ K7
-// Backward replay, back to front.  Per chunk of 64 survivors, in segments of at most BQ_CAP items / BWD_MAX_IT iterations:
+// Backward replay, back to front, over the survivor lists K6 left for every 8x8 block (no culling here: K6 culled exactly these
+// lists).  Per chunk of 64 survivors, in segments of at most BQ_CAP items / BWD_MAX_IT iterations:
 //   stage A  lock-step over the four quadrant lists (see the file header), ~45 VALU per iteration: falloff, alpha,
 //            T /= (1 - alpha); contributing (pixel, Gaussian) pairs are compacted (ballot + mbcnt) into the LDS item list
 //            {T, -, alpha_raw, key}; the iteration's ballot and first item stay in the registers of lane <iteration>.
@@ -412,19 +472,17 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //   stage C2 dense over TASKS = the items of one (iteration, quadrant) = up to 16 consecutive items of ONE Gaussian, four
 //            tasks per round (one per DPP row): the 28 per-Gaussian moment terms of every item, a 16-lane transposing butterfly
 //            (DPP only, wave_ops.h), and the 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.
+#ifndef BQ_CAP
 #define BQ_CAP 128
+#endif
 #define BWD_MAX_IT 16
-#define TB_CHUNK_LOG 9
-#define TB_CHUNK (1u << TB_CHUNK_LOG)             // records per pool chunk (= TEXGS_TEXBIN_CHUNK_RECORDS)
-#define TB_NONE 0xFFFFFFFFu                       // chunk-table value: "no chunk, use atomics" (pool exhausted)
-static_assert(TB_CHUNK == TEXGS_TEXBIN_CHUNK_RECORDS, "chunk size");
+#define TB_LIST_MAX (1u << 20)      // records per list the reduce kernel's fixed point can take; the rest of a longer list goes through atomics
 struct TexBinArgs {
-    float*    pool;        // [pool_chunks][5][TB_CHUNK]: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b (plane-major inside a chunk)
-    uint32_t* cursor;      // [nbins] records appended so far (may exceed slots * TB_CHUNK: the excess went to dL_dtexture directly)
-    uint32_t* table;       // [nbins][slots] chunk id + 1 of the list's k-th chunk; 0 = not allocated yet
-    uint32_t* stats;       // [0] max chunks wanted by a call (for the host), [1] bits of max |dL/dpixel colour| of this call,
-                           // [2] pool head of this call, [3] sticky error flag
-    uint32_t  pool_chunks, slots;
+    float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
+    uint32_t* cursor;      // [nbins] records appended so far to each list
+    const uint32_t* base;  // [nbins + 1] exclusive scan of K6's per-bin counts
+    uint32_t* stats;       // [0] max records a call wanted (for the host), [1] bits of max |dL/dpixel colour| of this call
+    uint32_t  cap;         // records the buffer holds; what does not fit goes to dL_dtexture directly
     int       nb;          // bins per face row = ceil(R / 32)
 };
 
@@ -433,31 +491,17 @@ struct __attribute__((aligned(16))) BwdLds {
     Planes p;                           // 6768
     float4 dpix[64];                    // 1024: dL/d(r, g, b, alpha) of the wave's pixels
     float4 dgeo[64];                    // 1024: dL/d(depth, normal)
-    uint32_t ring[TG_RING];             //  512
     uint32_t task[64];                  //  256
     uint8_t list[4][64];                //  256
-};                                      // 16032 B -> 10 waves per CU
+};                                      // 15520 B -> 10 waves per CU
 
-// footprints that cannot be binned (clamped at a face border, pool exhausted, list beyond its table): straight into dL_dtexture
+// footprints that cannot be binned (clamped at a face border, beyond the list / the buffer): straight into dL_dtexture
 __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, int o00, int o01, int o10, int o11, float w00, float w01,
                                                float w10, float w11, float x0, float x1, float x2) {
     unsafeAtomicAdd(dtex + o00, w00 * x0); unsafeAtomicAdd(dtex + o00 + 1, w00 * x1); unsafeAtomicAdd(dtex + o00 + 2, w00 * x2);
     unsafeAtomicAdd(dtex + o01, w01 * x0); unsafeAtomicAdd(dtex + o01 + 1, w01 * x1); unsafeAtomicAdd(dtex + o01 + 2, w01 * x2);
     unsafeAtomicAdd(dtex + o10, w10 * x0); unsafeAtomicAdd(dtex + o10 + 1, w10 * x1); unsafeAtomicAdd(dtex + o10 + 2, w10 * x2);
     unsafeAtomicAdd(dtex + o11, w11 * x0); unsafeAtomicAdd(dtex + o11 + 1, w11 * x1); unsafeAtomicAdd(dtex + o11 + 2, w11 * x2);
-}
-
-// chunk id of a list position whose first record belongs to another wave: that wave publishes it right after its cursor atomic
-// returned and never waits before doing so, hence the wait is short and cannot deadlock; bounded all the same (a spin that
-// runs out raises the sticky error flag and the footprint goes through atomics)
-__device__ __forceinline__ uint32_t wait_chunk(const uint32_t* p, uint32_t* err) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-        const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != 0u) return v;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return TB_NONE;
 }
 
 __global__ void __launch_bounds__(64, 2)
@@ -476,7 +520,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     const int px = wave_px + ox, py = wave_py + oy;
     const bool inside = (px < a.W) && (py < a.H);
     const float pxf = (float)px, pyf = (float)py;
-    const float wpx = (float)wave_px, wpy = (float)wave_py;
     const uint2 range = a.ranges[tile];
     const int todo = (int)(range.y - range.x);
     const int HW = a.W * a.H, pix = py * a.W + px;
@@ -498,7 +541,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     L.dpix[lane] = make_float4(dpix[0], dpix[1], dpix[2], dpix[7]);
     L.dgeo[lane] = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
     init_dummy(L.p, lane);
-    if (tb.pool != nullptr) {
+    if (tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale of THIS
         // call (K8 clears the word after the reduce).  Positive floats order like their bit patterns; the plain read first
         // keeps 10^4 waves off one hot word.
@@ -519,44 +562,150 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     float T = Tfin;
     float behind = Tfin * bgdot;      // sum of s_k alpha_k T_k over the contributors BEHIND the current one, + the background term
 
-    int r = wave_last, nq = 0, qh = 0;            // raw instances [0, r) are still to be culled, from the back
-    uint32_t nid = (r - 1 - lane >= 0) ? a.point_list[range.x + (r - 1 - lane)] : 0u;
-    for (;;) {
-        // ---- raw batches, back to front: 8x8 cull on the test records, survivors queued in reverse list order
-        while (nq < 64 && r > 0) {
-            const int idx = r - 1 - lane;
-            const uint32_t idb = nid;
-            r -= 64;
-            nid = (r - 1 - lane >= 0) ? a.point_list[range.x + (r - 1 - lane)] : 0u;
-            bool reach = false;
-            if (idx >= 0) {
-                const float4* __restrict__ tp = a.rec_test + 2 * (size_t)idb;
-                const float4 t0 = tp[0], t1 = tp[1];
-                reach = block_reachable(t0.x, t0.y, t0.z, t0.w, t1.x, t1.w, t1.z, wpx, wpy, 7.0f);
+    // The survivors of this block's cull come from K6 (it culled exactly this list, at least as far as the last contributor):
+    // chunks of 64 from the back, lane = survivor in descending list position.  The next chunk's entries are loaded one chunk ahead.
+    const size_t sbase = 4 * (size_t)range.x + (size_t)wave * (size_t)todo;
+    const int ns = (int)a.surv_cnt[4 * tile + wave];
+    uint2 nsv = make_uint2(0u, 0xFFFFFFFFu);
+    uint32_t nqm = 0u;
+    if (ns - 1 - lane >= 0) { nsv = a.surv[sbase + (ns - 1 - lane)]; nqm = a.surv_qm[sbase + (ns - 1 - lane)]; }
+    // ---- stage B, as two halves per round of 64 items (see the kernel header): FRONT issues everything that goes to memory,
+    // BACK consumes it.  A segment has at most two rounds: both fronts first (8 tap loads + 2 returning atomics in flight), then
+    // both backs.  (Starting round 0's front inside stage A, as soon as 64 items exist, was measured: K7 732 -> 771 us.)
+    int n_items = 0;
+    struct Round {                                        // what the back half needs, as few registers as possible
+        bool have, binned;
+        int e, pl, jj, my_leader, my_rank, axis;
+        uint32_t bin, slot0, b0, b1;                      // list slot of the group's first record; [b0, b1) = the bin's list
+        uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
+        int o00, dox, doy;                                // tap offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
+        float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
+        float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
+        Texel3 t00, t01, t10, t11;
+    };
+    auto front = [&](int rbase, Round& R) {
+        R.e = rbase + lane;
+        R.have = R.e < n_items;
+        float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (R.have) it = L.items[R.e * 3];
+        const uint32_t key = __float_as_uint(it.w);
+        R.pl = KEY_PL(key);
+        const int jj = KEY_J(key);
+        R.jj = jj;
+        const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj]);
+        const float4 d_ = L.p.D[jj], e4 = L.p.E[jj], f_ = L.p.F[jj];
+        const float2 g2 = L.p.G[jj];
+        R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
+        R.vd0 = f_.w; R.vd1 = g2.x; R.vd2 = g2.y;
+        // UV Taylor step, cubemap address, tap loads
+        const float dpx = (float)(wave_px + KEY_OX(key)) - xy.x, dpy = (float)(wave_py + KEY_OY(key)) - xy.y;
+        const float den = 1.0f + d_.x * dpx + d_.y * dpy;
+        R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+        R.nu0 = d_.z * dpx + d_.w * dpy; R.nu1 = e4.x * dpx + e4.y * dpy; R.nu2 = e4.z * dpx + e4.w * dpy;
+        const CubeTap ct = cube_address(f_.x + R.nu0 * R.inv, f_.y + R.nu1 * R.inv, f_.z + R.nu2 * R.inv, a.R);
+        const Texel3 tz = {0.f, 0.f, 0.f};
+        R.t00 = tz; R.t01 = tz; R.t10 = tz; R.t11 = tz;
+        if (R.have) {
+            R.t00 = load_texel(tex, ct.o00); R.t01 = load_texel(tex, ct.o01);
+            R.t10 = load_texel(tex, ct.o10); R.t11 = load_texel(tex, ct.o11);
+        }
+        R.axis = ct.axis; R.fx = ct.fx; R.fy = ct.fy;
+        R.ka = ct.su * ct.h; R.kb = ct.sv * ct.h;
+        const float km = ct.h * ct.rma * ct.sm;
+        R.kc = ct.sc * km; R.kd = ct.tc * km;
+        R.o00 = ct.o00; R.dox = ct.o01 - ct.o00; R.doy = ct.o10 - ct.o00;
+        // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
+        R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
+        R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
+        // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
+        // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
+        R.binned = R.have && tb.rec != nullptr && tap_binned(ct);
+        R.bin = tap_bin(ct, tb.nb);
+        bool leader = false;
+        R.my_leader = lane; R.my_rank = 0;
+        int my_n = 0;
+        ull pend = TG_BALLOT(R.binned);
+        while (pend != 0ull) {
+            const int l0 = __ffsll((long long)pend) - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
+            const ull m = TG_BALLOT(R.binned && R.bin == b0);
+            if ((m >> lane) & 1ull) {
+                R.my_leader = l0;
+                R.my_rank = mbcnt64(m);
+                if (lane == l0) { leader = true; my_n = __popcll(m); }
             }
-            const ull m = TG_BALLOT(reach);
-            if (reach) L.ring[(qh + nq + mbcnt64(m)) & (TG_RING - 1)] = (uint32_t)idx;
-            nq += __popcll(m);
+            pend &= ~m;
         }
-        if (nq == 0) break;
-        // ---- chunk: up to 64 survivors, lane = survivor (descending list position)
-        const int take = min(64, nq);
+        R.slot0 = 0u; R.b0 = 0u; R.b1 = 0u;
+        if (leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)my_n);
+        if (R.binned) { R.b0 = tb.base[R.bin]; R.b1 = tb.base[R.bin + 1u]; }
+    };
+    auto back = [&](Round& R) {
+        const Texel3 &t00 = R.t00, &t01 = R.t01, &t10 = R.t10, &t11 = R.t11;
+        const float w00 = (1.f - R.fx) * (1.f - R.fy), w01 = R.fx * (1.f - R.fy);
+        const float w10 = (1.f - R.fx) * R.fy,         w11 = R.fx * R.fy;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (R.have) {
+            const float w = R.w;
+            const float4 dp = L.dpix[R.pl];
+            const float d0 = dp.x, d1 = dp.y, d2 = dp.z;
+            const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + R.vd0 + 0.5f;
+            const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + R.vd1 + 0.5f;
+            const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + R.vd2 + 0.5f;
+            const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
+            // colour -> view-dependent term and texture
+            const float dc0 = (pre0 > 0.f) ? w * d0 : 0.f, dc1 = (pre1 > 0.f) ? w * d1 : 0.f, dc2 = (pre2 > 0.f) ? w * d2 : 0.f;
+            x0 = TG_SH_C0 * dc0; x1 = TG_SH_C0 * dc1; x2 = TG_SH_C0 * dc2;
+            const float dLdcol = x0 * ((1.f - R.fy) * (t01.x - t00.x) + R.fy * (t11.x - t10.x))
+                               + x1 * ((1.f - R.fy) * (t01.y - t00.y) + R.fy * (t11.y - t10.y))
+                               + x2 * ((1.f - R.fy) * (t01.z - t00.z) + R.fy * (t11.z - t10.z));
+            const float dLdrow = x0 * ((1.f - R.fx) * (t10.x - t00.x) + R.fx * (t11.x - t01.x))
+                               + x1 * ((1.f - R.fx) * (t10.y - t00.y) + R.fx * (t11.y - t01.y))
+                               + x2 * ((1.f - R.fx) * (t10.z - t00.z) + R.fx * (t11.z - t01.z));
+            const float dua = dLdcol * R.ka, dub = dLdrow * R.kb;
+            const float dum = -(dLdcol * R.kc + dLdrow * R.kd);
+            float du0, du1, du2;
+            if (R.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
+            else if (R.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
+            else                  { du2 = dum; du0 = dua; du1 = dub; }
+            const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
+            // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
+            // recurrence needs from this pair, formed here where all 64 lanes work
+            const float4 c5 = L.p.C[R.jj];
+            const float4 dg = L.dgeo[R.pl];
+            L.items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
+            L.items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
+            L.items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
+        }
+        // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
+        // a face border / does not fit its list or the buffer (still correct, just slow)
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0) + (uint32_t)R.my_rank;
+        const uint32_t pos = R.b0 + slot;
+        if (R.binned && slot < TB_LIST_MAX && pos < R.b1 && pos < tb.cap) {
+            float* __restrict__ rp = tb.rec + pos;
+            rp[0] = __uint_as_float(R.fxw); rp[tb.cap] = __uint_as_float(R.fyw);
+            rp[2 * (size_t)tb.cap] = x0; rp[3 * (size_t)tb.cap] = x1; rp[4 * (size_t)tb.cap] = x2;
+        } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
+            scatter_direct(dtex, R.o00, R.o00 + R.dox, R.o00 + R.doy, R.o00 + R.dox + R.doy, w00, w01, w10, w11, x0, x1, x2);
+        }
+    };
+    for (int hi = ns; hi > 0; hi -= 64) {
+        const bool live = hi - 1 - lane >= 0;
+        const uint32_t id = nsv.x, pos = nsv.y, qm = nqm;
+        nsv = make_uint2(0u, 0xFFFFFFFFu); nqm = 0u;
+        if (hi - 65 - lane >= 0) { nsv = a.surv[sbase + (hi - 65 - lane)]; nqm = a.surv_qm[sbase + (hi - 65 - lane)]; }
+        // survivors behind the block's last contributor (K6 tested them, nothing blended): skip whole chunks of them
+        const int take = min(64, hi);
+        if ((int)__builtin_amdgcn_readlane((int)pos, take - 1) >= wave_last) continue;
         __builtin_amdgcn_wave_barrier();
-        uint32_t pos = 0xFFFFFFFFu, id = 0u;
-        if (lane < take) {
-            pos = L.ring[(qh + lane) & (TG_RING - 1)];
-            id = a.point_list[range.x + pos];
-        }
-        qh = (qh + take) & (TG_RING - 1); nq -= take;
         float4 T0, T1;
-        load_chunk(a, L.p, lane, lane < take, id, pos, T0, T1);
+        load_chunk(a, L.p, lane, live, id, pos, T0, T1);
         reinterpret_cast<uint32_t*>(&L.list[0][0])[lane] = 0x40404040u;
         __builtin_amdgcn_wave_barrier();
         int len[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool rq = (lane < take) && ((int)pos < rowlast[q]) &&
-                block_reachable(T0.x, T0.y, T0.z, T0.w, T1.x, T1.w, T1.z, wpx + (float)((q & 1) << 2), wpy + (float)((q >> 1) << 2), 3.0f);
+            const bool rq = live && ((int)pos < rowlast[q]) && ((qm >> q) & 1u);
             const ull m = TG_BALLOT(rq);
             len[q] = __popcll(m);
             if (rq) L.list[q][mbcnt64(m)] = (uint8_t)lane;
@@ -566,7 +715,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         int t = 0;
         while (t < tmax) {
             // ================================================================ stage A
-            int n_items = 0, n_it = 0;
+            int n_it = 0;
+            n_items = 0;
             uint32_t it_lo = 0u, it_hi = 0u, it_first = 0u;      // lane k: ballot and first item of the segment's k-th productive iteration
             {
                 int cj = mylist[t], nj = mylist[min(t + 1, 63)], nnj = mylist[min(t + 2, 63)];
@@ -599,164 +749,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             __builtin_amdgcn_wave_barrier();
             if (n_items == 0) continue;
             // ================================================================ stage B
-            // A segment holds at most two rounds of 64 items.  Both rounds' FRONT halves run first (addresses, the 4 tap
-            // loads, bin grouping, the cursor atomic: 8 loads + 2 returning atomics in flight), then the chunk bookkeeping of
-            // the record lists (ALLOC for both rounds before either WAITS: a wave never waits on itself), then both BACK halves
-            // (colour / gradient math, record stores).
-            struct Round {                                        // what the back half needs, as few registers as possible
-                bool have, binned, leader;
-                int e, pl, jj, my_leader, my_rank, my_n, axis;
-                uint32_t bin, slot0, slot, chunk;
-                uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
-                int o00, dox, doy;                                // tap offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
-                float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
-                float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
-                Texel3 t00, t01, t10, t11;
-            };
-            auto front = [&](int rbase, Round& R) {
-                R.e = rbase + lane;
-                R.have = R.e < n_items;
-                float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
-                if (R.have) it = L.items[R.e * 3];
-                const uint32_t key = __float_as_uint(it.w);
-                R.pl = KEY_PL(key);
-                const int jj = KEY_J(key);
-                R.jj = jj;
-                const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj]);
-                const float4 d_ = L.p.D[jj], e4 = L.p.E[jj], f_ = L.p.F[jj];
-                const float2 g2 = L.p.G[jj];
-                R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
-                R.vd0 = f_.w; R.vd1 = g2.x; R.vd2 = g2.y;
-                // UV Taylor step, cubemap address, tap loads
-                const float dpx = (float)(wave_px + KEY_OX(key)) - xy.x, dpy = (float)(wave_py + KEY_OY(key)) - xy.y;
-                const float den = 1.0f + d_.x * dpx + d_.y * dpy;
-                R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-                R.nu0 = d_.z * dpx + d_.w * dpy; R.nu1 = e4.x * dpx + e4.y * dpy; R.nu2 = e4.z * dpx + e4.w * dpy;
-                const CubeTap ct = cube_address(f_.x + R.nu0 * R.inv, f_.y + R.nu1 * R.inv, f_.z + R.nu2 * R.inv, a.R);
-                const Texel3 tz = {0.f, 0.f, 0.f};
-                R.t00 = tz; R.t01 = tz; R.t10 = tz; R.t11 = tz;
-                if (R.have) {
-                    R.t00 = load_texel(tex, ct.o00); R.t01 = load_texel(tex, ct.o01);
-                    R.t10 = load_texel(tex, ct.o10); R.t11 = load_texel(tex, ct.o11);
-                }
-                R.axis = ct.axis; R.fx = ct.fx; R.fy = ct.fy;
-                R.ka = ct.su * ct.h; R.kb = ct.sv * ct.h;
-                const float km = ct.h * ct.rma * ct.sm;
-                R.kc = ct.sc * km; R.kd = ct.tc * km;
-                R.o00 = ct.o00; R.dox = ct.o01 - ct.o00; R.doy = ct.o10 - ct.o00;
-                // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
-                R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
-                R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
-                // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
-                // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
-                R.binned = R.have && tb.pool != nullptr && ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1;   // not clamped at a face border
-                R.bin = (uint32_t)((ct.face * tb.nb + (ct.y0 >> 5)) * tb.nb + (ct.x0 >> 5));
-                R.leader = false;
-                R.my_leader = lane; R.my_rank = 0; R.my_n = 0;
-                ull pend = TG_BALLOT(R.binned);
-                while (pend != 0ull) {
-                    const int l0 = __ffsll((long long)pend) - 1;
-                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
-                    const ull m = TG_BALLOT(R.binned && R.bin == b0);
-                    if ((m >> lane) & 1ull) {
-                        R.my_leader = l0;
-                        R.my_rank = mbcnt64(m);
-                        if (lane == l0) { R.leader = true; R.my_n = __popcll(m); }
-                    }
-                    pend &= ~m;
-                }
-                R.slot0 = 0u;
-                if (R.leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)R.my_n);
-            };
-            // the group whose records contain a chunk's FIRST record owns that chunk's allocation: pool head + publish
-            auto alloc = [&](Round& R) {
-                if (R.leader) {
-                    const uint32_t first = R.slot0, lastr = R.slot0 + (uint32_t)R.my_n - 1u;
-                    const uint32_t k0 = first >> TB_CHUNK_LOG, k1 = lastr >> TB_CHUNK_LOG;
-                    uint32_t* trow = tb.table + (size_t)R.bin * tb.slots;
-                    if ((first & (TB_CHUNK - 1u)) == 0u && k0 < tb.slots) {
-                        const uint32_t h = atomicAdd(tb.stats + 2, 1u);
-                        __hip_atomic_store(trow + k0, (h < tb.pool_chunks) ? h + 1u : TB_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (k1 != k0 && k1 < tb.slots) {
-                        const uint32_t h = atomicAdd(tb.stats + 2, 1u);
-                        __hip_atomic_store(trow + k1, (h < tb.pool_chunks) ? h + 1u : TB_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            };
-            auto resolve = [&](Round& R) {
-                uint32_t c0 = TB_NONE, c1 = TB_NONE;
-                if (R.leader) {
-                    const uint32_t k0 = R.slot0 >> TB_CHUNK_LOG, k1 = (R.slot0 + (uint32_t)R.my_n - 1u) >> TB_CHUNK_LOG;
-                    const uint32_t* trow = tb.table + (size_t)R.bin * tb.slots;
-                    if (k0 < tb.slots) c0 = wait_chunk(trow + k0, tb.stats + 3);
-                    c1 = c0;
-                    if (k1 != k0) c1 = (k1 < tb.slots) ? wait_chunk(trow + k1, tb.stats + 3) : TB_NONE;
-                }
-                const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0);
-                const uint32_t l0 = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)c0);
-                const uint32_t l1 = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)c1);
-                R.slot = s0 + (uint32_t)R.my_rank;
-                R.chunk = ((R.slot >> TB_CHUNK_LOG) == (s0 >> TB_CHUNK_LOG)) ? l0 : l1;
-            };
-            auto back = [&](Round& R) {
-                const Texel3 &t00 = R.t00, &t01 = R.t01, &t10 = R.t10, &t11 = R.t11;
-                const float w00 = (1.f - R.fx) * (1.f - R.fy), w01 = R.fx * (1.f - R.fy);
-                const float w10 = (1.f - R.fx) * R.fy,         w11 = R.fx * R.fy;
-                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-                if (R.have) {
-                    const float w = R.w;
-                    const float4 dp = L.dpix[R.pl];
-                    const float d0 = dp.x, d1 = dp.y, d2 = dp.z;
-                    const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + R.vd0 + 0.5f;
-                    const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + R.vd1 + 0.5f;
-                    const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + R.vd2 + 0.5f;
-                    const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
-                    // colour -> view-dependent term and texture
-                    const float dc0 = (pre0 > 0.f) ? w * d0 : 0.f, dc1 = (pre1 > 0.f) ? w * d1 : 0.f, dc2 = (pre2 > 0.f) ? w * d2 : 0.f;
-                    x0 = TG_SH_C0 * dc0; x1 = TG_SH_C0 * dc1; x2 = TG_SH_C0 * dc2;
-                    const float dLdcol = x0 * ((1.f - R.fy) * (t01.x - t00.x) + R.fy * (t11.x - t10.x))
-                                       + x1 * ((1.f - R.fy) * (t01.y - t00.y) + R.fy * (t11.y - t10.y))
-                                       + x2 * ((1.f - R.fy) * (t01.z - t00.z) + R.fy * (t11.z - t10.z));
-                    const float dLdrow = x0 * ((1.f - R.fx) * (t10.x - t00.x) + R.fx * (t11.x - t01.x))
-                                       + x1 * ((1.f - R.fx) * (t10.y - t00.y) + R.fx * (t11.y - t01.y))
-                                       + x2 * ((1.f - R.fx) * (t10.z - t00.z) + R.fx * (t11.z - t01.z));
-                    const float dua = dLdcol * R.ka, dub = dLdrow * R.kb;
-                    const float dum = -(dLdcol * R.kc + dLdrow * R.kd);
-                    float du0, du1, du2;
-                    if (R.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
-                    else if (R.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
-                    else                  { du2 = dum; du0 = dua; du1 = dub; }
-                    const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
-                    // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
-                    // recurrence needs from this pair, formed here where all 64 lanes work
-                    const float4 c5 = L.p.C[R.jj];
-                    const float4 dg = L.dgeo[R.pl];
-                    L.items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
-                    L.items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
-                    L.items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
-                }
-                // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
-                // a face border / the pool or the bin's chunk table is exhausted (still correct, just slow)
-                if (R.binned && R.chunk != TB_NONE) {
-                    float* __restrict__ rp = tb.pool + (size_t)(R.chunk - 1u) * TEXGS_TEXBIN_CHUNK_FLOATS + (R.slot & (TB_CHUNK - 1u));
-                    rp[0] = __uint_as_float(R.fxw); rp[TB_CHUNK] = __uint_as_float(R.fyw);
-                    rp[2 * TB_CHUNK] = x0; rp[3 * TB_CHUNK] = x1; rp[4 * TB_CHUNK] = x2;
-                } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
-                    scatter_direct(dtex, R.o00, R.o00 + R.dox, R.o00 + R.doy, R.o00 + R.dox + R.doy, w00, w01, w10, w11, x0, x1, x2);
-                }
-            };
             static_assert(BQ_CAP <= 128, "stage B is unrolled for at most two rounds per segment");
             {
                 Round R0, R1;
                 front(0, R0);
                 if (n_items > 64) front(64, R1);
-                if (tb.pool != nullptr) {
-                    alloc(R0);
-                    if (n_items > 64) alloc(R1);
-                    resolve(R0);
-                    if (n_items > 64) resolve(R1);
-                } else { R0.chunk = TB_NONE; R1.chunk = TB_NONE; R0.slot = 0u; R1.slot = 0u; }
                 back(R0);
                 if (n_items > 64) back(R1);
             }
@@ -858,27 +855,50 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ texture-gradient reduce
+// ------------------------------------------------------------------------------------------------ texture-gradient lists
+// Exclusive scan of K6's per-bin footprint counts -> list offsets (one workgroup; nbins = 6144 at R = 1024).
+__global__ void __launch_bounds__(1024)
+k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ stats) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    for (int b0 = 0; b0 < nbins; b0 += 1024) {
+        const int i = b0 + tid;
+        const uint32_t c = (i < nbins) ? count[i] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wv; ++w) off += s_w[w];
+        if (i < nbins) base[i] = off + incl - c;
+        __syncthreads();
+        if (tid == 1023) s_carry = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        base[nbins] = s_carry;
+        if (s_carry > stats[0]) stats[0] = s_carry;      // what the lists of this view need: the host sizes the buffer from it
+    }
+}
+
 // One workgroup per 32x32-texel bin: sum the bin's records into a 33x33-texel LDS tile (footprints anchored in the bin
 // reach one texel past its right / bottom edge, still inside the face), then add every non-zero texel of the tile to
 // dL_dtexture[6,R,R,3] once -- 99 consecutive dwords per tile row, i.e. coalesced memory-side requests; neighbouring
-// bins overlap in that one-texel seam, hence atomics.  Leaves the cursor and the bin's chunk-table entries at 0 for the
-// next call.
+// bins overlap in that one-texel seam, hence atomics.  Leaves the cursor at 0 for the next call.
 // The tile is 64-bit FIXED POINT: LDS float atomics retire ~3 cycles per lane on gfx950 (ds_add_f32: 193 cycles per wave
 // instruction, ds_add_u64: 6; scripts/ubench/lds_atomics.hip), which made the first version of this kernel 1.8 ms.  Scale:
 // every record value is bounded by C0 * max|dL/dpixel colour| OF THIS CALL (K7 leaves that maximum in stats[1], K8 clears it)
-// and is mapped to < 2^42; a list holds at most slots * 512 <= 2^20 records, so it cannot overflow; resolution 2^-42 of the
-// image-wide bound, sums exact and order-independent (the texture gradient of the binned path is bit-reproducible run to run).
+// and is mapped to < 2^42, so 2^20 records per bin cannot overflow (lists are cut there; the rest went through atomics);
+// resolution 2^-42 of the image-wide bound, sums exact and order-independent.
 #define TB_EDGE 33
 __global__ void __launch_bounds__(256)
 k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __shared__ long long s_tile[TB_EDGE * TB_EDGE * 3];          // [row][col][channel], 2^42-scaled fixed point
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
-    if (b == 0 && tid == 0) {                                  // pool bookkeeping: what this call wanted, head back to 0
-        const uint32_t h = tb.stats[2];
-        if (h > tb.stats[0]) tb.stats[0] = h;
-        tb.stats[2] = 0u;
-    }
     const uint32_t filled = tb.cursor[b];
     if (filled == 0u) return;                                  // uniform per workgroup
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) s_tile[k] = 0ll;
@@ -888,9 +908,11 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     (void)frexpf(bound, &e);                                   // bound < 2^e
     const double up = (double)ldexpf(1.0f, 42 - e);
     const float down = ldexpf(1.0f, e - 42);
-    const uint32_t nrec = min(filled, tb.slots << TB_CHUNK_LOG);
-    const uint32_t nch = (nrec + TB_CHUNK - 1u) >> TB_CHUNK_LOG;
-    uint32_t* trow = tb.table + (size_t)b * tb.slots;
+    const uint32_t b0 = tb.base[b], b1 = tb.base[b + 1];
+    const uint32_t room = (b0 < tb.cap) ? min(b1, tb.cap) - b0 : 0u;      // records of this list that exist (K7's own test)
+    const uint32_t cnt = min(min(filled, room), TB_LIST_MAX);
+    const float* __restrict__ rp = tb.rec + b0;
+    const size_t cap = tb.cap;
     // float -> int64 without the 11-instruction generic conversion: |v| < 2^42, so v + 1.5 * 2^52 (exact in double) carries
     // round(v) in its mantissa; subtracting the bias as integers leaves the two's-complement value
     const double magic = 6755399441055744.0;
@@ -908,21 +930,18 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         TB_ADD(t + TB_EDGE * 3 + 3, w11 * dx0); TB_ADD(t + TB_EDGE * 3 + 4, w11 * dx1); TB_ADD(t + TB_EDGE * 3 + 5, w11 * dx2);
 #undef TB_ADD
     };
-    // one chunk = 512 records = two per thread, both in flight (10 loads); the chunk ids of the list come from the bin's table row
-    for (uint32_t k = 0; k < nch; ++k) {
-        const uint32_t c = trow[k];
-        if (c == 0u || c == TB_NONE) continue;                 // uniform: that part of the list went through atomics
-        const uint32_t cnt = min(TB_CHUNK, nrec - (k << TB_CHUNK_LOG));
-        const float* __restrict__ rp = tb.pool + (size_t)(c - 1u) * TEXGS_TEXBIN_CHUNK_FLOATS;
-        const uint32_t i = (uint32_t)tid, i2 = i + 256u;
-        const bool ha = i < cnt, hb = i2 < cnt;
-        uint32_t fxa = 0u, fya = 0u, fxb = 0u, fyb = 0u;
-        float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f, xb0 = 0.f, xb1 = 0.f, xb2 = 0.f;
-        if (ha) { fxa = __float_as_uint(rp[i]); fya = __float_as_uint(rp[TB_CHUNK + i]); xa0 = rp[2 * TB_CHUNK + i]; xa1 = rp[3 * TB_CHUNK + i]; xa2 = rp[4 * TB_CHUNK + i]; }
-        if (hb) { fxb = __float_as_uint(rp[i2]); fyb = __float_as_uint(rp[TB_CHUNK + i2]); xb0 = rp[2 * TB_CHUNK + i2]; xb1 = rp[3 * TB_CHUNK + i2]; xb2 = rp[4 * TB_CHUNK + i2]; }
-        if (ha) add_record(fxa, fya, xa0, xa1, xa2);
-        if (hb) add_record(fxb, fyb, xb0, xb1, xb2);
+    // two records per thread in flight (10 loads)
+    uint32_t i = (uint32_t)tid;
+    for (; i + 256u < cnt; i += 512u) {
+        const uint32_t i2 = i + 256u;
+        const uint32_t fxa = __float_as_uint(rp[i]), fya = __float_as_uint(rp[cap + i]);
+        const float xa0 = rp[2 * cap + i], xa1 = rp[3 * cap + i], xa2 = rp[4 * cap + i];
+        const uint32_t fxb = __float_as_uint(rp[i2]), fyb = __float_as_uint(rp[cap + i2]);
+        const float xb0 = rp[2 * cap + i2], xb1 = rp[3 * cap + i2], xb2 = rp[4 * cap + i2];
+        add_record(fxa, fya, xa0, xa1, xa2);
+        add_record(fxb, fyb, xb0, xb1, xb2);
     }
+    if (i < cnt) add_record(__float_as_uint(rp[i]), __float_as_uint(rp[cap + i]), rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
     __syncthreads();
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
@@ -934,12 +953,11 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles, hence atomics
         unsafeAtomicAdd(dtex + ((size_t)(face * R + y) * R) * 3 + xq, (float)q * down);
     }
-    for (uint32_t k = (uint32_t)tid; k < nch; k += 256u) trow[k] = 0u;
     if (tid == 0) tb.cursor[b] = 0u;
 }
 
 inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
-                        const TexGSBinning* b) {
+                        const TexGSBinning* b, const TexGSImage* img) {
     PixArgs a;
     a.W = c.W; a.H = c.H; a.tiles_x = c.tiles_x; a.num_tiles = c.tiles_x * c.tiles_y; a.R = c.R;
     a.ranges = reinterpret_cast<const uint2*>(b->ranges);
@@ -949,20 +967,23 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
     a.rec_shade = reinterpret_cast<const float4*>(g->rec_shade);
     a.texture = in->texture;
     a.bg = f->bg;
+    const bool hand = img->survivors != nullptr && img->surv_qmask != nullptr && img->surv_count != nullptr;
+    a.surv = hand ? reinterpret_cast<uint2*>(img->survivors) : nullptr;
+    a.surv_qm = hand ? img->surv_qmask : nullptr;
+    a.surv_cnt = hand ? img->surv_count : nullptr;
     return a;
 }
 
-inline TexBinArgs make_bins(const CamConst& c, const TexGSGrads* gr) {
+inline TexBinArgs make_bins(const CamConst& c, const TexGSImage* img, const TexGSGrads* gr) {
     TexBinArgs tb;
     tb.nb = (c.R + 31) >> 5;
-    const bool on = gr->tex_bins != nullptr && gr->tex_bin_cursor != nullptr && gr->tex_bin_table != nullptr &&
-                    gr->tex_pool_chunks > 0 && gr->tex_bin_slots > 0;
-    tb.pool = on ? gr->tex_bins : nullptr;
+    const bool on = img->tex_bin_count != nullptr && gr->tex_bins != nullptr && gr->tex_bin_cursor != nullptr &&
+                    gr->tex_bin_base != nullptr && gr->tex_rec_cap > 0;
+    tb.rec = on ? gr->tex_bins : nullptr;
     tb.cursor = on ? gr->tex_bin_cursor : nullptr;
-    tb.table = on ? gr->tex_bin_table : nullptr;
+    tb.base = on ? gr->tex_bin_base : nullptr;
     tb.stats = on ? gr->tex_bin_cursor + tex_bin_count(c.R) : nullptr;
-    tb.pool_chunks = on ? gr->tex_pool_chunks : 0u;
-    tb.slots = on ? gr->tex_bin_slots : 0u;      // <= 2048 (checked in abi.hip): <= 2^20 records per list, the reduce's fixed point cannot overflow
+    tb.cap = on ? gr->tex_rec_cap : 0u;
     return tb;
 }
 
@@ -975,22 +996,26 @@ size_t tex_bin_count(int R) {
 
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
-    const PixArgs a = make_pix(c, f, in, g, b);
+    const PixArgs a = make_pix(c, f, in, g, b, img);
     hipLaunchKernelGGL(k_render_fwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
-                       img->out_norm, img->out_alpha, img->final_T, img->n_contrib);
+                       img->out_norm, img->out_alpha, img->final_T, img->n_contrib, img->tex_bin_count);
 }
 
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
-    const PixArgs a = make_pix(c, f, in, g, b);
-    hipLaunchKernelGGL(k_render_bwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, make_bins(c, gr), img->final_T,
+    const PixArgs a = make_pix(c, f, in, g, b, img);
+    const TexBinArgs tb = make_bins(c, img, gr);
+    if (tb.rec)      // list offsets from the counts the forward left (one small workgroup)
+        hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
+                           gr->tex_bin_base, tb.stats);
+    hipLaunchKernelGGL(k_render_bwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, tb, img->final_T,
                        img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture);
 }
 
-bool tex_bins_enabled(const CamConst& c, const TexGSGrads* gr) { return make_bins(c, gr).pool != nullptr; }
+bool tex_bins_enabled(const CamConst& c, const TexGSImage* img, const TexGSGrads* gr) { return make_bins(c, img, gr).rec != nullptr; }
 
-void launch_texgrad_reduce(const CamConst& c, TexGSGrads* gr, hipStream_t s) {
-    const TexBinArgs tb = make_bins(c, gr);
-    if (!tb.pool) return;
+void launch_texgrad_reduce(const CamConst& c, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
+    const TexBinArgs tb = make_bins(c, img, gr);
+    if (!tb.rec) return;
     hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(256), 0, s, c.R, tb, gr->dL_dtexture);
 }

@@ -11,9 +11,7 @@ ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8
 REC_SHADE_FLOATS = 20
-TEXBIN_CHUNK_RECORDS = 512
 TEXBIN_RECORD_FLOATS = 5
-TEXBIN_CHUNK_FLOATS = TEXBIN_CHUNK_RECORDS * TEXBIN_RECORD_FLOATS
 ACC_FLOATS = 32
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -43,15 +41,16 @@ class Binning(C.Structure):
 
 class Image(C.Structure):
     _fields_ = [("out_color", _fp), ("out_depth", _fp), ("out_norm", _fp), ("out_alpha", _fp),
-                ("final_T", _fp), ("n_contrib", _fp)]
+                ("final_T", _fp), ("n_contrib", _fp), ("tex_bin_count", _fp),
+                ("survivors", _fp), ("surv_qmask", _fp), ("surv_count", _fp)]
 
 
 class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
                 ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
-                ("dL_dcolor_offset", _fp), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_table", _fp),
-                ("tex_pool_chunks", C.c_uint32), ("tex_bin_slots", C.c_uint32),
+                ("dL_dcolor_offset", _fp), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_base", _fp),
+                ("tex_rec_cap", C.c_uint32),
                 ("accumulate", C.c_int32)]
 
 

@@ -17,10 +17,9 @@ from . import _lib
 
 import os as _os
 USE_TEX_BINS = _os.environ.get("TEXGS_TEX_BINS", "1") != "0"       # binned two-pass texture gradient
-TEX_POOL_CHUNKS = int(_os.environ.get("TEXGS_POOL_CHUNKS", "0"))   # fixed pool size in chunks (tests); 0 = adaptive
-TEX_BIN_SLOTS = int(_os.environ.get("TEXGS_BIN_SLOTS", "128"))     # chunk-table entries per bin (x 512 records)
+TEX_REC_CAP = int(_os.environ.get("TEXGS_REC_CAP", "0"))           # fixed record capacity (tests); 0 = adaptive
 DIRECT_LEAF_GRADS = _os.environ.get("TEXGS_DIRECT_LEAF_GRADS", "1") != "0"   # add into a leaf's existing .grad in place
-TEX_POOL_BYTES_MAX = int(float(_os.environ.get("TEXGS_BIN_GB_MAX", "4")) * (1 << 30))
+TEX_REC_BYTES_MAX = int(float(_os.environ.get("TEXGS_BIN_GB_MAX", "4")) * (1 << 30))
 # per-Gaussian gradient outputs in the order / bit positions of TEXGS_ACC_* (texgs.h)
 _ACC_BITS = dict(means3D=1, means2D=2, shs=4, opacities=8, scales=16, rotations=32, uvs=64, color_offset=128)
 
@@ -90,52 +89,51 @@ def scratch_bytes():
 
 
 class _TexBins:
-    """Scratch of the binned texture gradient for one (device, R, stream): the record POOL (fixed-size chunks taken with one
-    atomic counter), the per-bin cursors + four status words, and the per-bin chunk table (TexGSGrads.tex_bins /
-    tex_bin_cursor / tex_bin_table).  Cursors and table are all-zero between calls (the reduce kernel clears what it read),
-    the pool needs no initialisation.  The pool size adapts: every call leaves the number of chunks it wanted in the word
-    after the cursors; it is copied to pinned host memory asynchronously every few calls and looked at only when that copy
-    has completed -- the backward never waits for it.  An exhausted pool is not an error (the excess goes through
-    atomics), so a stale size costs speed, never correctness."""
+    """Scratch of the binned texture gradient for one (device, R, stream): the record buffer (TexGSGrads.tex_bins, 20 bytes per
+    bilinear footprint of a view, exactly-sized contiguous lists), the per-bin fill cursors + two status words (all-zero
+    between calls: the reduce kernel clears what it read) and the list offsets of the call in flight.  The buffer grows to
+    what the views need: every call leaves the number of records its lists wanted in the word after the cursors; it is copied
+    to pinned host memory asynchronously every few calls and looked at only when that copy has completed -- the backward
+    never waits for it.  A buffer that is too small is not an error (what does not fit goes through atomics), so a stale
+    size costs speed, never correctness."""
 
     def __init__(self, lib, device, R):
         self.device, self.R = device, R
         self.nbins = int(lib.texgs_tex_bin_count(R))
-        self.slots = max(1, min(TEX_BIN_SLOTS, 2048))
-        self.cursor = torch.zeros(self.nbins + 4, dtype=torch.int32, device=device)
-        self.table = torch.zeros(self.nbins * self.slots, dtype=torch.int32, device=device)
-        self.chunks = 0
-        self.pool = None
-        # first guess: every bin gets two chunks (a partial one is always there) -- 0.15 GB at R = 1024
-        self._resize(TEX_POOL_CHUNKS or 2 * self.nbins)
-        self.host_stat = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.cursor = torch.zeros(self.nbins + 2, dtype=torch.int32, device=device)
+        self.base = torch.empty(self.nbins + 1, dtype=torch.int32, device=device)
+        self.cap = 0
+        self.rec = None
+        self.host_stat = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.event = None
         self.calls = 0
 
     def nbytes(self):
-        return (self.pool.numel() + self.cursor.numel() + self.table.numel()) * 4
+        return ((0 if self.rec is None else self.rec.numel()) + self.cursor.numel() + self.base.numel()) * 4
 
-    def _resize(self, chunks):
-        chunks = max(4, min(int(chunks), TEX_POOL_BYTES_MAX // (4 * _lib.TEXBIN_CHUNK_FLOATS)))
-        if chunks != self.chunks:
-            self.pool = None
-            self.pool = torch.empty(chunks * _lib.TEXBIN_CHUNK_FLOATS, dtype=torch.float32, device=self.device)
-            self.chunks = chunks
+    def _resize(self, cap):
+        cap = max(1024, min(int(cap), TEX_REC_BYTES_MAX // (4 * _lib.TEXBIN_RECORD_FLOATS)))
+        if cap != self.cap:
+            self.rec = None
+            self.rec = torch.empty(cap * _lib.TEXBIN_RECORD_FLOATS, dtype=torch.float32, device=self.device)
+            self.cap = cap
 
-    def before_call(self):
+    def before_call(self, D):
+        if TEX_REC_CAP:
+            self._resize(TEX_REC_CAP)
+            return
         if self.event is not None and self.event.query():
             self.event = None
-            wanted, err = int(self.host_stat[0]), int(self.host_stat[3])
-            if err:
-                raise RuntimeError("texture-gradient bins: a chunk hand-off timed out inside k_render_bwd (sticky flag); "
-                                   "the affected footprints went through atomics -- please report")
-            if not TEX_POOL_CHUNKS and wanted > self.chunks:
-                self._resize(int(wanted * 1.25) + 64)
+            wanted = int(self.host_stat[0])
+            if wanted > self.cap:
+                self._resize(int(wanted * 1.25) + 4096)
+        if self.rec is None:
+            self._resize(20 * max(int(D), 1024))        # first guess: ~17 contributing pixels per (tile, Gaussian) instance at C3
 
     def after_call(self):
         self.calls += 1
-        if self.event is None and (self.calls <= 4 or self.calls % 16 == 0):
-            self.host_stat.copy_(self.cursor[self.nbins:self.nbins + 4], non_blocking=True)
+        if self.event is None and not TEX_REC_CAP and (self.calls <= 4 or self.calls % 16 == 0):
+            self.host_stat.copy_(self.cursor[self.nbins:self.nbins + 1], non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(self.device))
 
@@ -160,8 +158,11 @@ def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
     return f
 
 
-def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None):
-    """Run K1..K6.  Returns (outputs, state).  No autograd here."""
+def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None,
+                for_backward=True):
+    """Run K1..K6.  Returns (outputs, state).  No autograd here.  `for_backward`: K6 also counts the texture-gradient
+    footprints per texture bin (the exact list sizes of backward_raw's binned texture gradient); without the counts a
+    backward still works, through atomics."""
     lib = _lib.load()
     device = means3D.device
     if device.type != "cuda":
@@ -231,8 +232,10 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         out_alpha = torch.empty(1, H, W, **f32)
         final_T = torch.empty(H, W, **f32)
         n_contrib = torch.empty(H, W, **i32)
+        tex_bin_count = torch.empty(int(lib.texgs_tex_bin_count(R)), **i32) if (for_backward and USE_TEX_BINS) else None
+        surv_count = torch.empty(4 * tiles, **i32) if for_backward else None
         img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), _ptr(final_T),
-                         _ptr(n_contrib))
+                         _ptr(n_contrib), _ptr(tex_bin_count), None, None, _ptr(surv_count))
         ranges = torch.empty(tiles, 2, **i32)          # zero-filled by K3
         tile_order = torch.empty(tiles, **i32)
 
@@ -244,7 +247,11 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
             b = _lib.Binning(0, _ptr(keys_u), _ptr(keys_s), _ptr(point_list), _ptr(ranges), _ptr(tile_order), _ptr(sort_temp),
                              sort_bytes)
-            return b, (keys_u, keys_s, point_list, sort_temp)
+            # K6 -> K7 hand-off of the per-block survivor lists: four blocks per tile, each at most the tile's list length
+            surv = torch.empty(4 * max(cap, 1), 2, **i32) if for_backward else None
+            surv_qm = torch.empty(4 * max(cap, 1), dtype=torch.int16, device=device) if for_backward else None
+            img.survivors, img.surv_qmask = _ptr(surv), _ptr(surv_qm)
+            return b, (keys_u, keys_s, point_list, sort_temp, surv, surv_qm)
         hint_key = (device.index, N, H, W)
         cap = _CAPACITY_HINT.get(hint_key, max(4 * N, 1024))
         binning, bin_t = alloc_bin(cap)
@@ -260,14 +267,15 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
                                                    C.byref(img), stream)
         _lib.check(rc, "texgs_forward")
         _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
-        keys_u, keys_s, point_list, sort_temp = bin_t
+        keys_u, keys_s, point_list, sort_temp, surv, surv_qm = bin_t
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
     s.tensors = dict(keep=keep, rec=rec, rec_shade=rec_shade, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
                      offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s,
                      point_list=point_list, ranges=ranges, tile_order=tile_order,
-                     final_T=final_T, n_contrib=n_contrib,
+                     final_T=final_T, n_contrib=n_contrib, tex_bin_count=tex_bin_count,
+                     survivors=surv, surv_qmask=surv_qm, surv_count=surv_count,
                      scan_temp=scan_temp, sort_temp=sort_temp,
                      out=(out_color, out_depth, out_norm, out_alpha))
     return (out_color, out_depth, out_norm, out_alpha, radii), s
@@ -284,6 +292,8 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     existing .grad) and writes the others into one fresh allocation; a texture sink is used the same way (dL_dtexture is
     always accumulated into).  Outputs written into a sink come back as None."""
     lib = _lib.load()
+    if s.tensors.get("survivors") is None:
+        raise RuntimeError("this forward ran with for_backward=False (no survivor lists were kept): its backward cannot run")
     means3D = s.tensors["keep"][0]
     device = means3D.device
     f32 = dict(dtype=torch.float32, device=device)
@@ -328,15 +338,15 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
         tex_sink = sinks.get("texture")
         d_tex = tex_sink if tex_sink is not None else torch.zeros(6, R, R, 3, **f32)
         bins = None
-        if USE_TEX_BINS:
+        if USE_TEX_BINS and s.tensors.get("tex_bin_count") is not None:
             bins = sc.bins if (sc.bins is not None and sc.bins.R == R) else _TexBins(lib, device, R)
             sc.bins = None
-            bins.before_call()
+            bins.before_call(s.D)
         grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(outs["means3D"]), _ptr(outs["means2D"]),
                            _ptr(outs.get("shs")), _ptr(outs["opacities"]), _ptr(outs["scales"]), _ptr(outs["rotations"]),
                            _ptr(outs["uvs"]), _ptr(d_tex), _ptr(outs.get("color_offset")),
-                           _ptr(bins.pool) if bins else None, _ptr(bins.cursor) if bins else None,
-                           _ptr(bins.table) if bins else None, bins.chunks if bins else 0, bins.slots if bins else 0, mask)
+                           _ptr(bins.rec) if bins else None, _ptr(bins.cursor) if bins else None,
+                           _ptr(bins.base) if bins else None, bins.cap if bins else 0, mask)
         if before_accumulate is None:
             _lib.check(lib.texgs_backward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
                                           C.byref(s.img), C.byref(grads), stream), "texgs_backward")
@@ -379,7 +389,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         outs, state = forward_raw(st, means3D.detach(), None if shs is None else shs.detach(),
                                   opacities.detach(), scales.detach(), rotations.detach(), uvs.detach(),
                                   gradient_uvs.detach(), texture.detach(),
-                                  None if color_offset is None else color_offset.detach())
+                                  None if color_offset is None else color_offset.detach(),
+                                  for_backward=any(ctx.needs_input_grad))
         color, depth, norm, alpha, radii = outs
         ctx.state = state
         # the backward re-reads the inputs through raw pointers (K8 recomputes geometry, K7 re-fetches texels): remember
