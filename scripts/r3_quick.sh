@@ -14,3 +14,9 @@ for l in sys.stdin:
         d=json.loads(l); print('[$v]', d['value'], {k:round(v['avg_us']) for k,v in d['kernels'].items()})
 "
 done | tee gpurun_out/variants.log
+TEXGS_LIB=$PWD/texture-gs_amd/libtexgs.so timeout 300 python bench.py --workload c2 --streams 1 --no-cpu-baseline --steps 4 --warmup 2 2> gpurun_out/c2.err | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('[c2 serial]', d['value'], {k:round(v['avg_us']) for k,v in d['kernels'].items()})
+"

@@ -100,7 +100,6 @@ int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, Tex
     if (geom->scan_temp_bytes < scan_temp_bytes(frame->num_gaussians)) return fail_msg("scan_temp too small");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
-    if (int r = launch_bin_header(geom, frame->num_gaussians, s)) return fail("bin header memset", (hipError_t)r);
     { ProfScope p(TEXGS_K_PREPROCESS_FWD, s); launch_preprocess_fwd(c, frame, in, geom, s); }
     if (int r = check(frame, s, "preprocess_fwd")) return r;
     return 0;
@@ -115,7 +114,7 @@ static int depth_sort_scan(const TexGSFrame* frame, TexGSGeom* geom, hipStream_t
 }
 
 namespace {
-struct Readback { uint32_t* host = nullptr; hipEvent_t ev = nullptr; };
+struct Readback { uint32_t* host = nullptr; size_t words = 0; hipEvent_t ev = nullptr; };
 constexpr int RB_MAX_DEVICES = 64;
 thread_local Readback g_rb_dev[RB_MAX_DEVICES];   // one pinned word + event per (host thread, device): HIP events belong to the
                                                   // device that was current when they were created
@@ -132,11 +131,16 @@ int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RB_MAX_DEVICES) return fail_msg("hipGetDevice failed");
     Readback& g_rb = g_rb_dev[dev];
-    if (!g_rb.host) {
-        if (hipHostMalloc((void**)&g_rb.host, 64, hipHostMallocDefault) != hipSuccess) return fail_msg("hipHostMalloc failed");
-        if (hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming) != hipSuccess) return fail_msg("hipEventCreate failed");
+    // K1 left one partial sum of tiles_touched per workgroup (no atomics, nothing to zero-fill): copy them, add them up here
+    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK;
+    if (g_rb.words < nblk) {
+        if (g_rb.host) (void)hipHostFree(g_rb.host);
+        g_rb.host = nullptr;
+        g_rb.words = nblk < 4096 ? 4096 : nblk * 2;
+        if (hipHostMalloc((void**)&g_rb.host, g_rb.words * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { g_rb.words = 0; return fail_msg("hipHostMalloc failed"); }
     }
-    hipError_t e = hipMemcpyAsync(g_rb.host, bin_total_ptr(geom, num_gaussians), sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (!g_rb.ev && hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming) != hipSuccess) return fail_msg("hipEventCreate failed");
+    hipError_t e = hipMemcpyAsync(g_rb.host, bin_block_sums_ptr(geom, num_gaussians), nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return fail("num_rendered readback", e);
     e = hipEventRecord(g_rb.ev, s);
     if (e != hipSuccess) return fail("num_rendered event", e);
@@ -144,23 +148,31 @@ int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32
     if (int r = depth_sort_scan(&f0, const_cast<TexGSGeom*>(geom), s)) return r;
     e = hipEventSynchronize(g_rb.ev);
     if (e != hipSuccess) return fail("num_rendered sync", e);
-    *host_out = *g_rb.host;
+    unsigned long long total = 0ull;
+    for (size_t k = 0; k < nblk; ++k) total += g_rb.host[k];
+    if (total > 0xFFFFFFFFull) return fail_msg("num_rendered exceeds 2^32 - 1 instances");
+    *host_out = (uint32_t)total;
     return 0;
 }
 
-int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
-                         const TexGSBinning* bin, TexGSImage* img, void* stream) {
+static int render_forward_impl(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                               const TexGSBinning* bin, TexGSImage* img, void* stream, bool counters_zeroed) {
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !bin || !img) return fail_msg("NULL argument");
     if (!in->texture) return fail_msg("texture is NULL");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
-    if (img->tex_bin_count) {       // K6 counts the texture-gradient footprints per bin into it
+    if (img->tex_bin_count && !counters_zeroed) {       // K6 counts the texture-gradient footprints per bin into it
         hipError_t e = hipMemsetAsync(img->tex_bin_count, 0, sizeof(uint32_t) * tex_bin_count(c.R), s);
         if (e != hipSuccess) return fail("tex_bin_count memset", e);
     }
     { ProfScope p(TEXGS_K_RENDER_FWD, s); launch_render_fwd(c, frame, in, geom, bin, img, s); }
     return check(frame, s, "render_fwd");
+}
+
+int texgs_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
+                         const TexGSBinning* bin, TexGSImage* img, void* stream) {
+    return render_forward_impl(frame, in, geom, bin, img, stream, false);
 }
 
 int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
@@ -171,16 +183,17 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     const CamConst c = make_cam(frame);
     if (bin->num_rendered > 0) {
         if (bin->sort_temp_bytes < sort_temp_bytes(bin->num_rendered, (uint32_t)(c.tiles_x * c.tiles_y))) return fail_msg("sort_temp too small");
-        if (int r = launch_sort_header(bin->sort_temp, s)) return fail("sort header memset", (hipError_t)r);
         { ProfScope p(TEXGS_K_DUPLICATE, s); launch_duplicate(c, geom, bin, s); }
         if (int r = check(frame, s, "duplicate_with_keys")) return r;
         { ProfScope p(TEXGS_K_SORT, s);
           if (int r = launch_sort(c, geom, bin, s)) return fail("tile sort", (hipError_t)r); }
         if (int r = check(frame, s, "tile sort")) return r;
     }
-    { ProfScope p(TEXGS_K_RANGES, s); launch_ranges(c, bin, s); }
+    // (the one-workgroup tile-order kernel also zero-fills the per-bin footprint counters K6 adds into)
+    { ProfScope p(TEXGS_K_RANGES, s);
+      launch_ranges(c, bin, img->tex_bin_count, img->tex_bin_count ? (int)tex_bin_count(c.R) : 0, s); }
     if (int r = check(frame, s, "tile_ranges")) return r;
-    return texgs_render_forward(frame, in, geom, bin, img, stream);
+    return render_forward_impl(frame, in, geom, bin, img, stream, true);
 }
 
 int texgs_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, TexGSBinning* bin, uint32_t capacity,

@@ -49,7 +49,15 @@ k_radix_count(const KEY* __restrict__ keys, const uint32_t* __restrict__ n_ptr, 
     block_range(n, per, lo, hi);
     s_hist[threadIdx.x] = 0u;
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += RS_THREADS) atomicAdd(&s_hist[digit_of(keys[i], shift, mask)], 1u);
+    // 8 keys per thread per trip, all loads in flight together (the kernel is one dependent chain: its time is its round trips)
+    constexpr int CB = 8;
+    for (uint32_t b0 = lo + threadIdx.x; b0 < hi; b0 += RS_THREADS * CB) {
+        KEY kk[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) { const uint32_t i = b0 + (uint32_t)u * RS_THREADS; kk[u] = (i < hi) ? keys[i] : (KEY)0; }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) if (b0 + (uint32_t)u * RS_THREADS < hi) atomicAdd(&s_hist[digit_of(kk[u], shift, mask)], 1u);
+    }
     __syncthreads();
     const uint32_t c = s_hist[threadIdx.x];
     t.table[blockIdx.x * 256 + threadIdx.x] = c;
@@ -75,10 +83,28 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
     block_range(n, per, lo, hi);
     if (lo >= hi) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // wave w owns the w-th quarter of the block's range, in 64-element rows; RB rows (keys + values) are loaded together.  With
+    // per = 2048 that is the wave's whole quarter: the keys are read ONCE, and their loads are in flight together with the
+    // count-table loads below (the kernel is one dependent chain: its time is its round trips).
+    constexpr int RB = 8;
+    const uint32_t rows = (hi - lo + 63u) >> 6, rows_per_wave = (rows + 3u) >> 2;
+    const uint32_t wlo = min(hi, lo + (uint32_t)wv * rows_per_wave * 64u), whi = min(hi, wlo + rows_per_wave * 64u);
+    const bool single = (whi - wlo) <= 64u * RB;
+    KEY kk[RB];
+    uint32_t vv[RB];
+    auto load_batch = [&](uint32_t b0) {
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const uint32_t i = b0 + 64u * rr + lane;
+            kk[rr] = (i < whi) ? keys_in[i] : (KEY)0;
+            vv[rr] = (MODE == 0 && vals_in != nullptr && i < whi) ? vals_in[i] : i;
+        }
+    };
+    load_batch(wlo);
     // ---- where this block's digit-d elements start: digit base + blocks before this one
     uint32_t before = 0u;
     {
-        // fixed trip counts, predicated: all (at most 15 + 15) loads are in flight together instead of one round trip each
+        // fixed trip counts, predicated: all (at most 31 + 31) loads are in flight together instead of one round trip each
         const int g = blockIdx.x / RS_GROUP, inb = (int)blockIdx.x - g * RS_GROUP;
         uint32_t part[2 * RS_GROUP];
 #pragma unroll
@@ -100,12 +126,15 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
         before += wbase + incl - tot;
         __syncthreads();
     }
-    // ---- per-wave digit counts of this block (wave w owns the w-th quarter of the range, in 64-element rows)
-    const uint32_t rows = (hi - lo + 63u) >> 6, rows_per_wave = (rows + 3u) >> 2;
-    const uint32_t wlo = min(hi, lo + (uint32_t)wv * rows_per_wave * 64u), whi = min(hi, wlo + rows_per_wave * 64u);
+    // ---- per-wave digit counts of this block
     s_wcnt[0][tid] = 0u; s_wcnt[1][tid] = 0u; s_wcnt[2][tid] = 0u; s_wcnt[3][tid] = 0u;
     __syncthreads();
-    for (uint32_t i = wlo + lane; i < whi; i += 64u) atomicAdd(&s_wcnt[wv][digit_of(keys_in[i], shift, mask)], 1u);
+    for (uint32_t b0 = wlo; b0 < whi; b0 += 64u * RB) {
+        if (b0 != wlo) load_batch(b0);
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+            if (b0 + 64u * rr + lane < whi) atomicAdd(&s_wcnt[wv][digit_of(kk[rr], shift, mask)], 1u);
+    }
     __syncthreads();
     {   // thread = digit: turn the four wave counts into the four waves' first output slots
         uint32_t run = before;
@@ -113,19 +142,10 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
         for (int w = 0; w < 4; ++w) { const uint32_t c = s_wcnt[w][tid]; s_wcnt[w][tid] = run; run += c; }
     }
     __syncthreads();
-    // ---- stable ranking + scatter, one 64-element row at a time (rows in order, lanes in order); the keys (and values) of
-    // RB rows are loaded together first, so a wave has RB loads in flight instead of one exposed round trip per row
-    constexpr int RB = 8;
+    // ---- stable ranking + scatter, one 64-element row at a time (rows in order, lanes in order)
     uint32_t* cur = s_wcnt[wv];
     for (uint32_t b0 = wlo; b0 < whi; b0 += 64u * RB) {
-        KEY kk[RB];
-        uint32_t vv[RB];
-#pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-            const uint32_t i = b0 + 64u * rr + lane;
-            kk[rr] = (i < whi) ? keys_in[i] : (KEY)0;
-            vv[rr] = (MODE == 0 && vals_in != nullptr && i < whi) ? vals_in[i] : i;
-        }
+        if (!single) load_batch(b0);            // (a single batch is still in registers from the count pass)
         uint32_t dr[RB];
         if (MODE == 2) {        // the final pass's two gathers by depth rank, also batched
 #pragma unroll
@@ -178,7 +198,13 @@ k_scan_sums(int N, const uint32_t* __restrict__ id_rank, const uint32_t* __restr
     __shared__ uint32_t s_w[4];
     const int base = blockIdx.x * SC_PER;
     uint32_t s = 0u;
-    for (int k = threadIdx.x; k < SC_PER; k += RS_THREADS) { const int r = base + k; if (r < N) s += tiles_touched[id_rank[r]]; }
+    {   // both gathers batched: 8 index loads in flight, then 8 value loads
+        uint32_t ids[SC_PER / RS_THREADS];
+#pragma unroll
+        for (int k = 0; k < SC_PER / RS_THREADS; ++k) { const int r = base + (int)threadIdx.x + k * RS_THREADS; ids[k] = (r < N) ? id_rank[r] : 0u; }
+#pragma unroll
+        for (int k = 0; k < SC_PER / RS_THREADS; ++k) { const int r = base + (int)threadIdx.x + k * RS_THREADS; s += (r < N) ? tiles_touched[ids[k]] : 0u; }
+    }
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -222,9 +248,10 @@ k_scan_apply(int N, int nblocks, const uint32_t* __restrict__ id_rank, const uin
 __global__ void __launch_bounds__(TG_BLOCK)
 k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ offs_rank,
             const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, uint64_t* __restrict__ elems,
-            uint2* __restrict__ ranges) {
+            uint2* __restrict__ ranges, uint32_t* __restrict__ zero_words, int num_zero_words) {
     const int r = blockIdx.x * TG_BLOCK + threadIdx.x;
     for (int k = r; k < T; k += (int)gridDim.x * TG_BLOCK) ranges[k] = make_uint2(0u, 0u);
+    for (int k = r; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // group / total count tables of the tile sort
     if (r >= N) return;
     const uint32_t id = id_rank[r];
     if (tiles_touched[id] == 0u) return;
@@ -253,10 +280,12 @@ k_ranges(uint32_t D, const uint64_t* __restrict__ keys, uint2* __restrict__ rang
 // Launch order of the blend kernels: longest tile list first (LPT), as a counting sort on a 1024-level log-ish length
 // bucket in ONE workgroup (speed only: any order is correct; ties keep no particular order).
 __global__ void __launch_bounds__(1024)
-k_tile_order(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+k_tile_order(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* __restrict__ zero_words,
+             int num_zero_words) {
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = tid; k < num_zero_words; k += 1024) zero_words[k] = 0u;       // K6's per-bin footprint counters (texgs.h tex_bin_count)
     auto bucket = [](uint32_t len) -> uint32_t {            // monotone decreasing in len: 1023 = empty, 0 = longest
         if (len == 0u) return 1023u;
         const uint32_t e = 31u - (uint32_t)__clz((int)len);              // floor(log2 len), 0..31
@@ -294,14 +323,14 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- scratch layouts ------------------------------------------------------------------------------------------------
 // scan_temp (Gaussian level, sized by scan_temp_bytes(N)):
-//   [0]        zeroed header: 4 x (gtable + total) of the depth passes | 64 bytes: [0] D total
-//   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)])
+//   [0]        header zero-filled by K1: 4 x (gtable + total) of the depth passes
+//   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)]), block_D (u32[ceil(N / 256)])
 // sort_temp (instance level, sized by sort_temp_bytes(capacity, T)):
-//   [0]        zeroed header: 3 x (gtable + total) of the tile passes
+//   [0]        header zero-filled by K3: 3 x (gtable + total) of the tile passes
 //   then       3 x table, elem_tmp (u64[capacity])
 struct GaussScratch {
     uint32_t* tables;       // 4 passes
-    uint32_t* total_D;
+    uint32_t* block_D;      // [ceil(N / 256)] K1's per-workgroup sums of tiles_touched (the host adds them up: D)
     uint32_t *key_a, *key_b, *val_a, *val_b, *bsum;
     size_t header_bytes;
 };
@@ -310,15 +339,15 @@ inline GaussScratch gauss_scratch(void* base, int N) {
     GaussScratch g;
     char* p = (char*)base;
     g.tables = (uint32_t*)p;
-    g.total_D = (uint32_t*)(p + 4 * RS_ZERO_WORDS * 4);
-    g.header_bytes = zero_header_bytes(4, 64);
+    g.header_bytes = zero_header_bytes(4, 0);
     p += g.header_bytes + align256(4 * (size_t)RS_MAX_BLOCKS * 256 * 4);
     const size_t nb = align256((size_t)(N > 0 ? N : 1) * 4);
     g.key_a = (uint32_t*)p; p += nb;
     g.key_b = (uint32_t*)p; p += nb;
     g.val_a = (uint32_t*)p; p += nb;
     g.val_b = (uint32_t*)p; p += nb;
-    g.bsum = (uint32_t*)p;
+    g.bsum = (uint32_t*)p; p += align256(((size_t)(N > 0 ? N : 1) + SC_PER - 1) / SC_PER * 4 + 256);
+    g.block_D = (uint32_t*)p;
     return g;
 }
 // pass `pass` of `passes`: its (gtable, total) sit in the zeroed header at `base`, its table after the header
@@ -340,8 +369,8 @@ inline void pass_geometry(uint32_t n, uint32_t& blocks, uint32_t& per) {
 
 size_t scan_temp_bytes(int N) {
     const size_t n = (size_t)(N > 0 ? N : 1);
-    return zero_header_bytes(4, 64) + align256(4 * (size_t)RS_MAX_BLOCKS * 256 * 4) + 4 * align256(n * 4)
-         + align256(((n + SC_PER - 1) / SC_PER) * 4 + 256);
+    return zero_header_bytes(4, 0) + align256(4 * (size_t)RS_MAX_BLOCKS * 256 * 4) + 4 * align256(n * 4)
+         + align256(((n + SC_PER - 1) / SC_PER) * 4 + 256) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * 4);
 }
 
 constexpr int TILE_PASSES_MAX = 3;      // tile ids up to 2^24 in digits of at most 8 bits (the count / scatter kernels index 256-entry LDS tables)
@@ -353,13 +382,12 @@ size_t sort_temp_bytes(uint32_t D, uint32_t T) {
     return sort_tables_bytes() + align256((size_t)(D > 0 ? D : 1) * 8);
 }
 
-uint32_t* bin_total_ptr(const TexGSGeom* g, int N) { return gauss_scratch(g->scan_temp, N).total_D; }
-
-// Zero the group / total count tables of the passes and the D total (the only memsets of a forward: 70 KB + 35 KB).
-int launch_bin_header(const TexGSGeom* g, int N, hipStream_t s) {
-    return (int)hipMemsetAsync(g->scan_temp, 0, gauss_scratch(g->scan_temp, N).header_bytes, s);
+uint32_t* bin_block_sums_ptr(const TexGSGeom* g, int N) { return gauss_scratch(g->scan_temp, N).block_D; }
+uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // group / total count tables of the depth passes: K1 zero-fills them
+    const GaussScratch gs = gauss_scratch(g->scan_temp, N);
+    *words = (int)(gs.header_bytes / 4);
+    return gs.tables;
 }
-int launch_sort_header(void* sort_temp, hipStream_t s) { return (int)hipMemsetAsync(sort_temp, 0, zero_header_bytes(TILE_PASSES_MAX, 0), s); }
 
 // Gaussian level: depth sort (4 passes) + exclusive scan of tiles_touched in rank order.  Needs K1's depth keys
 // (bits of view z; 0xFFFFFFFF for culled) in g->depth.  Independent of D: runs while the host waits for the D readback.
@@ -372,7 +400,7 @@ int launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s) {
     const uint32_t* vin = nullptr;                        // first pass: value = index
     uint32_t* kout = gs.key_a; uint32_t* vout = gs.val_a;
     for (int pass = 0; pass < 4; ++pass) {
-        const RadixTables t = tables_at(gs.tables, pass, 4, 64);
+        const RadixTables t = tables_at(gs.tables, pass, 4, 0);
         hipLaunchKernelGGL(k_radix_count<uint32_t>, dim3(blocks), dim3(RS_THREADS), 0, s, kin, (const uint32_t*)nullptr, (uint32_t)N,
                            per, pass * 8, 255u, t);
         hipLaunchKernelGGL((k_radix_scatter<uint32_t, 0>), dim3(blocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout,
@@ -395,7 +423,8 @@ void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hi
     const GaussScratch gs = gauss_scratch(g->scan_temp, c.N);
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
     hipLaunchKernelGGL(k_duplicate, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, gs.val_b, g->offsets,
-                       g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges));
+                       g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges),
+                       reinterpret_cast<uint32_t*>(b->sort_temp), (int)(zero_header_bytes(TILE_PASSES_MAX, 0) / 4));
 }
 
 // Instance level: stable LSD sort by tile id in 1-3 digits of at most 8 bits (two for up to 65 536 tiles); the last pass
@@ -436,7 +465,7 @@ int launch_sort(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStrea
     return (int)hipGetLastError();
 }
 
-void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s) {
+void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int num_zero_words, hipStream_t s) {
     const uint32_t T = (uint32_t)(c.tiles_x * c.tiles_y);
     if (b->num_rendered == 0) (void)hipMemsetAsync(b->ranges, 0, sizeof(uint32_t) * 2 * T, s);     // no K3 ran: every tile is empty
     if (b->num_rendered > 0) {
@@ -444,5 +473,6 @@ void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s) {
         hipLaunchKernelGGL(k_ranges, dim3(blocks), dim3(TG_BLOCK), 0, s, b->num_rendered, b->keys_sorted,
                            reinterpret_cast<uint2*>(b->ranges));
     }
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, reinterpret_cast<const uint2*>(b->ranges), b->tile_order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, reinterpret_cast<const uint2*>(b->ranges), b->tile_order,
+                       zero_words, num_zero_words);
 }

@@ -58,15 +58,14 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
 void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                            TexGSGrads* gr, hipStream_t s);
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s);
-int  launch_bin_header(const TexGSGeom* g, int N, hipStream_t s);
-int  launch_sort_header(void* sort_temp, hipStream_t s);
 int  launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s);
-uint32_t* bin_total_ptr(const TexGSGeom* g, int N);
+uint32_t* bin_block_sums_ptr(const TexGSGeom* g, int N);
+uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words);
 size_t scan_temp_bytes(int N);
 size_t sort_temp_bytes(uint32_t D, uint32_t T);
 void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStream_t s);
 int  launch_sort(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStream_t s);
-void launch_ranges(const CamConst& c, TexGSBinning* b, hipStream_t s);
+void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int num_zero_words, hipStream_t s);
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s);
 size_t tex_bin_count(int R);

@@ -235,11 +235,13 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ uvs,
                  const float* __restrict__ juv, const float* __restrict__ coff,
                  float4* __restrict__ rec_test, float4* __restrict__ rec_shade, float* __restrict__ depth, int32_t* __restrict__ radii,
-                 uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ total_D) {
+                 uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_D,
+                 uint32_t* __restrict__ zero_words, int num_zero_words) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
     __shared__ uint32_t s_tt[TG_BLOCK / 64];
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
     const bool live = i < C.N;
+    for (int k = i; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // count tables of the depth sort (K2)
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     g.valid = false;
@@ -258,7 +260,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
         for (int k = threadIdx.x; k < count; k += TG_BLOCK) s_sh[k] = shs[first + k];
         __syncthreads();
     }
-    {   // D = sum of tiles_touched: one atomic per workgroup (the host reads it back while the depth sort runs)
+    {   // D = sum of tiles_touched: one partial sum per workgroup; the host reads them back (while the depth sort runs) and adds
         uint32_t tt = (live && g.valid) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
         for (int d = 32; d >= 1; d >>= 1) tt += __shfl_xor(tt, d, 64);
         if ((threadIdx.x & 63) == 0) s_tt[threadIdx.x >> 6] = tt;
@@ -266,7 +268,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
         if (threadIdx.x == 0) {
             uint32_t sum = 0u;
             for (int w = 0; w < TG_BLOCK / 64; ++w) sum += s_tt[w];
-            if (sum != 0u) atomicAdd(total_D, sum);
+            block_D[blockIdx.x] = sum;
         }
     }
     if (!live) return;
@@ -560,11 +562,13 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     if (c.N <= 0) return;
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
     const size_t lds = (in->shs && c.sh_degree > 0) ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
+    int hdr_words = 0;
+    uint32_t* hdr = bin_header_ptr(g, c.N, &hdr_words);
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset,
                        reinterpret_cast<float4*>(g->rec_test), reinterpret_cast<float4*>(g->rec_shade), g->depth, g->radii,
                        reinterpret_cast<uint2*>(g->rect),
-                       g->tiles_touched, bin_total_ptr(g, c.N));
+                       g->tiles_touched, bin_block_sums_ptr(g, c.N), hdr, hdr_words);
 }
 
 void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
