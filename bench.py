@@ -317,10 +317,13 @@ def main():
         op = leaves["opacities"].detach().clamp(1e-6, 1 - 1e-6)
         raw["opacities"] = torch.log(op / (1 - op)).requires_grad_(True)
 
+        compat_settings = {v: settings(cams[v]) for v in my_views[:max(4, min(16, len(my_views)))]}     # the reference's cameras
+        # live on the GPU (utils/cameras.py:62-65); the rasterizer module itself is built per call (render/uv_tex_render.py:40)
+
         def compat_view(v):
             m2 = torch.zeros_like(raw["means3D"], requires_grad=True) + 0
             m2.retain_grad()
-            out = GaussianRasterizer(settings(cams[v]))(
+            out = GaussianRasterizer(compat_settings[v])(
                 means3D=raw["means3D"], means2D=m2, shs=raw["shs"], opacities=torch.sigmoid(raw["opacities"]),
                 scales=torch.exp(raw["scales"]), rotations=torch.nn.functional.normalize(raw["rotations"]),
                 uvs=raw["uvs"], gradient_uvs=juv, texture=raw["texture"], extra_attrs=None)

@@ -210,75 +210,121 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         frame = _make_frame(st, N, K, R, device, keep)
         inputs = _lib.Inputs(_ptr(means3D), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(rotations),
                              _ptr(uvs), _ptr(gradient_uvs), _ptr(texture), _ptr(color_offset))
-        # per-Gaussian state
-        i32 = dict(dtype=torch.int32, device=device)
-        f32 = dict(dtype=torch.float32, device=device)
-        rec = torch.empty(max(N, 1), _lib.REC_TEST_FLOATS, **f32)           # test records: xy, conic, opacity, cull aids
-        rec_shade = torch.empty(max(N, 1), _lib.REC_SHADE_FLOATS, **f32)
-        depth = torch.empty(max(N, 1), **f32)
-        radii = torch.empty(N, **i32)          # K1 writes every entry (0 for culled)
-        rect = torch.empty(max(N, 1), 2, **i32)
-        tiles_touched = torch.empty(max(N, 1), **i32)
-        offsets = torch.empty(max(N, 1), **i32)
+        i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+        n1 = max(N, 1)
+        # Everything the kernels keep between forward and backward lives in TWO allocations (one sized by N / the image, one by
+        # the instance capacity): ~20 separate torch.empty calls were ~0.1 ms of host time per view.  Tensor views of the
+        # pieces are made on demand (tests, diagnostics).
         scan_bytes = lib.texgs_scan_temp_bytes(N)
-        scan_temp = torch.empty(scan_bytes, dtype=torch.uint8, device=device)
-        geom = _lib.Geom(_ptr(rec), _ptr(rec_shade), _ptr(depth), _ptr(radii), _ptr(rect), _ptr(tiles_touched), _ptr(offsets),
-                         _ptr(scan_temp), scan_bytes)
+        fix = _Arena(device)
+        fix.add("rec", (n1, _lib.REC_TEST_FLOATS), f32)          # test records: xy, conic, opacity, cull aids
+        fix.add("rec_shade", (n1, _lib.REC_SHADE_FLOATS), f32)
+        fix.add("depth", (n1,), f32)
+        fix.add("rect", (n1, 2), i32)
+        fix.add("tiles_touched", (n1,), i32)
+        fix.add("offsets", (n1,), i32)
+        fix.add("scan_temp", (scan_bytes,), u8)
+        fix.add("final_T", (H, W), f32)
+        fix.add("n_contrib", (H, W), i32)
+        fix.add("ranges", (tiles, 2), i32)              # zero-filled by K3
+        fix.add("tile_order", (tiles,), i32)
+        if for_backward and USE_TEX_BINS:
+            fix.add("tex_bin_count", (int(lib.texgs_tex_bin_count(R)),), i32)
+        if for_backward:
+            fix.add("surv_count", (4 * tiles,), i32)
+        fix.commit()
+        radii = torch.empty(N, dtype=i32, device=device)          # K1 writes every entry (0 for culled)
+        geom = _lib.Geom(fix.ptr("rec"), fix.ptr("rec_shade"), fix.ptr("depth"), _ptr(radii), fix.ptr("rect"),
+                         fix.ptr("tiles_touched"), fix.ptr("offsets"), fix.ptr("scan_temp"), scan_bytes)
         # everything is allocated BEFORE the one device->host sync, the D-sized buffers from a capacity hint
         # (largest D seen on this device x 1.25): texgs_forward then runs K1 -> sync -> K3..K6 with no host work between
-        out_color = torch.empty(3, H, W, **f32)
-        out_depth = torch.empty(1, H, W, **f32)
-        out_norm = torch.empty(3, H, W, **f32)
-        out_alpha = torch.empty(1, H, W, **f32)
-        final_T = torch.empty(H, W, **f32)
-        n_contrib = torch.empty(H, W, **i32)
-        tex_bin_count = torch.empty(int(lib.texgs_tex_bin_count(R)), **i32) if (for_backward and USE_TEX_BINS) else None
-        surv_count = torch.empty(4 * tiles, **i32) if for_backward else None
-        img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), _ptr(final_T),
-                         _ptr(n_contrib), _ptr(tex_bin_count), None, None, _ptr(surv_count))
-        ranges = torch.empty(tiles, 2, **i32)          # zero-filled by K3
-        tile_order = torch.empty(tiles, **i32)
+        out_color = torch.empty(3, H, W, dtype=f32, device=device)
+        out_depth = torch.empty(1, H, W, dtype=f32, device=device)
+        out_norm = torch.empty(3, H, W, dtype=f32, device=device)
+        out_alpha = torch.empty(1, H, W, dtype=f32, device=device)
+        img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), fix.ptr("final_T"),
+                         fix.ptr("n_contrib"), fix.ptr("tex_bin_count"), None, None, fix.ptr("surv_count"))
 
         def alloc_bin(cap):
-            keys_u = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
-            keys_s = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
-            point_list = torch.empty(max(cap, 1), **i32)
+            c1 = max(cap, 1)
             sort_bytes = lib.texgs_sort_temp_bytes(cap, tiles)
-            sort_temp = torch.empty(sort_bytes, dtype=torch.uint8, device=device)
-            b = _lib.Binning(0, _ptr(keys_u), _ptr(keys_s), _ptr(point_list), _ptr(ranges), _ptr(tile_order), _ptr(sort_temp),
-                             sort_bytes)
-            # K6 -> K7 hand-off of the per-block survivor lists: four blocks per tile, each at most the tile's list length
-            surv = torch.empty(4 * max(cap, 1), 2, **i32) if for_backward else None
-            surv_qm = torch.empty(4 * max(cap, 1), dtype=torch.int16, device=device) if for_backward else None
-            img.survivors, img.surv_qmask = _ptr(surv), _ptr(surv_qm)
-            return b, (keys_u, keys_s, point_list, sort_temp, surv, surv_qm)
+            ar = _Arena(device)
+            ar.add("keys_unsorted", (c1,), torch.int64)
+            ar.add("keys_sorted", (c1,), torch.int64)
+            ar.add("point_list", (c1,), i32)
+            ar.add("sort_temp", (sort_bytes,), u8)
+            if for_backward:        # K6 -> K7 hand-off of the per-block survivor lists: four blocks per tile, each at most the tile's list length
+                ar.add("survivors", (4 * c1, 2), i32)
+                ar.add("surv_qmask", (4 * c1,), torch.int16)
+            ar.commit()
+            b = _lib.Binning(0, ar.ptr("keys_unsorted"), ar.ptr("keys_sorted"), ar.ptr("point_list"), fix.ptr("ranges"),
+                             fix.ptr("tile_order"), ar.ptr("sort_temp"), sort_bytes)
+            img.survivors, img.surv_qmask = ar.ptr("survivors"), ar.ptr("surv_qmask")
+            return b, ar
         hint_key = (device.index, N, H, W)
         cap = _CAPACITY_HINT.get(hint_key, max(4 * N, 1024))
-        binning, bin_t = alloc_bin(cap)
+        binning, bin_ar = alloc_bin(cap)
         d_host = C.c_uint32(0)
         rc = lib.texgs_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning), cap, C.byref(img),
                                C.byref(d_host), stream)
         D = int(d_host.value)
         if rc == _lib.ERR_CAPACITY:             # rare: grow and run the second half
             cap = int(D * 1.25) + 1024
-            binning, bin_t = alloc_bin(cap)
+            binning, bin_ar = alloc_bin(cap)
             binning.num_rendered = D
             rc = lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
                                                    C.byref(img), stream)
         _lib.check(rc, "texgs_forward")
         _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
-        keys_u, keys_s, point_list, sort_temp, surv, surv_qm = bin_t
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
-    s.tensors = dict(keep=keep, rec=rec, rec_shade=rec_shade, depth=depth, radii=radii, rect=rect, tiles_touched=tiles_touched,
-                     offsets=offsets, keys_unsorted=keys_u, keys_sorted=keys_s,
-                     point_list=point_list, ranges=ranges, tile_order=tile_order,
-                     final_T=final_T, n_contrib=n_contrib, tex_bin_count=tex_bin_count,
-                     survivors=surv, surv_qmask=surv_qm, surv_count=surv_count,
-                     scan_temp=scan_temp, sort_temp=sort_temp,
-                     out=(out_color, out_depth, out_norm, out_alpha))
+    s.tensors = _Tensors((fix, bin_ar), keep=keep, radii=radii, out=(out_color, out_depth, out_norm, out_alpha))
     return (out_color, out_depth, out_norm, out_alpha, radii), s
+
+
+class _Arena:
+    """One device allocation carved into named, 256-byte-aligned pieces."""
+
+    def __init__(self, device):
+        self.device, self.specs, self.size, self.buf = device, {}, 0, None
+
+    def add(self, name, shape, dtype):
+        off = (self.size + 255) & ~255
+        self.specs[name] = (off, tuple(shape), dtype)
+        self.size = off + math.prod(shape) * torch.empty(0, dtype=dtype).element_size()
+
+    def commit(self):
+        self.buf = torch.empty(max(self.size, 1), dtype=torch.uint8, device=self.device)
+
+    def ptr(self, name):
+        return self.buf.data_ptr() + self.specs[name][0] if name in self.specs else None
+
+    def view(self, name):
+        off, shape, dtype = self.specs[name]
+        n = math.prod(shape) * torch.empty(0, dtype=dtype).element_size()
+        return self.buf[off:off + n].view(dtype).view(shape)
+
+
+class _Tensors(dict):
+    """What a forward leaves behind, by name: real tensors (inputs kept alive, outputs) plus views into the arenas, made on
+    first access.  A name that was not allocated (e.g. the survivor lists of a forward-only call) reads as None."""
+
+    def __init__(self, arenas, **real):
+        super().__init__(**real)
+        self._arenas = arenas
+
+    def __missing__(self, name):
+        for ar in self._arenas:
+            if name in ar.specs:
+                self[name] = v = ar.view(name)
+                return v
+        self[name] = None
+        return None
+
+    def get(self, name, default=None):
+        v = self[name]
+        return default if v is None else v
 
 
 def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None, before_accumulate=None):
