@@ -247,9 +247,11 @@ int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_i
 
 /* Pseudo-normal and validity mask from the operator's depth output -- norm_from_depth of losses/norm_reg_loss.py:16-63, the
  * producer of (gt_norm, mask) for the normal-regularisation term norm_reg_loss (:73-78, models/texture_gaussian3d.py:360-363;
- * the reference detaches depth there, so there is no backward).  depth f32[1,H,W]; cam_to_world = 12 HOST floats, rows 0..2 of
- * inverse(world_view_transform^T) (camera -> world, column-vector convention); out_norm f32[3,H,W]; out_mask f32[1,H,W]. */
-int texgs_norm_from_depth(const float* depth, const float* cam_to_world, float tanfovx, float tanfovy, int32_t H, int32_t W,
+ * the reference detaches depth there, so there is no backward).  depth f32[1,H,W]; viewmatrix = DEVICE f32[16], the camera's
+ * world_view_transform as the reference stores it (row-vector form, the same tensor TexGSFrame.viewmatrix points to): the
+ * kernel inverts it itself (camera -> world), so the loss needs neither a host copy nor a sync; out_norm f32[3,H,W];
+ * out_mask f32[1,H,W]. */
+int texgs_norm_from_depth(const float* depth, const float* viewmatrix, float tanfovx, float tanfovy, int32_t H, int32_t W,
                           float threshold, float* out_norm, float* out_mask, void* stream);
 
 /* Fused UV-Taylor producer: the operator inputs `uvs` and `gradient_uvs` straight from the Gaussian centres, replacing
@@ -268,6 +270,12 @@ typedef struct TexGSUVNet {
 } TexGSUVNet;
 size_t texgs_uv_taylor_temp_bytes(void);
 int texgs_uv_taylor(const TexGSUVNet* net, const float* xyz, int32_t N, float* uvs, float* grad_uvs, void* temp, void* stream);
+/* The same in two steps, for callers that evaluate one set of weights many times (every view of a retexture / viewer session,
+ * every forward between two optimizer steps): texgs_uv_pack re-orders W2..W4 for the matrix cores into `packed`
+ * (texgs_uv_taylor_temp_bytes() bytes) once, texgs_uv_taylor_packed evaluates with it. */
+int texgs_uv_pack(const TexGSUVNet* net, void* packed, void* stream);
+int texgs_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
+                           void* stream);
 
 /* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
  * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,

@@ -25,6 +25,13 @@ no source) travel to the GPU box, the reference does not.
                itself cannot be imported here (cv2, tinycudann, nvdiffrast), so the four function definitions are taken
                from its source with `ast` at generation time and RUN (nothing of them is stored); input = a 12-px-per-face
                downsample of assets/textures/mosaic.png and a random SH-DC texture
+  ckpt_stage3.pth  a stage-3 checkpoint FILE as the reference writes it: TextureGaussian3D.setup_optim and .state_dict
+               (models/texture_gaussian3d.py:99-172; method definitions taken from the source with `ast` and RUN on a stand-in
+               object) + torch.save((state_dict, iteration)) of train.py:181-184.  40 Gaussians, R = 4; nn.Parameter entries,
+               three Adam states after one step, the ChainedScheduler state; uv_net / inv_uv_net hold their weights the way
+               the shipped configs do (`use_tcnn: True`: one flat `params` tensor per tiny-cuda-nn network -- stand-in
+               modules with that one parameter, tinycudann itself is not installable here).  ckpt_stage3_expect.npz: uvs of
+               16 points by plain float64 torch from the matrices that were packed into those flat tensors.
   op_small.npz the operator itself on a tiny seeded scene, as computed by oracle/texgs_torch.py in float64
                (regression pin of the oracle; the reference holds no vector for the operator: parity unpinned)
 """
@@ -291,6 +298,80 @@ def texture_io():
     np.savez_compressed(os.path.join(HERE, "texture_io.npz"), **out)
 
 
+def checkpoint():
+    import ast
+    from torch import nn
+    from texgs.uvnet import pack_tcnn_params, HIDDEN
+    sys.path.insert(0, REF)
+    from utils.general import get_expon_lr_func                       # importable reference piece (pure python)
+    src = open(os.path.join(REF, "models", "texture_gaussian3d.py")).read()
+    tree = ast.parse(src)
+    meths = [n for cls in tree.body if isinstance(cls, ast.ClassDef) and cls.name == "TextureGaussian3D"
+             for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("setup_optim", "state_dict")]
+    assert len(meths) == 2
+    ns = {"torch": torch, "nn": nn, "get_expon_lr_func": get_expon_lr_func}
+    exec(compile(ast.Module(body=meths, type_ignores=[]), "<reference TextureGaussian3D methods>", "exec"), ns)
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+
+    class TcnnLike(nn.Module):           # what a tcnn.Network looks like to state_dict(): one flat parameter called `params`
+        def __init__(self, flat):
+            super().__init__()
+            self.params = nn.Parameter(flat.clone())
+
+    g = torch.Generator().manual_seed(9)
+    rn = lambda *sh, s=1.0: torch.randn(*sh, generator=g) * s
+    pre = [(rn(HIDDEN, 3), rn(HIDDEN, s=0.3)), (rn(HIDDEN, HIDDEN, s=0.1), None)]
+    mlp = [(rn(HIDDEN, HIDDEN, s=0.1), None), (rn(HIDDEN, HIDDEN, s=0.1), None), (rn(3, HIDDEN), None)]
+
+    class Net(nn.Module):
+        def __init__(self, a, b):
+            super().__init__()
+            self.pre_mlp, self.mlp = a, b
+    uv_net = Net(TcnnLike(pack_tcnn_params(pre, 3, HIDDEN)), TcnnLike(pack_tcnn_params(mlp, HIDDEN, 3)))
+    # inv_uv_net: hash-grid encoding + MLP = nn.Sequential(enc, mlp) -> keys pre_mlp.0.params / pre_mlp.1.params
+    inv_net = Net(nn.Sequential(TcnnLike(rn(4096, s=0.01)), TcnnLike(rn(32 * 128 + 128 * 128, s=0.1))), TcnnLike(rn(2 * 128 * 128 + 16 * 128, s=0.1)))
+    N, R = 40, 4
+
+    class Stub:
+        pass
+    m = Stub()
+    m.max_sh_degree, m.active_sh_degree, m.spatial_lr_scale = 3, 3, 1.7
+    m._xyz = nn.Parameter(rn(N, 3)); m._scaling = nn.Parameter(rn(N, 3) - 4.0); m._rotation = nn.Parameter(rn(N, 4))
+    m._opacity = nn.Parameter(rn(N, 1)); m._shs = nn.Parameter(rn(N, 15, 3, s=0.1)); m._texture = nn.Parameter(rn(6, R, R, 3))
+    m.uv_net, m.inv_uv_net, m.geo_emb = uv_net, inv_net, nn.Embedding(1, 128)
+    optim_cfg = Cfg(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+                    opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, tex_lr=0.0025, uv_net_lr=0.00002, inv_uv_net_lr=0.00002,
+                    uv_net_milestones=[10000, 20000], uv_net_gamma=0.1)
+    ns["setup_optim"](m, optim_cfg)
+    loss = sum((p ** 2).sum() for p in (m._xyz, m._scaling, m._rotation, m._opacity, m._shs, m._texture)) \
+        + sum((p ** 2).sum() for net in (uv_net, inv_net, m.geo_emb) for p in net.parameters())
+    loss.backward()
+    for o in (m.optimizer, m.optimizer_uv, m.optimizer_tex):
+        o.step()
+    m.scheduler_uv.step()
+    sd = ns["state_dict"](m)
+    torch.save((sd, 40000), os.path.join(HERE, "ckpt_stage3.pth"))           # train.py:181-184
+    # what the flat uv_net state evaluates to (plain float64 torch on the matrices AFTER the optimizer step: unpack by hand here)
+    def mats(flat, n_in, n_out, hidden):
+        pin, pout = -(-n_in // 16) * 16, -(-n_out // 16) * 16
+        shapes = [(128, pin)] + [(128, 128)] * (hidden - 1) + [(pout, 128)]
+        out, off = [], 0
+        for a, b in shapes:
+            out.append(flat[off:off + a * b].reshape(a, b).double()); off += a * b
+        return out
+    p1, p2 = mats(uv_net.pre_mlp.params.detach(), 3, 128, 1)
+    q1, q2, q3 = mats(uv_net.mlp.params.detach(), 128, 3, 2)
+    xyz = torch.randn(16, 3, generator=g).double()
+    emb = m.geo_emb.weight.detach()[0].double()
+    x16 = torch.cat([xyz, torch.ones(16, 13, dtype=torch.float64)], 1)            # identity encoding padded with ones
+    h = torch.relu(x16 @ p1.t()); a = torch.relu(h @ p2.t() + emb)
+    h = torch.relu(torch.relu(a @ q1.t()) @ q2.t()); o = (h @ q3.t())[:, :3]
+    np.savez_compressed(os.path.join(HERE, "ckpt_stage3_expect.npz"), xyz=xyz.numpy(), uvs=torch.nn.functional.normalize(o, dim=-1).numpy(),
+                        xyz_param=m._xyz.detach().numpy(), texture=m._texture.detach().numpy())
+
+
 def op_small():
     from texgs import synth
     import helpers as Hh
@@ -309,7 +390,7 @@ def op_small():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "norm_from_depth", "host_terms", "uvnet", "texture_io", "op_small"]
+    which = sys.argv[1:] or ["cameras", "sh", "cube", "losses", "geom_losses", "norm_from_depth", "host_terms", "uvnet", "texture_io", "checkpoint", "op_small"]
     for name in which:
         globals()[name]()
     print("golden fixtures written to", HERE)

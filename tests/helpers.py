@@ -112,8 +112,11 @@ def rel_err(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=0.005, global_rel=2e-2, label=None):
-    """Robust gradient comparison.  fp32 (HIP) vs fp64 (oracle) differ by isolated discrete events -- a
+def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=None, global_rel=1e-2, label=None):
+    """Robust gradient comparison.  Bars ~5x the slack measured on MI355X (profiles/r03_parity_report.jsonl): global
+    relative L2 <= 1e-2 (worst measured 7.1e-3: C5 `uvs`; small cases <= 5.9e-3 with 11 of 1000 rows off, 3e-5 without
+    them); outlier rows <= 0.15 % when there are >= 1e5 rows (worst measured 0.075 %), <= 0.5 % (at least 20) below that
+    -- a 256x256 image has ~13 discrete flips whatever N is.  fp32 (HIP) vs fp64 (oracle) differ by isolated discrete events -- a
     bilinear cell chosen differently for one (pixel, Gaussian) pair changes that pair's dL/duv by O(1), a
     1/255 or clamp threshold decided differently adds or removes one pair -- so a handful of rows may be off
     while everything else agrees to rounding.  Rows = first dimension (Gaussians / cubemap faces*rows).
@@ -131,6 +134,8 @@ def grad_close(got, exp, row_rtol=1e-3, row_atol_frac=1e-4, max_outlier_frac=0.0
     err = (g - e).abs().max(dim=1).values
     tol = row_rtol * e.abs().max(dim=1).values + row_atol_frac * gmax
     nbad = int((err > tol).sum())
+    if max_outlier_frac is None:
+        max_outlier_frac = 0.0015 if g.shape[0] >= 100000 else 0.005
     budget = max(int(max_outlier_frac * g.shape[0]), 20)    # ~13 cell flips per 256x256 image are expected
     rel = float((g - e).norm() / e.norm())
     ok = (nbad <= budget) and (rel <= global_rel)

@@ -270,9 +270,9 @@ def test_c5_full_size_vs_c_oracle(lib_built):
     nc = t["n_contrib"].cpu().numpy().astype(np.uint32)
     Hh.report("hip_vs_c32/c5/fwd", D=D, pixels_over_1e4th_frac=float(bad.float().mean()), worst_pixel=float((err / scale).max()),
               n_contrib_agree_frac=float((nc == ref.n_contrib).mean()))
-    assert float(bad.float().mean()) < 2e-3
-    assert float((err / scale).max()) < 2e-2
-    assert float((nc == ref.n_contrib).mean()) > 0.998
+    assert float(bad.float().mean()) < 3e-4          # measured 5.5e-5 (profiles/r03_parity_report.jsonl)
+    assert float((err / scale).max()) < 5e-3         # measured 4.3e-4
+    assert float((nc == ref.n_contrib).mean()) > 0.9995
     H, W = 1200, 1600
     g = torch.Generator().manual_seed(55)
     dout = torch.randn(8, H, W, generator=g) / (H * W)

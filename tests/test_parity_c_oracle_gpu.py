@@ -2,9 +2,12 @@
 
 Bit-exact (integer / index work): radii, tile rects, tiles_touched, offsets, D, unsorted keys, sorted keys, point list,
 tile ranges -- at small sizes AND at BASELINE's full sizes (configs[1] 100k/512^2 and configs[2] 300k/1024^2, 800x800).
-Floating point at full size: >= 99.8 % of pixels within 1e-4 of the C oracle (the rest are threshold decisions that
-hardware exp/rcp decide differently: alpha >= 1/255, T >= 1e-4, bilinear cell), worst pixel < 2e-2; gradients by
-helpers.grad_close.  Plus size-independent properties on the GPU outputs themselves."""
+Floating point at full size: >= 99.97 % of pixels within 1e-4 of the C oracle (the rest are threshold decisions that
+hardware exp/rcp decide differently: alpha >= 1/255, T >= 1e-4, bilinear cell), worst pixel < 5e-3; gradients by
+helpers.grad_close with the full-size bars (global rel-L2 <= 1e-2, <= 0.15 % outlier rows).  The bars are ~5x the slack
+measured on MI355X (profiles/r03_parity_report.jsonl: C3 1.6e-6 of pixels / worst 9.9e-4, C5 5.5e-5 / 4.3e-4; worst
+gradient global rel-L2 7.1e-3 (C5 uvs), worst outlier fraction 7.5e-4).  Plus size-independent properties on the GPU
+outputs themselves."""
 import math
 
 import numpy as np
@@ -88,9 +91,9 @@ def test_forward_full_size_vs_c_oracle(lib_built, name):
     Hh.report(f"hip_vs_c32/{name}/fwd", pixels_over_1e4th_frac=float(bad.float().mean()), worst_pixel=float((err / scale).max()),
               median_err=float(err.median()), p999_err=float(err.flatten().kthvalue(int(0.999 * err.numel())).values),
               n_contrib_agree_frac=float((nc == ref.n_contrib).mean()))
-    assert float(bad.float().mean()) < 2e-3, float(bad.float().mean())
-    assert float((err / scale).max()) < 2e-2
-    assert float((nc == ref.n_contrib).mean()) > 0.998
+    assert float(bad.float().mean()) < 3e-4, float(bad.float().mean())
+    assert float((err / scale).max()) < 5e-3
+    assert float((nc == ref.n_contrib).mean()) > 0.9995
 
 
 @pytest.mark.parametrize("name", ["small", "c3"])
@@ -172,8 +175,8 @@ def test_stress_scene_vs_c_oracle(lib_built):
     got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
     err = (got - torch.tensor(ref.out)).abs()
     scale = torch.ones(8, 1, 1); scale[3] = 10.0
-    assert float(((err > 1e-4 * scale).any(dim=0)).float().mean()) < 5e-3
-    assert float((err / scale).max()) < 5e-2
+    assert float(((err > 1e-4 * scale).any(dim=0)).float().mean()) < 2e-3
+    assert float((err / scale).max()) < 2e-2
     H, W = cam.image_height, cam.image_width
     gen = torch.Generator().manual_seed(11)
     dout = torch.randn(8, H, W, generator=gen) / (H * W)
@@ -183,6 +186,6 @@ def test_stress_scene_vs_c_oracle(lib_built):
     gref = ref.backward(dout.numpy())
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
         assert bool(torch.isfinite(got_g).all()), name_
-        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.01, global_rel=5e-2,
+        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.005, global_rel=1e-2,
                                 label=f"hip_vs_c32/stress/bwd/{name_}")
         assert ok, (name_, msg)

@@ -3,8 +3,16 @@
 Tolerances: per-pixel RGB / alpha within 1e-4 (BASELINE.json north_star) on every pixel whose discrete
 decisions (alpha >= 1/255, T >= 1e-4, power <= 0, cubemap face, den >= DEN_MIN) are not within fp32 rounding
 of their thresholds; those 'ambiguous' pixels (flagged by the oracle) must be < 0.5 % of the image and stay
-within 2e-2.  Gradients: helpers.grad_close -- every row (Gaussian / texel) within 1e-3 relative + 1e-4 of the largest
-entry, at most max(0.5 %, 20) outlier rows (isolated fp32-vs-fp64 discrete events), and global relative L2 <= 2e-2.
+within 5e-3 (measured worst 1.3e-3).  Gradients: helpers.grad_close -- every row (Gaussian / texel) within 1e-3 relative +
+1e-4 of the largest entry, at most max(0.5 %, 20) outlier rows (isolated fp32-vs-fp64 discrete events), and global
+relative L2 <= 1e-2.
+
+Where the 1e-4 bar is nearly used up (measured 9.49e-5 / 9.34e-5 on the two 4000-Gaussian cases, <= 7.7e-5 elsewhere): it
+is the IMAGE channel only (depth / normal / alpha, which do not go through the texture, stay below 4.6e-5 on the same
+pixels), on a 128^2 white-noise cubemap.  The term that carries it is therefore the bilinear texture sample: fp32 cancellation in the UV Taylor step uv = phi + G dp / (1 + g.dp) leaves ~1e-4 texel of
+error in (col, row), a white-noise texel differs from its neighbour by O(1) SH-DC units, so
+C0 * |d tex / d col| * 1e-4 ~ 3e-5 per contributor, summed over ~3 contributors at alpha*T ~ 1.  The fp32 C oracle itself
+sits at 9e-5 from the fp64 oracle on these cases -- it is fp32 arithmetic of the contract, not the kernel.
 """
 import pytest
 import torch
@@ -50,7 +58,7 @@ def test_forward_matches_oracle(lib_built, case):
         scale = 1.0 if name != "depth" else 4.0        # depth is in scene units (~3.2), same relative bar
         clean = err[:, ~amb]
         assert clean.numel() == 0 or float(clean.max()) < 1e-4 * scale, (name, float(clean.max()))
-        assert float(err.max()) < 2e-2 * scale, (name, float(err.max()))
+        assert float(err.max()) < 5e-3 * scale, (name, float(err.max()))
     # radii: int32, compare exactly except where 3*sqrt(lambda) is within rounding of an integer
     r_got = out[4].cpu().to(torch.int64)
     r_exp = ref[4].to(torch.int64)

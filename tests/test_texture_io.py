@@ -91,3 +91,33 @@ def test_checkpoint_round_trip(tmp_path):
     torch.save(({"hyperparams": (0, 1.0), "params": (1, 2, 3)}, 1), p)
     with pytest.raises(ValueError, match="stage-3"):
         TIO.load_checkpoint(p)
+
+
+def test_reference_format_checkpoint_fixture():
+    """tests/golden/ckpt_stage3.pth was written by the REFERENCE's own TextureGaussian3D.setup_optim / state_dict
+    (models/texture_gaussian3d.py:99-172, run via `ast` by tests/golden/make_golden.py) and train.py's torch.save: nn.Parameter
+    entries, three Adam states, the scheduler state, tiny-cuda-nn style flat `params` for the UV networks.  load_checkpoint
+    must take it with weights_only=True, and the UV network it carries must evaluate to the stored uvs."""
+    from texgs.uvnet import UVNet
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    st = TIO.load_checkpoint(os.path.join(here, "ckpt_stage3.pth"))            # weights_only=True by default
+    E = np.load(os.path.join(here, "ckpt_stage3_expect.npz"))
+    N, R = 40, 4
+    assert st.iteration == 40000 and st.active_sh_degree == 3 and abs(st.spatial_lr_scale - 1.7) < 1e-12
+    assert tuple(st.xyz.shape) == (N, 3) and tuple(st.scaling.shape) == (N, 3) and tuple(st.rotation.shape) == (N, 4)
+    assert tuple(st.opacity.shape) == (N, 1) and tuple(st.shs.shape) == (N, 15, 3) and tuple(st.texture.shape) == (6, R, R, 3)
+    assert not any(t.requires_grad for t in st[:6])                              # nn.Parameter in the file, plain tensors out
+    assert np.array_equal(st.xyz.numpy(), E["xyz_param"]) and np.array_equal(st.texture.numpy(), E["texture"])
+    assert torch.allclose(st.get_rotation().norm(dim=1), torch.ones(N), atol=1e-6) and bool((st.get_scaling() > 0).all())
+    uv_state, inv_state, emb_state = st.net_state
+    assert set(uv_state) == {"pre_mlp.params", "mlp.params"} and set(emb_state) == {"weight"}
+    assert len(st.optim_state) == 4 and "param_groups" in st.optim_state[0]
+    net = UVNet().load_reference_state(uv_state).double()
+    uvs = net(torch.tensor(E["xyz"]), emb_state["weight"][0].double())
+    assert float((uvs - torch.tensor(E["uvs"])).abs().max()) < 1e-6
+    # and it goes back out in the same layout
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        TIO.save_checkpoint(st, os.path.join(d, "x.pth"))
+        sd, it = torch.load(os.path.join(d, "x.pth"), weights_only=True)
+        assert it == 40000 and set(sd) == {"hyperparams", "optim_state", "net_state", "params"} and len(sd["params"]) == 6

@@ -82,3 +82,93 @@ def test_fused_kernel_full_size_vs_float64_autograd(lib_built, variant):
     # [3*i+j] layout: J u = 0 would hold for J^T (d|uv|^2 = 0  =>  u^T J = 0), check the row index is the uv component
     uJ = torch.einsum("ni,nij->nj", uvs[idx.to(dev)].cpu().double(), J[idx.to(dev)].cpu().double().reshape(-1, 3, 3))
     assert float(uJ.abs().max()) < 1e-4 * float(ref_J.abs().max())
+
+
+def test_tcnn_flat_params_round_trip_and_first_layer_bias():
+    """tiny-cuda-nn FullyFusedMLP state (`use_tcnn: True`, every shipped config): one flat bias-free tensor per network,
+    input padded to 16 columns with ones (-> first-layer bias), output padded to 16 rows.  Layout restated from tiny-cuda-nn's
+    published source (unpinned: the package is absent here); this pins the loader against that statement and against the
+    nn.Linear evaluation of the same weights."""
+    from texgs.uvnet import unpack_tcnn_params, pack_tcnn_params, HIDDEN
+    g = torch.Generator().manual_seed(5)
+    pre = [(torch.randn(HIDDEN, 3, generator=g), torch.randn(HIDDEN, generator=g)), (torch.randn(HIDDEN, HIDDEN, generator=g) * 0.1, None)]
+    mlp = [(torch.randn(HIDDEN, HIDDEN, generator=g) * 0.1, None), (torch.randn(HIDDEN, HIDDEN, generator=g) * 0.1, None),
+           (torch.randn(3, HIDDEN, generator=g), None)]
+    fp, fm = pack_tcnn_params(pre, 3, HIDDEN), pack_tcnn_params(mlp, HIDDEN, 3)
+    assert fp.numel() == 128 * 16 + 128 * 128 and fm.numel() == 2 * 128 * 128 + 16 * 128          # the sizes tcnn reports for these nets
+    for flat, layers, (i, o, h) in ((fp, pre, (3, HIDDEN, 1)), (fm, mlp, (HIDDEN, 3, 2))):
+        for (w, b), (w2, b2) in zip(unpack_tcnn_params(flat.half(), i, o, h), layers):      # fp16 storage, as tcnn's native precision
+            assert torch.allclose(w, w2, atol=2e-3, rtol=1e-3) and ((b is None) == (b2 is None))
+            if b is not None:
+                assert torch.allclose(b, b2, atol=2e-3, rtol=1e-3)
+    with pytest.raises(ValueError, match="expected"):
+        unpack_tcnn_params(fp[:-1], 3, HIDDEN, 1)
+    # a module loaded from the flat form evaluates like one built from the matrices
+    net = UVNet().load_reference_state({"pre_mlp.params": fp, "mlp.params": fm})
+    ref = UVNet()
+    with torch.no_grad():
+        for lin, (w, b) in zip(ref._linears(), pre + mlp):
+            lin.weight.copy_(w)
+            lin.bias.zero_() if b is None else lin.bias.copy_(b)
+    x = torch.randn(50, 3, generator=g)
+    emb = torch.randn(HIDDEN, generator=g) * 0.2
+    assert torch.allclose(net(x, emb), ref(x, emb), atol=1e-6)
+    # the ones-padding: column 3 of the first matrix IS the bias
+    x16 = torch.cat([x, torch.ones(50, 13)], 1)
+    assert torch.allclose(x16 @ fp[:128 * 16].reshape(128, 16).t(), ref.pre_mlp[0](x), atol=1e-5)
+
+
+def test_manual_backward_matches_autograd_float64():
+    """texgs.uvnet.uvnet_backward (the GEMM chain behind uvs_and_jacobian_with_grad) vs torch autograd of UVNet.forward."""
+    from texgs.uvnet import uvnet_backward
+    torch.manual_seed(2)
+    net = UVNet(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2]).double()
+    emb = (torch.randn(128) * 0.2).double().requires_grad_(True)
+    xyz = torch.randn(200, 3).double().requires_grad_(True)
+    g = torch.randn(200, 3).double()
+    (net(xyz, emb) * g).sum().backward()
+    lins = net._linears()
+    with torch.no_grad():
+        xn = net._norm_in(xyz)
+        dxn, demb, dW, db = uvnet_backward(xn, emb, [l.weight for l in lins], [l.bias for l in lins], g)
+    assert torch.allclose(dxn / net.xyz_scale, xyz.grad, atol=1e-10)
+    assert torch.allclose(demb, emb.grad, atol=1e-10)
+    for l, w, b in zip(lins, dW, db):
+        assert torch.allclose(w, l.weight.grad, atol=1e-9) and torch.allclose(b, l.bias.grad, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_fused_forward_with_gradients(lib_built):
+    """uvs_and_jacobian_with_grad: one fused launch forward, gradients to xyz (= J^T g), the embedding and all weights vs torch
+    autograd of the module's plain forward (float64 on the CPU)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    net = UVNet(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2])
+    emb0 = torch.randn(128) * 0.2
+    N = 20000
+    xyz0 = torch.randn(N, 3)
+    xyz0 = xyz0 / xyz0.norm(dim=1, keepdim=True)
+    g = torch.randn(N, 3)
+    net64 = UVNet(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2]).double()
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    e64, x64 = emb0.double().requires_grad_(True), xyz0.double().requires_grad_(True)
+    (net64(x64, e64) * g.double()).sum().backward()
+    netd = net.to(dev)
+    emb, xyz = emb0.to(dev).requires_grad_(True), xyz0.to(dev).requires_grad_(True)
+    uvs, juv = netd.uvs_and_jacobian_with_grad(xyz, emb)
+    assert not juv.requires_grad and uvs.requires_grad
+    (uvs * g.to(dev)).sum().backward()
+    errs = dict(xyz=Hh.rel_err(xyz.grad.cpu(), x64.grad), emb=Hh.rel_err(emb.grad.cpu(), e64.grad))
+    for k, (l, l64) in enumerate(zip(netd._linears(), net64._linears())):
+        errs[f"W{k + 1}"] = Hh.rel_err(l.weight.grad.cpu(), l64.weight.grad)
+        errs[f"b{k + 1}"] = Hh.rel_err(l.bias.grad.cpu(), l64.bias.grad)
+    Hh.report("uv_taylor/with_grad/20k", **errs)
+    assert max(errs.values()) < 2e-4, errs
+    # the packed-weight cache: a second call re-uses it, an in-place weight update invalidates it
+    key = netd._packed_key
+    netd.uv_and_jacobian(xyz, emb)
+    assert netd._packed_key == key
+    with torch.no_grad():
+        netd.mlp[0].weight.mul_(1.01)
+    u2, _ = netd.uv_and_jacobian(xyz, emb)
+    assert netd._packed_key != key and float((u2 - uvs.detach()).abs().max()) > 1e-6

@@ -305,11 +305,11 @@ int texgs_geom_losses(const float* norm, const float* gt_norm, const float* gt_i
     return e == hipSuccess ? 0 : fail("geom_losses", e);
 }
 
-int texgs_norm_from_depth(const float* depth, const float* cam_to_world, float tanfovx, float tanfovy, int32_t H, int32_t W,
+int texgs_norm_from_depth(const float* depth, const float* viewmatrix, float tanfovx, float tanfovy, int32_t H, int32_t W,
                           float threshold, float* out_norm, float* out_mask, void* stream) {
-    if (!depth || !cam_to_world || !out_norm || !out_mask) return fail_msg("NULL argument");
+    if (!depth || !viewmatrix || !out_norm || !out_mask) return fail_msg("NULL argument");
     if (H <= 0 || W <= 0) return fail_msg("image size must be positive");
-    launch_norm_from_depth(depth, cam_to_world, tanfovx, tanfovy, H, W, threshold, out_norm, out_mask, (hipStream_t)stream);
+    launch_norm_from_depth(depth, viewmatrix, tanfovx, tanfovy, H, W, threshold, out_norm, out_mask, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("norm_from_depth", e);
 }
@@ -322,6 +322,28 @@ int texgs_uv_taylor(const TexGSUVNet* net, const float* xyz, int32_t N, float* u
     if (!net->W1 || !net->W2 || !net->W3 || !net->W4 || !net->W5 || !net->emb) return fail_msg("weight pointer is NULL");
     if (N < 0) return fail_msg("N < 0");
     if (int r = launch_uv_taylor(net, xyz, N, uvs, grad_uvs, temp, (hipStream_t)stream)) return fail("uv_taylor", (hipError_t)r);
+    return 0;
+}
+
+static int check_uvnet(const TexGSUVNet* net) {
+    if (net->hidden != 128) return fail_msg("texgs_uv_taylor supports the shipped UVNet shape only (hidden width 128)");
+    if (!net->W1 || !net->W2 || !net->W3 || !net->W4 || !net->W5 || !net->emb) return fail_msg("weight pointer is NULL");
+    return 0;
+}
+
+int texgs_uv_pack(const TexGSUVNet* net, void* packed, void* stream) {
+    if (!net || !packed) return fail_msg("NULL argument");
+    if (int r = check_uvnet(net)) return r;
+    if (int r = launch_uv_pack(net, packed, (hipStream_t)stream)) return fail("uv_pack", (hipError_t)r);
+    return 0;
+}
+
+int texgs_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
+                           void* stream) {
+    if (!net || !packed || !xyz || !uvs || !grad_uvs) return fail_msg("NULL argument");
+    if (int r = check_uvnet(net)) return r;
+    if (N < 0) return fail_msg("N < 0");
+    if (int r = launch_uv_taylor_packed(net, packed, xyz, N, uvs, grad_uvs, (hipStream_t)stream)) return fail("uv_taylor", (hipError_t)r);
     return 0;
 }
 

@@ -80,7 +80,9 @@ void launch_selftest_waveops(const float* seed128, float* out576, hipStream_t s)
 int launch_geom_losses(const float* norm, const float* gt_norm, const float* gt_image, const float* mask, const float* depth,
                        const float* gt_depth, int H, int W, float lambda_norm, float lambda_smooth, float gamma,
                        float lambda_depth, float* sums, float* d_norm, float* d_depth, hipStream_t s);
-int launch_norm_from_depth(const float* depth, const float* c2w12, float tanfovx, float tanfovy, int H, int W, float threshold,
+int launch_norm_from_depth(const float* depth, const float* viewmatrix, float tanfovx, float tanfovy, int H, int W, float threshold,
                            float* out_norm, float* out_mask, hipStream_t s);
 size_t uv_taylor_temp_bytes();
+int launch_uv_pack(const TexGSUVNet* net, void* packed, hipStream_t s);
+int launch_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const float* xyz, int N, float* uvs, float* grad_uvs, hipStream_t s);
 int launch_uv_taylor(const TexGSUVNet* net, const float* xyz, int N, float* uvs, float* grad_uvs, void* temp, hipStream_t s);

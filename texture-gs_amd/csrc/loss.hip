@@ -241,10 +241,28 @@ k_geom_grad(GeomArgs a, float l_norm, float l_smooth, float l_depth, const float
 // ------------------------------------------------------------------------------------------------ pseudo-normal from depth
 // losses/norm_reg_loss.py:16-63 (norm_from_depth): back-project every pixel's depth to a world-space point, one-sided
 // differences to the four neighbours (replicate border), normal = normalise(cross(grad_y, grad_x)) with grad_x / grad_y the
-// means of the two one-sided differences, mask = all four differences shorter than `threshold`.  `c2w` is the inverse of the
-// column-convention view matrix (world_view_transform^T), rows 0..2 (12 floats).  One thread per pixel: 5 depth reads (L1 / L2
-// hits), 16 bytes written -- elementwise HBM work, no LDS.
+// means of the two one-sided differences, mask = all four differences shorter than `threshold`.  The camera-to-world matrix
+// (inverse of the column-convention view matrix world_view_transform^T, rows 0..2) is formed IN the kernel from the device-resident
+// view matrix (adjugate of its 3x3 part: wave-uniform scalar work) -- no host copy, no host-side inverse, no sync in the loss.
+// One thread per pixel: 5 depth reads (L1 / L2 hits), 16 bytes written -- elementwise HBM work, no LDS.
 struct DepthNormArgs { int H, W; float tx, ty, thr; float m[12]; };
+
+// vm = world_view_transform as the reference stores it (row-vector convention, [4,4] row-major): p_view = [p, 1] @ vm, i.e.
+// p_view = A p + t with A[r][c] = vm[c*4 + r], t[r] = vm[12 + r].  Returns rows 0..2 of [A^-1 | -A^-1 t].
+__device__ __forceinline__ void cam_to_world(const float* __restrict__ vm, float (&m)[12]) {
+    const float a00 = vm[0], a01 = vm[4], a02 = vm[8], a10 = vm[1], a11 = vm[5], a12 = vm[9], a20 = vm[2], a21 = vm[6], a22 = vm[10];
+    const float t0 = vm[12], t1 = vm[13], t2 = vm[14];
+    const float c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const float c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const float c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const float idet = 1.0f / (a00 * c00 + a01 * c10 + a02 * c20);
+    const float i[9] = {c00 * idet, c01 * idet, c02 * idet, c10 * idet, c11 * idet, c12 * idet, c20 * idet, c21 * idet, c22 * idet};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        m[4 * r] = i[3 * r]; m[4 * r + 1] = i[3 * r + 1]; m[4 * r + 2] = i[3 * r + 2];
+        m[4 * r + 3] = -(i[3 * r] * t0 + i[3 * r + 1] * t1 + i[3 * r + 2] * t2);
+    }
+}
 
 __device__ __forceinline__ void backproject(const DepthNormArgs& a, const float* __restrict__ depth, int x, int y, float (&p)[3]) {
     const float d = depth[y * a.W + x];
@@ -255,9 +273,11 @@ __device__ __forceinline__ void backproject(const DepthNormArgs& a, const float*
 }
 
 __global__ void __launch_bounds__(256)
-k_norm_from_depth(DepthNormArgs a, const float* __restrict__ depth, float* __restrict__ out_norm, float* __restrict__ out_mask) {
+k_norm_from_depth(DepthNormArgs a, const float* __restrict__ viewmatrix, const float* __restrict__ depth,
+                  float* __restrict__ out_norm, float* __restrict__ out_mask) {
     const int i = blockIdx.x * 256 + threadIdx.x, P = a.H * a.W;
     if (i >= P) return;
+    cam_to_world(viewmatrix, a.m);
     const int y = i / a.W, x = i - y * a.W;
     float c[3], l[3], r[3], u[3], dn[3];
     backproject(a, depth, x, y, c);
@@ -321,12 +341,12 @@ int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float
     return 0;
 }
 
-int launch_norm_from_depth(const float* depth, const float* c2w12, float tanfovx, float tanfovy, int H, int W, float threshold,
+int launch_norm_from_depth(const float* depth, const float* viewmatrix, float tanfovx, float tanfovy, int H, int W, float threshold,
                            float* out_norm, float* out_mask, hipStream_t s) {
     DepthNormArgs a;
     a.H = H; a.W = W; a.tx = tanfovx; a.ty = tanfovy; a.thr = threshold;
-    for (int k = 0; k < 12; ++k) a.m[k] = c2w12[k];
+    for (int k = 0; k < 12; ++k) a.m[k] = 0.f;
     const int P = H * W;
-    hipLaunchKernelGGL(k_norm_from_depth, dim3((P + 255) / 256), dim3(256), 0, s, a, depth, out_norm, out_mask);
+    hipLaunchKernelGGL(k_norm_from_depth, dim3((P + 255) / 256), dim3(256), 0, s, a, viewmatrix, depth, out_norm, out_mask);
     return 0;
 }

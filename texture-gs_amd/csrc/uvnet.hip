@@ -122,13 +122,25 @@ k_uv_taylor(UVArgs a, const float* __restrict__ xyz, int N, float* __restrict__ 
 
 size_t uv_taylor_temp_bytes() { return (size_t)3 * UV_H * UV_H * sizeof(float); }
 
-int launch_uv_taylor(const TexGSUVNet* net, const float* xyz, int N, float* uvs, float* grad_uvs, void* temp, hipStream_t s) {
+// W2, W3, W4 -> MFMA A-operand order.  The result depends on the weights only: callers that evaluate the same network again
+// (every view of a retexture / viewer session; every step between two optimizer updates) pack once and reuse `packed`.
+int launch_uv_pack(const TexGSUVNet* net, void* packed, hipStream_t s) {
+    hipLaunchKernelGGL(k_uv_pack, dim3(3 * 4 * 64 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4, reinterpret_cast<float*>(packed));
+    return (int)hipGetLastError();
+}
+
+int launch_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const float* xyz, int N, float* uvs, float* grad_uvs,
+                            hipStream_t s) {
     if (N <= 0) return 0;
-    float* packed = reinterpret_cast<float*>(temp);
-    hipLaunchKernelGGL(k_uv_pack, dim3(3 * 4 * 64 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4, packed);
     UVArgs a;
     a.W1 = net->W1; a.b1 = net->b1; a.b2 = net->b2; a.emb = net->emb; a.b3 = net->b3; a.b4 = net->b4; a.W5 = net->W5; a.b5 = net->b5;
-    a.off = net->xyz_offset; a.scale = net->xyz_scale; a.packed = packed;
+    a.off = net->xyz_offset; a.scale = net->xyz_scale; a.packed = reinterpret_cast<const float*>(packed);
     hipLaunchKernelGGL(k_uv_taylor, dim3((N + UV_P - 1) / UV_P), dim3(256), 0, s, a, xyz, N, uvs, grad_uvs);
     return (int)hipGetLastError();
+}
+
+int launch_uv_taylor(const TexGSUVNet* net, const float* xyz, int N, float* uvs, float* grad_uvs, void* temp, hipStream_t s) {
+    if (N <= 0) return 0;
+    if (int r = launch_uv_pack(net, temp, s)) return r;
+    return launch_uv_taylor_packed(net, temp, xyz, N, uvs, grad_uvs, s);
 }

@@ -125,13 +125,14 @@ def norm_from_depth(depth, world_view_transform, tanfovx, tanfovy, threshold=1e-
         raise ValueError(f"depth must be float32 [1,H,W], got {depth.dtype} {tuple(depth.shape)}")
     depth = depth.contiguous()
     _, H, W = depth.shape
-    # inverse of the column-convention view matrix, as the reference forms it (float32 torch.linalg.inv)
-    c2w = torch.linalg.inv(world_view_transform.detach().to(torch.float32).cpu().transpose(0, 1))[:3].contiguous()
-    m = (C.c_float * 12)(*[float(v) for v in c2w.reshape(-1)])
+    # the kernel inverts the (device-resident) view matrix itself: no .cpu(), no host-side inverse, no sync inside the loss
+    vm = world_view_transform.detach().to(device=depth.device, dtype=torch.float32).contiguous()
+    if vm.shape != (4, 4):
+        raise ValueError("world_view_transform must be [4,4]")
     norm = torch.empty(3, H, W, dtype=torch.float32, device=depth.device)
     mask = torch.empty(1, H, W, dtype=torch.float32, device=depth.device)
     with torch.cuda.device(depth.device):
-        _lib.check(lib.texgs_norm_from_depth(depth.data_ptr(), m, float(tanfovx), float(tanfovy), H, W, float(threshold),
+        _lib.check(lib.texgs_norm_from_depth(depth.data_ptr(), vm.data_ptr(), float(tanfovx), float(tanfovy), H, W, float(threshold),
                                              norm.data_ptr(), mask.data_ptr(),
                                              torch.cuda.current_stream(depth.device).cuda_stream), "texgs_norm_from_depth")
     return norm, mask

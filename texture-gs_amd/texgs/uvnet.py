@@ -1,11 +1,20 @@
 """UV-Taylor producer: the operator inputs `uvs` = phi(mu) and `gradient_uvs` = d phi / d x.
 
-`UVNet` is the reference's UV MLP (models/modules/uv_net.py:9-36) in its nn.Linear form (the fallback of
-models/modules/utils.py:43-61, `use_tcnn: False`): same module names (`pre_mlp`, `mlp` = nn.Sequential of Linear / ReLU),
-so a reference state_dict of that form loads directly; `forward` is plain torch (differentiable, for the training graph
-of `uvs`).  `uv_and_jacobian` runs the fused HIP kernel (csrc/uvnet.hip, fp32 MFMA): phi and its analytic 3x3 Jacobian
-by forward-mode propagation in one launch, instead of UVNet.forward plus the three backward passes of
-torch.autograd.functional.jacobian (models/texture_gaussian3d.py:216-236).
+`UVNet` is the reference's UV MLP (models/modules/uv_net.py:9-36): 3 -> 128 -> emb_dim(128); relu(. + emb); 128 -> 128 -> 128 -> 3;
+F.normalize.  It holds its weights as nn.Linear modules under the reference's module names (`pre_mlp`, `mlp` = nn.Sequential of
+Linear / ReLU, models/modules/utils.py:43-54), so a reference state_dict of the `use_tcnn: False` form loads directly, and
+`load_reference_state` also accepts the form every SHIPPED config produces (`use_tcnn: True`, configs/*.yaml): tiny-cuda-nn
+FullyFusedMLP networks, whose state_dict is ONE flat `params` tensor per network (see `unpack_tcnn_params`).
+
+Three ways to evaluate:
+  forward(xyz, emb)                       plain torch, differentiable (any device)
+  uv_and_jacobian(xyz, emb)               the fused HIP kernel (csrc/uvnet.hip, fp32 MFMA): phi and its analytic 3x3 Jacobian by
+                                          forward-mode propagation in one launch, instead of UVNet.forward plus the three backward
+                                          passes of torch.autograd.functional.jacobian (models/texture_gaussian3d.py:216-236)
+  uvs_and_jacobian_with_grad(xyz, emb)    the same launch inside an autograd node: `uvs` carries gradients to xyz (= J^T g, free:
+                                          J is there), to the embedding and to every weight (plain library GEMMs over the
+                                          recomputed activations), so the training graph of `uvs` stays on the device with one
+                                          fused forward instead of a second, torch-side evaluation of the network.
 """
 import ctypes as C
 
@@ -16,15 +25,66 @@ import torch.nn.functional as F
 from . import _lib
 
 HIDDEN = 128
+TCNN_ALIGN = 16          # tiny-cuda-nn pads input / output widths of FullyFusedMLP to multiples of 16
 
 
-def _mlp(n_hidden, in_dims, out_dims, width=HIDDEN):
+def _mlp(n_hidden, in_dims, out_dims, width=HIDDEN, bias=True):
     mods, ch = [], in_dims
     for _ in range(n_hidden):
-        mods += [nn.Linear(ch, width), nn.ReLU()]
+        mods += [nn.Linear(ch, width, bias=bias), nn.ReLU()]
         ch = width
-    mods.append(nn.Linear(ch, out_dims))
+    mods.append(nn.Linear(ch, out_dims, bias=bias))
     return nn.Sequential(*mods)
+
+
+def unpack_tcnn_params(params, n_in, n_out, n_hidden_layers, width=HIDDEN):
+    """The flat `params` tensor of a tiny-cuda-nn `Network(n_in, n_out, FullyFusedMLP, n_neurons=width, n_hidden_layers)` ->
+    [(weight [out, in], bias or None)] per layer, nn.Linear convention.
+
+    Layout restated from tiny-cuda-nn's published source (the package is an un-vendored, unpinned dependency of the reference,
+    requirements.txt; it cannot be imported here, so this is UNPINNED against the real thing): FullyFusedMLP stores its weight
+    matrices back to back, each ROW-major [fan_out, fan_in] -- first [width, pad16(n_in)], then n_hidden_layers - 1 matrices
+    [width, width], last [pad16(n_out), width] -- no biases.  `tcnn.Network` feeds the MLP through an identity encoding that
+    pads the input to 16 columns WITH ONES, so the weights of the padded input columns act as a learned first-layer bias
+    (returned as that layer's bias); padded output rows are dropped.  fp16 or fp32 storage is accepted, math is float32."""
+    p = params.detach().reshape(-1).to(torch.float32)
+    pin, pout = -(-n_in // TCNN_ALIGN) * TCNN_ALIGN, -(-n_out // TCNN_ALIGN) * TCNN_ALIGN
+    shapes = [(width, pin)] + [(width, width)] * (n_hidden_layers - 1) + [(pout, width)]
+    need = sum(a * b for a, b in shapes)
+    if p.numel() != need:
+        raise ValueError(f"tcnn params: expected {need} values for {n_in}->{n_out} with {n_hidden_layers} hidden layer(s) of {width}, "
+                         f"got {p.numel()}")
+    mats, off = [], 0
+    for a, b in shapes:
+        mats.append(p[off:off + a * b].reshape(a, b))
+        off += a * b
+    first = mats[0]
+    layers = [(first[:, :n_in].contiguous(), first[:, n_in:].sum(dim=1) if pin > n_in else None)]
+    layers += [(m.contiguous(), None) for m in mats[1:-1]]
+    layers.append((mats[-1][:n_out].contiguous(), None))
+    return layers
+
+
+def pack_tcnn_params(layers, n_in, n_out, width=HIDDEN):
+    """Inverse of unpack_tcnn_params (fixtures / tests): the first layer's bias goes to the first padded input column."""
+    pin, pout = -(-n_in // TCNN_ALIGN) * TCNN_ALIGN, -(-n_out // TCNN_ALIGN) * TCNN_ALIGN
+    out = []
+    for k, (w, b) in enumerate(layers):
+        w = w.detach().to(torch.float32)
+        if k == 0:
+            m = torch.zeros(width, pin)
+            m[:, :n_in] = w
+            if b is not None:
+                if pin == n_in:
+                    raise ValueError("no padded input column to carry the first-layer bias")
+                m[:, n_in] = b
+        elif k == len(layers) - 1:
+            m = torch.zeros(pout, width)
+            m[:n_out] = w
+        else:
+            m = w
+        out.append(m.reshape(-1))
+    return torch.cat(out)
 
 
 class UVNet(nn.Module):
@@ -34,40 +94,146 @@ class UVNet(nn.Module):
         super().__init__()
         self.pre_mlp = _mlp(1, 3, HIDDEN)
         self.mlp = _mlp(2, HIDDEN, 3)
-        self.xyz_offset = None if xyz_offset is None else torch.as_tensor(xyz_offset, dtype=torch.float32)
-        self.xyz_scale = None if xyz_scale is None else torch.as_tensor(xyz_scale, dtype=torch.float32)
+        # device-resident (buffers follow .to() / .cuda()): the reference moves them to the device on every call (uv_net.py:23-24)
+        self.register_buffer("xyz_offset", None if xyz_offset is None else torch.as_tensor(xyz_offset, dtype=torch.float32), persistent=False)
+        self.register_buffer("xyz_scale", None if xyz_scale is None else torch.as_tensor(xyz_scale, dtype=torch.float32), persistent=False)
+        self._packed = None          # W2..W4 in MFMA operand order + the parameter versions it was made from
+        self._packed_key = None
+
+    # ---- weights --------------------------------------------------------------------------------------------------------
+    def _linears(self):
+        return [self.pre_mlp[0], self.pre_mlp[2], self.mlp[0], self.mlp[2], self.mlp[4]]
+
+    def load_reference_state(self, state):
+        """A reference `uv_net.state_dict()` in either form: nn.Linear keys (`pre_mlp.0.weight`, ...) or tiny-cuda-nn keys
+        (`pre_mlp.params`, `mlp.params`: flat, bias-free, 16-padded -- every shipped config)."""
+        if "pre_mlp.params" in state and "mlp.params" in state:
+            pre = unpack_tcnn_params(state["pre_mlp.params"], 3, HIDDEN, 1)
+            mlp = unpack_tcnn_params(state["mlp.params"], HIDDEN, 3, 2)
+            with torch.no_grad():
+                for lin, (w, b) in zip(self._linears(), pre + mlp):
+                    lin.weight.copy_(w)
+                    lin.bias.zero_() if b is None else lin.bias.copy_(b)
+            return self
+        self.load_state_dict(state)
+        return self
+
+    def _norm_in(self, xyz):
+        # both or neither, as uv_net.py:22-25
+        if self.xyz_offset is not None and self.xyz_scale is not None:
+            return (xyz - self.xyz_offset.to(xyz)) / self.xyz_scale.to(xyz)
+        return xyz
 
     def forward(self, xyz, emb):
-        if self.xyz_offset is not None and self.xyz_scale is not None:
-            xyz = (xyz - self.xyz_offset.to(xyz)) / self.xyz_scale.to(xyz)
-        x = F.relu(self.pre_mlp(xyz) + emb[None, :])
+        x = F.relu(self.pre_mlp(self._norm_in(xyz)) + emb[None, :])
         return F.normalize(self.mlp(x), dim=-1)
+
+    # ---- fused kernel ---------------------------------------------------------------------------------------------------
+    def _kernel_args(self, dev, emb):
+        f = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        both = self.xyz_offset is not None and self.xyz_scale is not None
+        lins = self._linears()
+        ws = [f(lins[0].weight), f(lins[0].bias), f(lins[1].weight), f(lins[1].bias), f(emb),
+              f(lins[2].weight), f(lins[2].bias), f(lins[3].weight), f(lins[3].bias), f(lins[4].weight), f(lins[4].bias),
+              f(self.xyz_offset) if both else None, f(self.xyz_scale) if both else None]
+        if ws[0].shape != (HIDDEN, 3) or ws[2].shape != (HIDDEN, HIDDEN) or ws[9].shape != (3, HIDDEN) or ws[4].numel() != HIDDEN:
+            raise ValueError("the fused kernel supports the shipped UVNet shape only (3-128-128 | 128-128-128-3, emb 128)")
+        return ws
 
     @torch.no_grad()
     def uv_and_jacobian(self, xyz, emb):
         """(uvs f32[N,3], gradient_uvs f32[N,9] with [3*i+j] = d uv_i / d x_j) from the fused HIP kernel.  No autograd graph
-        (the reference detaches the Jacobian too, models/texture_gaussian3d.py:227; use forward() for a differentiable uvs)."""
+        (the reference detaches the Jacobian too, models/texture_gaussian3d.py:227; see uvs_and_jacobian_with_grad).  The
+        MFMA-ordered copy of W2..W4 is cached on the module and re-made only when one of those weights changed."""
         lib = _lib.load()
         dev = xyz.device
         if dev.type != "cuda":
             raise RuntimeError("UVNet.uv_and_jacobian runs on an AMD GPU; there is no CPU fallback (use forward + autograd)")
-        f = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        x = f(xyz)
+        x = xyz.detach().to(dtype=torch.float32).contiguous()
         N = x.shape[0]
-        ws = [f(self.pre_mlp[0].weight), f(self.pre_mlp[0].bias), f(self.pre_mlp[2].weight), f(self.pre_mlp[2].bias), f(emb),
-              f(self.mlp[0].weight), f(self.mlp[0].bias), f(self.mlp[2].weight), f(self.mlp[2].bias),
-              f(self.mlp[4].weight), f(self.mlp[4].bias), f(self.xyz_offset), f(self.xyz_scale)]
-        if ws[0].shape != (HIDDEN, 3) or ws[2].shape != (HIDDEN, HIDDEN) or ws[9].shape != (3, HIDDEN) or ws[4].numel() != HIDDEN:
-            raise ValueError("the fused kernel supports the shipped UVNet shape only (3-128-128 | 128-128-128-3, emb 128)")
+        ws = self._kernel_args(dev, emb)
         p = lambda t: None if t is None else t.data_ptr()
         net = _lib.UVNetStruct(*[p(t) for t in ws], HIDDEN)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = tuple((t.data_ptr(), t._version) for t in (self.pre_mlp[2].weight, self.mlp[0].weight, self.mlp[2].weight)) + (dev,)
         uvs = torch.empty(N, 3, dtype=torch.float32, device=dev)
         juv = torch.empty(N, 9, dtype=torch.float32, device=dev)
-        temp = torch.empty(lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.texgs_uv_taylor(C.byref(net), p(x), N, p(uvs), p(juv), p(temp), torch.cuda.current_stream(dev).cuda_stream),
-                       "texgs_uv_taylor")
+            if self._packed is None or self._packed_key != key:
+                self._packed = torch.empty(lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)
+                _lib.check(lib.texgs_uv_pack(C.byref(net), p(self._packed), stream), "texgs_uv_pack")
+                self._packed_key = key
+            _lib.check(lib.texgs_uv_taylor_packed(C.byref(net), p(self._packed), p(x), N, p(uvs), p(juv), stream),
+                       "texgs_uv_taylor_packed")
         return uvs, juv
+
+    def uvs_and_jacobian_with_grad(self, xyz, emb):
+        """(uvs, gradient_uvs) from ONE fused launch, with `uvs` differentiable w.r.t. xyz, emb and the network's weights
+        (`gradient_uvs` carries no gradient, as in the reference)."""
+        lins = self._linears()
+        params = [t for lin in lins for t in (lin.weight, lin.bias)]
+        uvs, juv = _FusedUV.apply(self, xyz, emb, *params)
+        return uvs, juv
+
+
+def uvnet_backward(xn, emb, weights, biases, g, inv_scale=None):
+    """Gradients of uvs = normalize(MLP(xn)) w.r.t. (xn, emb, weights, biases) for an upstream gradient g [N,3], by hand: the
+    activations are recomputed with five GEMMs, the chain rule is six more.  Pure torch (runs anywhere; tests run it in
+    float64 on the CPU against autograd).  xn = the (already offset / scaled) input; returns (d_xn, d_emb, [dW], [db])."""
+    W1, W2, W3, W4, W5 = weights
+    b1, b2, b3, b4, b5 = [None if b is None else b for b in biases]
+    add = lambda z, b: z if b is None else z + b
+    z1 = add(xn @ W1.t(), b1); h1 = z1.clamp_min(0)
+    z2 = add(h1 @ W2.t(), b2) + emb; a = z2.clamp_min(0)
+    z3 = add(a @ W3.t(), b3); h2 = z3.clamp_min(0)
+    z4 = add(h2 @ W4.t(), b4); h3 = z4.clamp_min(0)
+    o = add(h3 @ W5.t(), b5)
+    n = o.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    u = o / n
+    do = (g - u * (u * g).sum(dim=1, keepdim=True)) / n                 # F.normalize backward
+    dW5 = do.t() @ h3; db5 = do.sum(0)
+    d4 = (do @ W5) * (z4 > 0)
+    dW4 = d4.t() @ h2; db4 = d4.sum(0)
+    d3 = (d4 @ W4) * (z3 > 0)
+    dW3 = d3.t() @ a; db3 = d3.sum(0)
+    d2 = (d3 @ W3) * (z2 > 0)
+    dW2 = d2.t() @ h1; db2 = d2.sum(0); demb = db2
+    d1 = (d2 @ W2) * (z1 > 0)
+    dW1 = d1.t() @ xn; db1 = d1.sum(0)
+    dxn = d1 @ W1
+    return dxn, demb, [dW1, dW2, dW3, dW4, dW5], [db1, db2, db3, db4, db5]
+
+
+class _FusedUV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, xyz, emb, *params):
+        uvs, juv = net.uv_and_jacobian(xyz, emb)
+        ctx.net = net
+        ctx.save_for_backward(xyz, emb, juv, *params)
+        ctx.mark_non_differentiable(juv)
+        return uvs, juv
+
+    @staticmethod
+    def backward(ctx, g, _gj):
+        xyz, emb, juv, *params = ctx.saved_tensors
+        net = ctx.net
+        need = ctx.needs_input_grad           # (net, xyz, emb, W1, b1, ..., W5, b5)
+        g = g.to(torch.float32).contiguous()
+        d_xyz = None
+        if need[1]:                           # d uv_i / d x_j = J[3 i + j]: d_xyz_j = sum_i g_i J_ij  -- J is already there
+            d_xyz = torch.einsum("ni,nij->nj", g, juv.reshape(-1, 3, 3))
+        d_emb, d_params = None, [None] * 10
+        if any(need[2:]):
+            with torch.no_grad():
+                xn = net._norm_in(xyz.detach().to(torch.float32))
+                ws, bs = list(params[0::2]), list(params[1::2])
+                _, d_emb, dW, db = uvnet_backward(xn, emb.detach().to(torch.float32), [w.detach() for w in ws], [b.detach() for b in bs], g)
+            for k in range(5):
+                d_params[2 * k] = dW[k] if need[3 + 2 * k] else None
+                d_params[2 * k + 1] = db[k] if need[4 + 2 * k] else None
+            if not need[2]:
+                d_emb = None
+        return (None, d_xyz, d_emb, *d_params)
 
 
 def jacobian_by_autograd(net: UVNet, xyz, emb):
