@@ -27,55 +27,64 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
     return t;
 }
 
+// (Same-address global atomics execute memory-side, ~13 ns each and serialised: one pair per 16x16 tile -- 15 000 of them at
+// 800x800 -- made this kernel 201 us, 3 % of its HBM bound.  Blocks therefore loop over tiles and add their sums ONCE.)
 __global__ void __launch_bounds__(256)
-k_ssim_fwd(int H, int W, Win win, const float* __restrict__ img, const float* __restrict__ gt,
+k_ssim_fwd(int H, int W, int tiles_x, int tiles_y, Win win, const float* __restrict__ img, const float* __restrict__ gt,
            float* __restrict__ part /* [3 maps][3 ch][H][W] */, float* __restrict__ sums) {
     __shared__ float s_x[LW][LW + 1], s_y[LW][LW + 1];
     __shared__ float s_h[5][LW][LT + 1];
     __shared__ float s_red[4];
-    const int c = blockIdx.z, tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT;
-    const float* __restrict__ X = img + (size_t)c * H * W;
-    const float* __restrict__ Y = gt + (size_t)c * H * W;
-    for (int k = threadIdx.x; k < LW * LW; k += 256) {
-        const int r = k / LW, q = k % LW, yy = ty0 + r - LH, xx = tx0 + q - LH;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        s_x[r][q] = in ? X[(size_t)yy * W + xx] : 0.f;
-        s_y[r][q] = in ? Y[(size_t)yy * W + xx] : 0.f;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < LW * LT; k += 256) {        // horizontal pass
-        const int r = k / LT, q = k % LT;
-        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+    float acc_ssim = 0.f, acc_l1 = 0.f;
+    const int nwork = tiles_x * tiles_y * 3;
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int c = work / (tiles_x * tiles_y), tt = work - c * (tiles_x * tiles_y);
+        const int tx0 = (tt % tiles_x) * LT, ty0 = (tt / tiles_x) * LT;
+        const float* __restrict__ X = img + (size_t)c * H * W;
+        const float* __restrict__ Y = gt + (size_t)c * H * W;
+        __syncthreads();                                        // the previous tile's LDS reads are done
+        for (int k = threadIdx.x; k < LW * LW; k += 256) {
+            const int r = k / LW, q = k % LW, yy = ty0 + r - LH, xx = tx0 + q - LH;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            s_x[r][q] = in ? X[(size_t)yy * W + xx] : 0.f;
+            s_y[r][q] = in ? Y[(size_t)yy * W + xx] : 0.f;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < LW * LT; k += 256) {        // horizontal pass
+            const int r = k / LT, q = k % LT;
+            float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                const float x = s_x[r][q + t], y = s_y[r][q + t], w = win.w[t];
+                a += w * x; b += w * y; aa += w * x * x; bb += w * y * y; ab += w * x * y;
+            }
+            s_h[0][r][q] = a; s_h[1][r][q] = b; s_h[2][r][q] = aa; s_h[3][r][q] = bb; s_h[4][r][q] = ab;
+        }
+        __syncthreads();
+        const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, px = tx0 + lx, py = ty0 + ly;
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
-            const float x = s_x[r][q + t], y = s_y[r][q + t], w = win.w[t];
-            a += w * x; b += w * y; aa += w * x * x; bb += w * y * y; ab += w * x * y;
+            const float w = win.w[t];
+            mu1 += w * s_h[0][ly + t][lx]; mu2 += w * s_h[1][ly + t][lx]; e11 += w * s_h[2][ly + t][lx];
+            e22 += w * s_h[3][ly + t][lx]; e12 += w * s_h[4][ly + t][lx];
         }
-        s_h[0][r][q] = a; s_h[1][r][q] = b; s_h[2][r][q] = aa; s_h[3][r][q] = bb; s_h[4][r][q] = ab;
+        if (px < W && py < H) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+            const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+            const float inv = 1.f / (B1 * B2);
+            const float ssim = A1 * A2 * inv;
+            const size_t o = ((size_t)c * H + py) * W + px, plane = (size_t)3 * H * W;
+            part[o]             = 2.f * mu2 * (A2 - A1) * inv - ssim * 2.f * mu1 * (B2 - B1) * inv;   // dS/dmu1
+            part[plane + o]     = -ssim / B2;                                                        // dS/dE[x^2]
+            part[2 * plane + o] = 2.f * A1 * inv;                                                    // dS/dE[xy]
+            acc_ssim += ssim;
+            acc_l1 += fabsf(s_x[ly + LH][lx + LH] - s_y[ly + LH][lx + LH]);
+        }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, px = tx0 + lx, py = ty0 + ly;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 11; ++t) {
-        const float w = win.w[t];
-        mu1 += w * s_h[0][ly + t][lx]; mu2 += w * s_h[1][ly + t][lx]; e11 += w * s_h[2][ly + t][lx];
-        e22 += w * s_h[3][ly + t][lx]; e12 += w * s_h[4][ly + t][lx];
-    }
-    float ssim = 0.f, l1 = 0.f;
-    if (px < W && py < H) {
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
-        const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
-        const float inv = 1.f / (B1 * B2);
-        ssim = A1 * A2 * inv;
-        const size_t o = ((size_t)c * H + py) * W + px, plane = (size_t)3 * H * W;
-        part[o]             = 2.f * mu2 * (A2 - A1) * inv - ssim * 2.f * mu1 * (B2 - B1) * inv;   // dS/dmu1
-        part[plane + o]     = -ssim / B2;                                                        // dS/dE[x^2]
-        part[2 * plane + o] = 2.f * A1 * inv;                                                    // dS/dE[xy]
-        l1 = fabsf(s_x[ly + LH][lx + LH] - s_y[ly + LH][lx + LH]);
-    }
-    const float ts = block_sum(ssim, s_red), tl = block_sum(l1, s_red);
+    const float ts = block_sum(acc_ssim, s_red), tl = block_sum(acc_l1, s_red);
     if (threadIdx.x == 0) { atomicAdd(sums + 0, tl); atomicAdd(sums + 1, ts); }
 }
 
@@ -117,15 +126,14 @@ __global__ void __launch_bounds__(256)
 k_alpha_l1(int P, const float* __restrict__ a, const float* __restrict__ gt, float g, float* __restrict__ d_a,
            float* __restrict__ sums) {
     __shared__ float s_red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     float l = 0.f;
-    if (i < P) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
         const float d = a[i] - gt[i];
-        l = fabsf(d);
+        l += fabsf(d);
         d_a[i] = g * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
     }
     const float t = block_sum(l, s_red);
-    if (threadIdx.x == 0) atomicAdd(sums + 2, t);
+    if (threadIdx.x == 0) atomicAdd(sums + 2, t);          // one atomic per block (grid-stride: a few hundred blocks)
 }
 
 // ---- geometric regularisers of TextureGaussian3D.compute_loss (models/texture_gaussian3d.py:347-368) on the operator's
@@ -162,21 +170,22 @@ __device__ __forceinline__ bool pair_ends(int k, int y, int x, int H, int W, int
     return ya >= 0 && yb >= 0 && xa >= 0 && xb >= 0 && ya < H && yb < H && xa < W && xb < W;
 }
 
+// (Eleven same-address atomics per 256 pixels -- 27 500 at 800x800, serialised memory-side -- made this kernel 359 us; blocks
+// now stride over the image, keep the eleven sums in registers and add them once.)
 __global__ void __launch_bounds__(256)
 k_geom_sums(GeomArgs a, int do_norm, int do_smooth, int do_depth, float* __restrict__ sums) {
     __shared__ float s_red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x, P = a.H * a.W;
-    const bool in = i < P;
-    const int y = in ? i / a.W : 0, x = in ? i % a.W : 0;
+    const int P = a.H * a.W;
     float v[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) v[k] = 0.f;
-    if (in) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
+        const int y = i / a.W, x = i % a.W;
         const float n0 = a.norm ? a.norm[i] : 0.f, n1 = a.norm ? a.norm[P + i] : 0.f, n2 = a.norm ? a.norm[2 * P + i] : 0.f;
         if (do_norm) {
             const float m = a.mask ? a.mask[i] : 1.f;
-            v[0] = m;
-            v[1] = (1.f - (n0 * a.gt_norm[i] + n1 * a.gt_norm[P + i] + n2 * a.gt_norm[2 * P + i])) * m;
+            v[0] += m;
+            v[1] += (1.f - (n0 * a.gt_norm[i] + n1 * a.gt_norm[P + i] + n2 * a.gt_norm[2 * P + i])) * m;
         }
         if (do_smooth) {
 #pragma unroll
@@ -185,12 +194,12 @@ k_geom_sums(GeomArgs a, int do_norm, int do_smooth, int do_depth, float* __restr
                 if (!pair_ends(k, y, x, a.H, a.W, ya, xa, yb, xb)) continue;
                 const float w = pair_weight(a, ya, xa, yb, xb);
                 const size_t ia = (size_t)ya * a.W + xa, ib = (size_t)yb * a.W + xb;
-                v[2 + k] = w;
-                v[6 + k] = fabsf(w * (a.norm[ia] - a.norm[ib])) + fabsf(w * (a.norm[P + ia] - a.norm[P + ib]))
-                         + fabsf(w * (a.norm[2 * P + ia] - a.norm[2 * P + ib]));
+                v[2 + k] += w;
+                v[6 + k] += fabsf(w * (a.norm[ia] - a.norm[ib])) + fabsf(w * (a.norm[P + ia] - a.norm[P + ib]))
+                          + fabsf(w * (a.norm[2 * P + ia] - a.norm[2 * P + ib]));
             }
         }
-        if (do_depth) v[10] = fabsf(a.depth[i] - a.gt_depth[i]);
+        if (do_depth) v[10] += fabsf(a.depth[i] - a.gt_depth[i]);
     }
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
@@ -312,7 +321,8 @@ int launch_geom_losses(const float* norm, const float* gt_norm, const float* gt_
     a.gt_depth = gt_depth; a.inv_gamma = 1.f / gamma;
     (void)hipMemsetAsync(sums, 0, 12 * sizeof(float), s);
     const int P = H * W, blocks = (P + 255) / 256;
-    hipLaunchKernelGGL(k_geom_sums, dim3(blocks), dim3(256), 0, s, a, lambda_norm != 0.f, lambda_smooth != 0.f,
+    // 512 persistent blocks (2 per CU) stride over the image: 11 atomics per BLOCK, not per 256 pixels
+    hipLaunchKernelGGL(k_geom_sums, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, s, a, lambda_norm != 0.f, lambda_smooth != 0.f,
                        lambda_depth != 0.f, sums);
     hipLaunchKernelGGL(k_geom_grad, dim3(blocks), dim3(256), 0, s, a, lambda_norm, lambda_smooth, lambda_depth,
                        (const float*)sums, d_norm, d_depth);
@@ -330,12 +340,15 @@ int launch_rgb_alpha_loss(const float* image, const float* gt_image, const float
     (void)hipMemsetAsync(sums, 0, 4 * sizeof(float), s);
     const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, 3);
     const float n = (float)(3 * (size_t)H * W);
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, s, H, W, win, image, gt_image, scratch, sums);
+    const int nwork = (int)(grid.x * grid.y * 3);
+    hipLaunchKernelGGL(k_ssim_fwd, dim3(nwork < 1024 ? nwork : 1024), dim3(256), 0, s, H, W, (int)grid.x, (int)grid.y, win, image,
+                       gt_image, scratch, sums);
     hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, s, H, W, win, image, gt_image, (const float*)scratch,
                        -lambda_dssim / n, (1.f - lambda_dssim) / n, d_image);
     if (alpha && gt_alpha && d_alpha) {
         const int P = H * W;
-        hipLaunchKernelGGL(k_alpha_l1, dim3((P + 255) / 256), dim3(256), 0, s, P, alpha, gt_alpha, lambda_alpha / (float)P,
+        const int ab = (P + 255) / 256;
+        hipLaunchKernelGGL(k_alpha_l1, dim3(ab < 512 ? ab : 512), dim3(256), 0, s, P, alpha, gt_alpha, lambda_alpha / (float)P,
                            d_alpha, sums);
     }
     return 0;

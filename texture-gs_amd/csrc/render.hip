@@ -294,23 +294,27 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             p10 = load_texel(tex, ct.o10); p11 = load_texel(tex, ct.o11);
         }
         if (bin_count != nullptr) {
-            // a backward will follow: count this round's footprints per texture bin (sizes of K7's record lists).  Lanes are
-            // grouped by bin with ballots; the group's size goes to a small per-wave LDS cache (8 entries, hashed by bin) that is
-            // flushed with one atomic per entry on a conflict and at the end: global atomics execute memory-side (~700 k of
-            // them per view cost 80 us), a block's footprints fall into a handful of bins.
+            // a backward will follow: count this round's footprints per texture bin (sizes of K7's record lists) in a small
+            // per-wave LDS cache (8 entries, hashed by bin; a block's footprints fall into a handful of bins), flushed with one
+            // global atomic per entry on a conflict and at the end: global atomics execute memory-side (one per (round, bin) =
+            // 700 k per view cost 80 us).  Hit: ONE integer LDS atomic per lane, no grouping.  Miss (first touch of a bin, or
+            // a hash conflict): the lanes are grouped by bin with ballots and the group leader replaces the entry.
             const bool binned = (lane < n_) && tap_binned(ct);
             const uint32_t bin = tap_bin(ct, nbins_row);
-            ull pend = TG_BALLOT(binned);
+            const uint32_t ce = (bin ^ (bin >> 5)) & 7u;
+            const bool hit = binned && L.cbin[ce] == bin;
+            if (hit) atomicAdd(&L.ccnt[ce], 1u);
+            ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
             while (pend != 0ull) {
                 const int l0 = __ffsll((long long)pend) - 1;
                 const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
-                const ull m = TG_BALLOT(binned && bin == b0);
+                const ull m = pend & TG_BALLOT(bin == b0);
                 if (lane == l0) {
-                    const uint32_t n = (uint32_t)__popcll(m), e = (b0 ^ (b0 >> 5)) & 7u, ob = L.cbin[e];
-                    if (ob == b0) L.ccnt[e] += n;
+                    const uint32_t n = (uint32_t)__popcll(m), ob = L.cbin[ce];
+                    if (ob == b0) L.ccnt[ce] += n;            // (installed by an earlier group of this round? cannot be: one group per bin)
                     else {
-                        if (ob != 0xFFFFFFFFu) atomicAdd(bin_count + ob, L.ccnt[e]);
-                        L.cbin[e] = b0; L.ccnt[e] = n;
+                        if (ob != 0xFFFFFFFFu) atomicAdd(bin_count + ob, L.ccnt[ce]);
+                        L.cbin[ce] = b0; L.ccnt[ce] = n;
                     }
                 }
                 pend &= ~m;
