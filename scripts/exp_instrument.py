@@ -49,6 +49,25 @@ rep('''            nq += __popcll(m);
         // ---- chunk: up to 64 survivors, lane = survivor
         const int take = min(64, nq);
         CNT(4, 1);''')
+rep('        if (a.surv != nullptr) {                // a backward will follow: it replays exactly these survivors, back to front',
+    '''#ifdef TG_STATS
+        {   // what 16 per-2x2-quad lists would give: first-order upper bound of the concave falloff at the quad centre
+            int mx = 0, sm = 0, mx_exact = 0;
+            for (int qd = 0; qd < 16; ++qd) {
+                const float cx = wpx + 2.f * (float)(qd & 3) + 0.5f, cy = wpy + 2.f * (float)(qd >> 2) + 0.5f;
+                const float dx = T0.x - cx, dy = T0.y - cy;
+                const float p = T0.z * dx * dx + T0.w * dx * dy + T1.x * dy * dy;
+                const float g1 = 2.f * T0.z * dx + T0.w * dy, g2 = T0.w * dx + 2.f * T1.x * dy;
+                const bool ok = (lane < take) && T1.z >= 0.f && (p + 0.5f * (fabsf(g1) + fabsf(g2)) >= T1.w - 1e-3f * fabsf(T1.w) - 1e-4f);
+                const int n = __popcll(TG_BALLOT(ok));
+                mx = max(mx, n); sm += n;
+                const bool ex = (lane < take) && block_reachable(T0.x, T0.y, T0.z, T0.w, T1.x, T1.w, T1.z, cx - 0.5f, cy - 0.5f, 1.0f);
+                mx_exact = max(mx_exact, __popcll(TG_BALLOT(ex)));
+            }
+            CNT(11, mx); CNT(12, sm); CNT(13, mx_exact);
+        }
+#endif
+        if (a.surv != nullptr) {                // a backward will follow: it replays exactly these survivors, back to front''')
 rep('        int tmax = max(max(len[0], len[1]), max(len[2], len[3]));',
     '        int tmax = max(max(len[0], len[1]), max(len[2], len[3]));\n        CNT(5, len[0] + len[1] + len[2] + len[3]); CNT(6, tmax);\n        if (FABL & 2) tmax = 0;')
 rep('            if (m_ok == 0ull) continue;', '            CNT(7, 1);\n            if (m_ok == 0ull) continue;\n            CNT(8, 1);')
@@ -97,6 +116,24 @@ rep('            for (int k = 0; k < n_it; ++k) {\n                const uint32_
     '            if (!(ABL & 1)) for (int k = 0; k < n_it; ++k) {\n                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)it_lo, k);')
 rep('                        if (lo != 0.f) unsafeAtomicAdd(row, lo);\n                        if (hi != 0.f) unsafeAtomicAdd(row + 16, hi);',
     '                        if (ABL & 64) { if (lo == 12345.f && hi == 54321.f) row[0] = lo; } else {\n                        if (lo != 0.f) unsafeAtomicAdd(row, lo);\n                        if (hi != 0.f) unsafeAtomicAdd(row + 16, hi); }')
+rep('                const bool havet = (itk < n_it) && (c > 0);\n',
+    '''                const bool havet = (itk < n_it) && (c > 0);
+#ifdef TG_STATS
+                {   // what per-Gaussian task merging inside a segment would give
+                    const int jmine = KEY_J(__float_as_uint(L.items[(havet ? (int)(f0 + (uint32_t)below) : BQ_CAP) * 3].w));
+                    int distinct = 0, merged = 0;
+                    for (int jj = 0; jj < 64; ++jj) {
+                        const ull mm = TG_BALLOT(havet && jmine == jj);
+                        if (mm == 0ull) continue;
+                        int n = 0;
+                        ull m2 = mm;
+                        while (m2) { const int l = __ffsll((long long)m2) - 1; m2 &= m2 - 1; n += __builtin_amdgcn_readlane(c, l); }
+                        ++distinct; merged += (n + 15) >> 4;
+                    }
+                    CNT(14, distinct); CNT(15, merged);
+                }
+#endif
+''')
 rep('                ntask = __popcll(tm);\n', '                ntask = __popcll(tm);\n                CNT(12, ntask); CNT(13, (ntask + 3) >> 2);\n                if (ABL & 2) ntask = 0;\n')
 rep('''            __builtin_amdgcn_wave_barrier();
         }
