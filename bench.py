@@ -267,7 +267,7 @@ def main():
     dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"]) if kinfo else None        # every group launches once per view
     roofline = None
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")      # PMC pass of the same command (scripts/prof.sh)
+    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")      # PMC pass of the same command (scripts/prof.sh)
     if dom and args.workload == "c3" and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(dom, {}).get("traffic_bytes")
@@ -277,7 +277,7 @@ def main():
         ach = kinfo[dom]["GBps"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload with --streams 1, scripts/prof.sh; FETCH x2)" if traffic else None,
+                    "traffic_source": "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload with --streams 1, scripts/prof.sh; FETCH x2)" if traffic else None,
                     "alg_bytes_per_launch": ab[dom], "avg_launch_us": round(kinfo[dom]["avg_us"], 2)}
         if dom == DOMINANT and kern_solo_dom[1]:
             solo_us = 1e3 * kern_solo_dom[0] / kern_solo_dom[1]

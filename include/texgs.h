@@ -152,7 +152,7 @@ typedef struct TexGSGrads {
     uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: list fill counters, ALL-ZERO on entry and all-zero again on
                                   return (the reduce clears what it read).  Word [count] receives max(records a call needed)
                                   (never cleared by the library: the caller sizes tex_rec_cap from it); [count+1] = bits of
-                                  max |dL/dpixel colour| of the call in flight (zero on entry; K8 clears it).             */
+                                  max |dL/dpixel colour| of the call in flight (reset at the start of every backward).             */
     uint32_t* tex_bin_base;    /* u32[texgs_tex_bin_count(R) + 1]: scratch, list offsets of this call (no initialisation)    */
     uint32_t  tex_rec_cap;     /* records tex_bins holds.  Too small is not an error: footprints that do not fit fall back
                                   to atomics.                                                                            */

@@ -326,10 +326,9 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  float* __restrict__ acc,
                  float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
-                 float* __restrict__ d_uvs, float* __restrict__ d_coff, int accumulate, uint32_t* __restrict__ clear_word) {
+                 float* __restrict__ d_uvs, float* __restrict__ d_coff, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K]: SH rows in, dL/dSH rows out
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
-    if (i == 0 && clear_word) *clear_word = 0u;     // per-call scratch word of the texture-gradient reduce (runs before K8)
     const int K = C.sh_coeffs;
     const bool live = i < C.N;
     const int row = 3 * K;
@@ -579,8 +578,7 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
-                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate,
-                       (gr->tex_bins && gr->tex_bin_cursor) ? gr->tex_bin_cursor + tex_bin_count(c.R) + 1 : nullptr);
+                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate);
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

@@ -547,7 +547,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     init_dummy(L.p, lane);
     if (tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale of THIS
-        // call (K8 clears the word after the reduce).  Positive floats order like their bit patterns; the plain read first
+        // call (k_bin_offsets, launched just before this kernel, cleared the word).  Positive floats order like their bit patterns; the plain read first
         // keeps 10^4 waves off one hot word.
         const int mbits = wave_max_i(__float_as_int(fmaxf(fabsf(dpix[0]), fmaxf(fabsf(dpix[1]), fabsf(dpix[2])))));
         if (lane == 0 && (uint32_t)mbits > __hip_atomic_load(tb.stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -886,6 +886,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
     if (tid == 0) {
         base[nbins] = s_carry;
         if (s_carry > stats[0]) stats[0] = s_carry;      // what the lists of this view need: the host sizes the buffer from it
+        stats[1] = 0u;                                   // max |dL/dpixel colour| of THIS call: K7 raises it, the reduce reads it
     }
 }
 
@@ -895,7 +896,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
 // bins overlap in that one-texel seam, hence atomics.  Leaves the cursor at 0 for the next call.
 // The tile is 64-bit FIXED POINT: LDS float atomics retire ~3 cycles per lane on gfx950 (ds_add_f32: 193 cycles per wave
 // instruction, ds_add_u64: 6; scripts/ubench/lds_atomics.hip), which made the first version of this kernel 1.8 ms.  Scale:
-// every record value is bounded by C0 * max|dL/dpixel colour| OF THIS CALL (K7 leaves that maximum in stats[1], K8 clears it)
+// every record value is bounded by C0 * max|dL/dpixel colour| OF THIS CALL (k_bin_offsets clears stats[1], K7 raises it)
 // and is mapped to < 2^42, so 2^20 records per bin cannot overflow (lists are cut there; the rest went through atomics);
 // resolution 2^-42 of the image-wide bound, sums exact and order-independent.
 #define TB_EDGE 33
