@@ -228,6 +228,44 @@ __device__ __forceinline__ int sh_active(int deg, int K) {
     return want < K ? want : K;
 }
 
+// The staged dL/dSH rows of a workgroup, LDS -> global (store, or add into a gradient buffer).  Four 16-byte accesses per
+// thread are issued before the first is waited for: one element per iteration was 48 dependent read-modify-write round trips per
+// wave (3K = 48) and 25 of K8's 116 us.  `g` must be 16-byte aligned for the vector path (checked by the caller, uniform).
+template <int BLOCK, bool ADD>
+__device__ __forceinline__ void sh_rows_out(float* __restrict__ g, const float* __restrict__ s, int count, bool vec) {
+    const int tid = (int)threadIdx.x;
+    int done = 0;
+    if (vec) {
+        const int n4 = count >> 2;
+        float4* __restrict__ g4 = reinterpret_cast<float4*>(g);
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        for (int k = tid; k < n4; k += 4 * BLOCK) {
+            float4 v[4], o[4];
+            bool nz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = k + u * BLOCK < n4;
+                v[u] = in ? s4[k + u * BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
+                nz[u] = in && (!ADD || v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f);      // rows of culled Gaussians: nothing to add
+            }
+            if (ADD) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (nz[u]) o[u] = g4[k + u * BLOCK];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (nz[u]) g4[k + u * BLOCK] = make_float4(o[u].x + v[u].x, o[u].y + v[u].y, o[u].z + v[u].z, o[u].w + v[u].w);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (nz[u]) g4[k + u * BLOCK] = v[u];
+            }
+        }
+        done = n4 << 2;
+    }
+    for (int k = done + tid; k < count; k += BLOCK) {
+        const float v = s[k];
+        if (ADD) { if (v != 0.f) g[k] += v; } else g[k] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 __global__ void __launch_bounds__(TG_BLOCK)
 k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
@@ -318,7 +356,10 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ K8
-__global__ void __launch_bounds__(TG_BLOCK)
+#ifndef K8_BLOCK
+#define K8_BLOCK 256
+#endif
+__global__ void __launch_bounds__(K8_BLOCK)
 k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
                  const float* __restrict__ scales,
@@ -328,15 +369,16 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
                  float* __restrict__ d_uvs, float* __restrict__ d_coff, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K]: SH rows in, dL/dSH rows out
-    const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
+    const int i = blockIdx.x * K8_BLOCK + threadIdx.x;
     const int K = C.sh_coeffs;
     const bool live = i < C.N;
     const int row = 3 * K;
     const int na = (shs != nullptr && C.sh_degree > 0) ? sh_active(C.sh_degree, K) : 0;
-    const size_t first = (size_t)blockIdx.x * TG_BLOCK * row;
-    const int count = d_shs ? (int)min((size_t)TG_BLOCK * row, (size_t)C.N * row - first) : 0;
+    const size_t first = (size_t)blockIdx.x * K8_BLOCK * row;
+    const int count = d_shs ? (int)min((size_t)K8_BLOCK * row, (size_t)C.N * row - first) : 0;
+    const bool vec = d_shs && (((size_t)d_shs) & 15) == 0;
     if (na > 0 && d_shs) {
-        for (int k = threadIdx.x; k < count; k += TG_BLOCK) s_sh[k] = shs[first + k];
+        for (int k = threadIdx.x; k < count; k += K8_BLOCK) s_sh[k] = shs[first + k];      // plain loads: the compiler batches them
         __syncthreads();
     }
     const bool visible = live && radii[i] > 0;
@@ -541,8 +583,8 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
             if (live) for (int k = 0; k < row; ++k) s_sh[threadIdx.x * row + k] = 0.f;
         }
         __syncthreads();
-        if (accumulate & TEXGS_ACC_SHS) { for (int k = threadIdx.x; k < count; k += TG_BLOCK) { const float v = s_sh[k]; if (v != 0.f) d_shs[first + k] += v; } }
-        else            { for (int k = threadIdx.x; k < count; k += TG_BLOCK) d_shs[first + k] = s_sh[k]; }
+        if (accumulate & TEXGS_ACC_SHS) sh_rows_out<K8_BLOCK, true>(d_shs + first, s_sh, count, vec);
+        else sh_rows_out<K8_BLOCK, false>(d_shs + first, s_sh, count, vec);
     }
 }
 
@@ -573,9 +615,9 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
 void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                            TexGSGrads* gr, hipStream_t s) {
     if (c.N <= 0) return;
-    const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
-    const size_t lds = gr->dL_dshs ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
+    const int blocks = (c.N + K8_BLOCK - 1) / K8_BLOCK;
+    const size_t lds = gr->dL_dshs ? (size_t)K8_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(K8_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
                        gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
                        gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate);
