@@ -146,6 +146,21 @@ rep('''            __builtin_amdgcn_wave_barrier();
     if (ABL != 0 && L.items[lane * 3].x == 12345.678f) acc[0] = behind + T;    // ablation builds: keep the chains alive
 }
 ''')
+# ABL & 128: K7's record slots without the returning global atomic and without the per-lane base loads (wrong lists, same stores)
+rep('        if (leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)my_n);\n        if (R.binned) { R.b0 = tb.base[R.bin]; R.b1 = tb.base[R.bin + 1u]; }',
+    '''        if (ABL & 128) {
+            if (leader) R.slot0 = (uint32_t)((rbase * 7 + n_items * 13) & 2047);
+            if (R.binned) { R.b0 = R.bin * 3000u; R.b1 = R.b0 + 3000u; }
+        } else {
+        if (leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)my_n);
+        if (R.binned) { R.b0 = tb.base[R.bin]; R.b1 = tb.base[R.bin + 1u]; }
+        }''')
+# ABL & 256: the ballot grouping loop replaced by one group per round (wrong lists, same atomics and stores)
+rep('        while (pend != 0ull) {\n            const int l0 = __ffsll((long long)pend) - 1;\n            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);\n            const ull m = TG_BALLOT(R.binned && R.bin == b0);',
+    '''        while (pend != 0ull) {
+            const int l0 = __ffsll((long long)pend) - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
+            const ull m = (ABL & 256) ? pend : TG_BALLOT(R.binned && R.bin == b0);''')
 src += '''
 #ifdef TG_STATS
 extern "C" int texgs_debug_stats(unsigned long long* out32, int reset) {

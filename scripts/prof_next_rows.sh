@@ -24,7 +24,7 @@ for d in ("pmc1", "pmc2", "pmc3"):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
             for k in ("k_uv_taylor", "k_ssim", "k_geom", "k_norm_from"):
-                if k in n: agg[n.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if k in n: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
             print(d, k, {c: round(sum(v) / len(v) / 1e6, 3) for c, v in cs.items()}, "(millions)")
 PY
