@@ -134,7 +134,7 @@ rep('                const bool havet = (itk < n_it) && (c > 0);\n',
                 }
 #endif
 ''')
-rep('                ntask = __popcll(tm);\n', '                ntask = __popcll(tm);\n                CNT(12, ntask); CNT(13, (ntask + 3) >> 2);\n                if (ABL & 2) ntask = 0;\n')
+rep('                ntask = __popcll(tm);\n', '                ntask = __popcll(tm);\n                CNT(12, ntask); CNT(13, (ntask + 3) >> 2);\n                { const int n8_ = __popcll(TG_BALLOT(havet && c <= 8)), n4_ = __popcll(TG_BALLOT(havet && c <= 4)); CNT(1, n8_); CNT(2, n4_); CNT(0, ((ntask - n8_ + 3) >> 2) + ((n8_ + 7) >> 3)); }\n                if (ABL & 2) ntask = 0;\n')
 rep('''            __builtin_amdgcn_wave_barrier();
         }
     }

@@ -36,7 +36,7 @@ for v in views:
 torch.cuda.synchronize(); lib.texgs_debug_stats(buf, 1)
 nv = len(views)
 k6 = ["waves", "raw batches", "raw instances", "survivors 8x8", "chunks", "quadrant list entries", "sum tmax", "iterations", "iterations any-ok", "items", "drains", "sum max over 16 quad lists (bound)", "16 quad list entries (bound)", "sum max over 16 quad lists (exact)"]
-k7 = ["waves", "raw batches", "raw instances", "survivors 8x8", "chunks", "quadrant list entries", "sum tmax", "iterations", "productive iterations", "items", "segments", "B rounds", "C2 tasks", "C2 rounds", "distinct Gaussians per segment (sum)", "C2 tasks if merged per Gaussian"]
+k7 = ["waves + C2 rounds if tasks <= 8 items were paired", "C2 tasks with <= 8 items", "C2 tasks with <= 4 items", "survivors 8x8", "chunks", "quadrant list entries", "sum tmax", "iterations", "productive iterations", "items", "segments", "B rounds", "C2 tasks", "C2 rounds", "distinct Gaussians per segment (sum)", "C2 tasks if merged per Gaussian"]
 print("workload", wl, "D", s.D, "mean of", nv, "views")
 for i, n in enumerate(k6): print(f"K6 {n:26s} {buf[i] / nv:14.0f}")
 for i, n in enumerate(k7): print(f"K7 {n:26s} {buf[16 + i] / nv:14.0f}")
