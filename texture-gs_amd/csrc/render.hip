@@ -846,7 +846,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                         for (int k = M_N + 3; k < 32; ++k) part[k] = 0.f;
                     }
                     float lo, hi;
-                    reduce32_rows16(part, lane, lo, hi);          // lane holds slots transposed_index(lane & 15) and 16 + that
+                    static_assert(M_N + 3 == 28, "the butterfly below skips slots 28..31");
+                    reduce32_rows16<28>(part, lane, lo, hi);      // 28 moments (common.h M_*); lane holds slots transposed_index(lane & 15) and 16 + that
                     if (live) {
                         float* row = acc + (size_t)gid * TEXGS_ACC_FLOATS + transposed_index(sub);
                         if (lo != 0.f) unsafeAtomicAdd(row, lo);

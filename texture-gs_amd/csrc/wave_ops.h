@@ -148,13 +148,16 @@ __device__ __forceinline__ float reduce32_bankfirst(float (&v)[32], int lane) {
 // 16-lane version: sums v[0..31] over each DPP row (16 lanes) separately.  On return lane l holds, for its row, the total of
 // slot transposed_index(l & 15) in `lo` and of slot 16 + transposed_index(l & 15) in `hi` (the four steps of
 // reduce32_bankfirst before its cross-row exchanges: lane^4, lane^8 bank-masked, lane^1, lane^2 quad_perm).
+// NLIVE (a multiple of 4): slots >= NLIVE are known to be zero in every lane; their exchanges are not issued.
+template <int NLIVE = 32>
 __device__ __forceinline__ void reduce32_rows16(float (&v)[32], int lane, float& lo, float& hi) {
+    static_assert(NLIVE % 4 == 0 && NLIVE > 0 && NLIVE <= 32, "NLIVE");
     const bool b0 = lane & 1, b1 = lane & 2;
     float a[16], b[8], c[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = pair_xor4(v[2 * i], v[2 * i + 1]);
+    for (int i = 0; i < 16; ++i) a[i] = (2 * i < NLIVE) ? pair_xor4(v[2 * i], v[2 * i + 1]) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = pair_xor8(a[2 * i], a[2 * i + 1]);
+    for (int i = 0; i < 8; ++i) b[i] = (4 * i < NLIVE) ? pair_xor8(a[2 * i], a[2 * i + 1]) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float keep = b0 ? b[2 * i + 1] : b[2 * i], send = b0 ? b[2 * i] : b[2 * i + 1];
