@@ -26,9 +26,9 @@ constexpr int RS_GROUP = 32;            // rows per group partial
 struct RadixTables {                    // one per pass
     uint32_t* table;                    // [RS_MAX_BLOCKS][256] per-block digit counts (written, not accumulated)
     uint32_t* gtable;                   // [RS_MAX_BLOCKS / RS_GROUP][256] group partial sums (atomics: zero before the pass)
-    uint32_t* total;                    // [256] digit totals (atomics: zero before the pass)
-};
-constexpr size_t RS_ZERO_WORDS = (size_t)(RS_MAX_BLOCKS / RS_GROUP + 1) * 256;       // gtable + total of one pass
+};                                      // (digit totals = column sums of gtable, formed by the scatter kernel: a `total[256]` kept by
+                                        //  atomics took one atomic per (block, digit) on 256 hot words -- 548 per word in K4 at C3)
+constexpr size_t RS_ZERO_WORDS = (size_t)(RS_MAX_BLOCKS / RS_GROUP) * 256;           // gtable of one pass
 
 __device__ __forceinline__ uint32_t digit_of(uint32_t k, int shift, uint32_t mask) { return (k >> shift) & mask; }
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
@@ -61,10 +61,7 @@ k_radix_count(const KEY* __restrict__ keys, const uint32_t* __restrict__ n_ptr, 
     __syncthreads();
     const uint32_t c = s_hist[threadIdx.x];
     t.table[blockIdx.x * 256 + threadIdx.x] = c;
-    if (c != 0u) {
-        atomicAdd(&t.gtable[(blockIdx.x / RS_GROUP) * 256 + threadIdx.x], c);
-        atomicAdd(&t.total[threadIdx.x], c);
-    }
+    if (c != 0u) atomicAdd(&t.gtable[(blockIdx.x / RS_GROUP) * 256 + threadIdx.x], c);
 }
 
 // MODE 0: pairs (u32 key, u32 val) -> pairs; val_in == nullptr means val = element index (first depth pass)
@@ -104,18 +101,23 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
     // ---- where this block's digit-d elements start: digit base + blocks before this one
     uint32_t before = 0u;
     {
-        // fixed trip counts, predicated: all (at most 31 + 31) loads are in flight together instead of one round trip each
+        // fixed trip counts, predicated: all (at most 32 + 31) loads are in flight together instead of one round trip each.
+        // Every group row is read: the rows before this block's group count towards `before`, all of them towards the digit total.
+        static_assert(RS_MAX_BLOCKS / RS_GROUP <= RS_GROUP, "one loop covers the group rows and the rows inside a group");
         const int g = blockIdx.x / RS_GROUP, inb = (int)blockIdx.x - g * RS_GROUP;
+        const int ngroups = ((int)gridDim.x + RS_GROUP - 1) / RS_GROUP;
         uint32_t part[2 * RS_GROUP];
 #pragma unroll
         for (int k = 0; k < RS_GROUP; ++k) {
-            part[k] = (k < g) ? t.gtable[k * 256 + tid] : 0u;
+            part[k] = (k < ngroups) ? t.gtable[k * 256 + tid] : 0u;
             part[RS_GROUP + k] = (k < inb) ? t.table[(g * RS_GROUP + k) * 256 + tid] : 0u;
         }
+        uint32_t tot = 0u;
 #pragma unroll
-        for (int k = 0; k < 2 * RS_GROUP; ++k) before += part[k];
+        for (int k = 0; k < RS_GROUP; ++k) { tot += part[k]; before += (k < g) ? part[k] : 0u; }
+#pragma unroll
+        for (int k = RS_GROUP; k < 2 * RS_GROUP; ++k) before += part[k];
         // exclusive scan of the digit totals over the 256 digits (thread = digit)
-        const uint32_t tot = t.total[tid];
         uint32_t incl = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
@@ -251,7 +253,7 @@ k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, con
             uint2* __restrict__ ranges, uint32_t* __restrict__ zero_words, int num_zero_words) {
     const int r = blockIdx.x * TG_BLOCK + threadIdx.x;
     for (int k = r; k < T; k += (int)gridDim.x * TG_BLOCK) ranges[k] = make_uint2(0u, 0u);
-    for (int k = r; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // group / total count tables of the tile sort
+    for (int k = r; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // group count tables of the tile sort
     if (r >= N) return;
     const uint32_t id = id_rank[r];
     if (tiles_touched[id] == 0u) return;
@@ -323,10 +325,10 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- scratch layouts ------------------------------------------------------------------------------------------------
 // scan_temp (Gaussian level, sized by scan_temp_bytes(N)):
-//   [0]        header zero-filled by K1: 4 x (gtable + total) of the depth passes
+//   [0]        header zero-filled by K1: 4 x gtable of the depth passes
 //   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)]), block_D (u32[ceil(N / 256)])
 // sort_temp (instance level, sized by sort_temp_bytes(capacity, T)):
-//   [0]        header zero-filled by K3: 3 x (gtable + total) of the tile passes
+//   [0]        header zero-filled by K3: 3 x gtable of the tile passes
 //   then       3 x table, elem_tmp (u64[capacity])
 struct GaussScratch {
     uint32_t* tables;       // 4 passes
@@ -350,11 +352,10 @@ inline GaussScratch gauss_scratch(void* base, int N) {
     g.block_D = (uint32_t*)p;
     return g;
 }
-// pass `pass` of `passes`: its (gtable, total) sit in the zeroed header at `base`, its table after the header
+// pass `pass` of `passes`: its gtable sits in the zeroed header at `base`, its table after the header
 inline RadixTables tables_at(uint32_t* base, int pass, int passes, size_t extra) {
     RadixTables t;
     t.gtable = base + (size_t)pass * RS_ZERO_WORDS;
-    t.total = t.gtable + (size_t)(RS_MAX_BLOCKS / RS_GROUP) * 256;
     t.table = reinterpret_cast<uint32_t*>((char*)base + zero_header_bytes(passes, extra)) + (size_t)pass * RS_MAX_BLOCKS * 256;
     return t;
 }
@@ -383,7 +384,7 @@ size_t sort_temp_bytes(uint32_t D, uint32_t T) {
 }
 
 uint32_t* bin_block_sums_ptr(const TexGSGeom* g, int N) { return gauss_scratch(g->scan_temp, N).block_D; }
-uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // group / total count tables of the depth passes: K1 zero-fills them
+uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // group count tables of the depth passes: K1 zero-fills them
     const GaussScratch gs = gauss_scratch(g->scan_temp, N);
     *words = (int)(gs.header_bytes / 4);
     return gs.tables;
