@@ -864,24 +864,33 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 // Exclusive scan of K6's per-bin footprint counts -> list offsets (one workgroup; nbins = 6144 at R = 1024).
 __global__ void __launch_bounds__(1024)
 k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ stats) {
+    // one pass: thread t owns the `per` consecutive counts [t * per, (t + 1) * per) -- serial inside the thread, one wave scan,
+    // one cross-wave step (6 144 bins at R = 1024: 6 per thread).  Chunks of 1 024 x BO_MAX bins if there are more.
+    constexpr int BO_MAX = 32;
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_carry = 0u;
     __syncthreads();
-    for (int b0 = 0; b0 < nbins; b0 += 1024) {
-        const int i = b0 + tid;
-        const uint32_t c = (i < nbins) ? count[i] : 0u;
-        uint32_t incl = c;
+    for (int c0 = 0; c0 < nbins; c0 += 1024 * BO_MAX) {
+        const int n = min(nbins - c0, 1024 * BO_MAX);
+        const int per = (n + 1023) >> 10;
+        const int i0 = c0 + tid * per;
+        uint32_t v[BO_MAX];
+        uint32_t sum = 0u;
+#pragma unroll
+        for (int k = 0; k < BO_MAX; ++k) { v[k] = (k < per && i0 + k < c0 + n) ? count[i0 + k] : 0u; sum += v[k]; }
+        uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
         if (lane == 63) s_w[wv] = incl;
         __syncthreads();
-        uint32_t off = s_carry;
-        for (int w = 0; w < wv; ++w) off += s_w[w];
-        if (i < nbins) base[i] = off + incl - c;
+        uint32_t run = s_carry + incl - sum;
+        for (int w = 0; w < wv; ++w) run += s_w[w];
+#pragma unroll
+        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) base[i0 + k] = run; run += v[k]; }
         __syncthreads();
-        if (tid == 1023) s_carry = off + incl;
+        if (tid == 1023) s_carry = run;
         __syncthreads();
     }
     if (tid == 0) {
