@@ -22,6 +22,11 @@ namespace {
 constexpr int RS_THREADS = 256;         // 4 waves
 constexpr int RS_MAX_BLOCKS = 1024;     // count-table rows per pass
 constexpr int RS_GROUP = 32;            // rows per group partial
+// elements per block, lower bound: a block is one dependent chain (loads -> table prefix -> 64-element rows ranked one after the
+// other), so at the sizes of this path smaller blocks finish sooner: 2048 / 1024 / 512 / 256 -> K2 + K4 = 92 / 78 / 73 / 75 us at C2
+#ifndef RS_PER_MIN
+#define RS_PER_MIN 512u
+#endif
 
 struct RadixTables {                    // one per pass
     uint32_t* table;                    // [RS_MAX_BLOCKS][256] per-block digit counts (written, not accumulated)
@@ -194,7 +199,11 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
 }
 
 // ---- exclusive scan of tiles_touched in depth-rank order (two launches, 2048 elements per block)
-constexpr int SC_PER = 2048;
+#ifndef SC_PER_DEF
+#define SC_PER_DEF 512          // 2048 / 1024 / 512: K2 48.6 / 46.5 / 45.2 us at C2 (same reason as RS_PER_MIN)
+#endif
+constexpr int SC_PER = SC_PER_DEF;
+constexpr int SC_ELEMS = SC_PER / RS_THREADS;      // consecutive elements per thread in k_scan_apply
 __global__ void __launch_bounds__(RS_THREADS)
 k_scan_sums(int N, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ bsum) {
     __shared__ uint32_t s_w[4];
@@ -227,12 +236,12 @@ k_scan_apply(int N, int nblocks, const uint32_t* __restrict__ id_rank, const uin
         if (tid == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
-    // thread t owns elements [t * 8, t * 8 + 8) of the block (rank order)
-    const int r0 = blockIdx.x * SC_PER + tid * 8;
-    uint32_t v[8];
+    // thread t owns elements [t * SC_ELEMS, (t + 1) * SC_ELEMS) of the block (rank order)
+    const int r0 = blockIdx.x * SC_PER + tid * SC_ELEMS;
+    uint32_t v[SC_ELEMS];
     uint32_t s = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int r = r0 + k; v[k] = (r < N) ? tiles_touched[id_rank[r]] : 0u; s += v[k]; }
+    for (int k = 0; k < SC_ELEMS; ++k) { const int r = r0 + k; v[k] = (r < N) ? tiles_touched[id_rank[r]] : 0u; s += v[k]; }
     uint32_t incl = s;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
@@ -242,7 +251,7 @@ k_scan_apply(int N, int nblocks, const uint32_t* __restrict__ id_rank, const uin
     uint32_t run = s_base + incl - s;
     for (int w = 0; w < wv; ++w) run += s_w[w];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int r = r0 + k; if (r < N) offs_rank[r] = run; run += v[k]; }
+    for (int k = 0; k < SC_ELEMS; ++k) { const int r = r0 + k; if (r < N) offs_rank[r] = run; run += v[k]; }
 }
 
 // K3: one thread per depth rank; emits that Gaussian's instances, element = (tile << 32) | rank, at offs_rank[rank]...
@@ -361,7 +370,7 @@ inline RadixTables tables_at(uint32_t* base, int pass, int passes, size_t extra)
 }
 inline void pass_geometry(uint32_t n, uint32_t& blocks, uint32_t& per) {
     per = ((n + RS_MAX_BLOCKS - 1) / RS_MAX_BLOCKS + 63u) & ~63u;       // elements per block, multiple of 64
-    if (per < 2048u) per = 2048u;
+    if (per < RS_PER_MIN) per = RS_PER_MIN;
     blocks = (n + per - 1) / per;
     if (blocks == 0u) blocks = 1u;
 }
