@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 9
+#define TEXGS_ABI_VERSION 10
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
 #define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
@@ -59,10 +59,18 @@ typedef struct TexGSInputs {
     const float* rotations;    /* f32[N,4] (w,x,y,z), unit (:201)                                      */
     const float* uvs;          /* f32[N,3] phi(mu) on the unit sphere (:229-236)                       */
     const float* gradient_uvs; /* f32[N,9] [3*i+j] = d uv_i / d x_j (:216-227)                         */
-    const float* texture;      /* f32[6,R,R,3] SH-DC valued cubemap (:51, :16-21)                      */
+    const float* texture;      /* f32[6,R,R,3] SH-DC valued cubemap (:51, :16-21).  NULL = the UNTEXTURED surface (`diff_gauss`,
+                                  render/render.py:75-84): colour = max(0, viewdep + color_offset + 0.5); uvs / gradient_uvs may
+                                  then be NULL too, the blend kernels skip the UV step, the cubemap address and the taps, and
+                                  TexGSFrame.tex_res is ignored                                                             */
     const float* color_offset; /* f32[N,3] or NULL: added to the view-dependent colour term.  Used by the
                                   untextured `diff_gauss` surface (render/render.py:75-84): C0*SH_DC or
                                   colors_precomp - 0.5                                                    */
+    const float* cov3D_precomp;/* f32[N,6] or NULL: world-space covariance (xx,xy,xz,yy,yz,zz -- strip_lowerdiag,
+                                  utils/general.py:73-82) used INSTEAD of scales / rotations (render/render.py:52-53,
+                                  `cov3Ds_precomp`; scales / rotations may then be NULL and scale_modifier is not applied).
+                                  Untextured surface only.  The splat normal is then the eigenvector of the smallest eigenvalue
+                                  (a selection: no gradient flows through it)                                           */
 } TexGSInputs;
 
 /* Per-Gaussian state written by texgs_preprocess_forward (K1) and texgs_read_num_rendered (K2). */
@@ -121,7 +129,16 @@ typedef struct TexGSImage {
 #define TEXGS_ACC_ROTATIONS 32
 #define TEXGS_ACC_UVS 64
 #define TEXGS_ACC_COLOR_OFFSET 128
-#define TEXGS_ACC_ALL 255
+#define TEXGS_ACC_COV3D 256
+#define TEXGS_ACC_ALL 511
+
+/* TexGSGrads.want: which gradients the caller will read.  The backward compiles out what nobody asked for. */
+#define TEXGS_WANT_TEXTURE   1  /* dL_dtexture (records + bin reduce, or atomics).  Without it K6 need not count footprints
+                                   (TexGSImage.tex_bin_count NULL) and K7 appends nothing                                    */
+#define TEXGS_WANT_GAUSSIANS 2  /* every per-Gaussian output (means3D .. color_offset): K7's per-pixel recurrence and moment sums,
+                                   and K8.  Without it texgs_backward_preprocess is a no-op and the per-Gaussian outputs are
+                                   left untouched (a texture-only optimisation step, models/texture_gaussian3d.py:439-440)  */
+#define TEXGS_WANT_ALL       3
 
 /* Backward: upstream grads in, input grads out.  NULL dL_dout pointers mean "zero". */
 typedef struct TexGSGrads {
@@ -129,7 +146,7 @@ typedef struct TexGSGrads {
     const float* dL_ddepth;    /* f32[1,H,W] or NULL */
     const float* dL_dnorm;     /* f32[3,H,W] or NULL */
     const float* dL_dalpha;    /* f32[1,H,W] or NULL */
-    float* acc;                /* f32[N,32] ALL-ZERO on entry and all-zero again on return (K8 clears the rows it read):
+    float* acc;                /* (needed with TEXGS_WANT_GAUSSIANS) f32[N,32] ALL-ZERO on entry and all-zero again on return (K8 clears the rows it read):
                                   per-Gaussian raw moment sums, scratch between the two backward kernels              */
     float* dL_dmeans3D;        /* f32[N,3]                                                             */
     float* dL_dmeans2D;        /* f32[N,3] dL/d(ndc xy), z = 0 (lineage convention)                    */
@@ -138,8 +155,12 @@ typedef struct TexGSGrads {
     float* dL_dscales;         /* f32[N,3]                                                             */
     float* dL_drotations;      /* f32[N,4]                                                             */
     float* dL_duvs;            /* f32[N,3]                                                             */
-    float* dL_dtexture;        /* f32[6,R,R,3] caller zero-filled; accumulated with fp32 atomics       */
+    float* dL_dtexture;        /* (needed with TEXGS_WANT_TEXTURE) f32[6,R,R,3] caller zero-filled; accumulated into with fp32
+                                  atomics.  An inf / NaN upstream colour gradient reaches exactly the texels it touches     */
     float* dL_dcolor_offset;   /* f32[N,3] or NULL                                                     */
+    float* dL_dcov3D;          /* f32[N,6] or NULL (required with TexGSInputs.cov3D_precomp when Gaussian gradients are wanted;
+                                  off-diagonal entries carry both symmetric halves, as the lineage's do)                 */
+    uint32_t want;             /* TEXGS_WANT_* bit mask, non-zero                                      */
     float*    tex_bins;        /* texture-gradient records, f32[5 * tex_rec_cap] (plane-major), or NULL.
                                   The texture is cut into 32x32-texel blocks ("bins", 6 * ceil(R/32)^2 of them).  K7 appends
                                   one 20-byte record {fx | cell x, fy | cell y, dL/dtexel-colour rgb} per bilinear footprint
@@ -149,10 +170,10 @@ typedef struct TexGSGrads {
                                   NULL (or no counts, or cap 0) = fp32 atomics straight into dL_dtexture (~20 G requests/s
                                   memory-side: 0.7 ms per C3 view).  Contents need no initialisation.  The 5 low mantissa
                                   bits of fx / fy carry the cell (fx, fy keep 18 bits, rounded).                         */
-    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: list fill counters, ALL-ZERO on entry and all-zero again on
-                                  return (the reduce clears what it read).  Word [count] receives max(records a call needed)
-                                  (never cleared by the library: the caller sizes tex_rec_cap from it); [count+1] = bits of
-                                  max |dL/dpixel colour| of the call in flight (reset at the start of every backward).             */
+    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: the lists' fill cursors (scratch, set at the start of every
+                                  backward: no initialisation) + two status words: [count] receives max(records a call needed)
+                                  -- zero it once; never cleared by the library: the caller sizes tex_rec_cap from it --,
+                                  [count+1] = bits of max |dL/dpixel colour| of the call in flight (reset by every backward).  */
     uint32_t* tex_bin_base;    /* u32[texgs_tex_bin_count(R) + 1]: scratch, list offsets of this call (no initialisation)    */
     uint32_t  tex_rec_cap;     /* records tex_bins holds.  Too small is not an error: footprints that do not fit fall back
                                   to atomics.                                                                            */

@@ -106,8 +106,12 @@ def sh_view_dependent(deg, shs, dirs):
     return res
 
 
-def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, st, dtype, color_offset=None):
-    """K1 of SURVEY Appendix A.2 (+ the texture pre-fold).  Returns a dict of per-Gaussian state."""
+def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, st, dtype, color_offset=None,
+               cov3D_precomp=None):
+    """K1 of SURVEY Appendix A.2 (+ the texture pre-fold).  Returns a dict of per-Gaussian state.
+    cov3D_precomp [N,6] (xx,xy,xz,yy,yz,zz -- strip_lowerdiag, utils/general.py:73-82; render/render.py:52-53): the world
+    covariance, used instead of scales / rotations and without the scale modifier (lineage); the normal is then the
+    eigenvector of the smallest eigenvalue, a selection like the shortest-axis choice: no gradient through it."""
     H, W = int(st.image_height), int(st.image_width)
     V = st.viewmatrix.to(dtype)      # row-vector: p_view = [x,y,z,1] @ V   (utils/cameras.py:62)
     P = st.projmatrix.to(dtype)      # full world->clip, row-vector          (utils/cameras.py:64)
@@ -131,10 +135,16 @@ def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradien
         ndc = ndc + means2D[:, :2]   # dL/d(ndc xy) = dL/d(pixel xy) * S/2, the lineage's convention
     xy = torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], dim=1)
 
-    R = build_rotation(rotations)
-    s = scales * st.scale_modifier
-    M = R * s[:, None, :]            # R @ diag(s)
-    Sigma = M @ M.transpose(1, 2)    # models/gaussian3d.py:17-21
+    if cov3D_precomp is not None:
+        c6 = cov3D_precomp
+        Sigma = torch.stack([c6[:, 0], c6[:, 1], c6[:, 2], c6[:, 1], c6[:, 3], c6[:, 4],
+                             c6[:, 2], c6[:, 4], c6[:, 5]], dim=1).reshape(N, 3, 3)
+        R = None
+    else:
+        R = build_rotation(rotations)
+        s = scales * st.scale_modifier
+        M = R * s[:, None, :]            # R @ diag(s)
+        Sigma = M @ M.transpose(1, 2)    # models/gaussian3d.py:17-21
 
     limx, limy = FRUSTUM_CLAMP * st.tanfovx, FRUSTUM_CLAMP * st.tanfovy
     txtz, tytz = tx / tzs, ty / tzs
@@ -177,8 +187,11 @@ def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradien
         viewdep = viewdep + color_offset
 
     # normal = shortest axis, flipped to face the camera, world space
-    kmin = torch.argmin(scales.detach(), dim=1)
-    n = R[torch.arange(N), :, kmin]
+    if R is None:
+        n = torch.linalg.eigh(Sigma.detach()).eigenvectors[:, :, 0]      # eigenvalues ascending: column 0 = smallest
+    else:
+        kmin = torch.argmin(scales.detach(), dim=1)
+        n = R[torch.arange(N), :, kmin]
     flip = (n.detach() * dirs.detach()).sum(1) > 0
     n = torch.where(flip[:, None], -n, n)
 
@@ -385,13 +398,13 @@ def _scatter_image(out, PY, PX, VAL):
 
 
 def rasterize(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture,
-              st: Settings, dtype=torch.float64, debug=False, color_offset=None):
+              st: Settings, dtype=torch.float64, debug=False, color_offset=None, cov3D_precomp=None):
     """Whole operator (reference call: render/uv_tex_render.py:56-66).  Returns
     (image[3,H,W], depth[1,H,W], norm[3,H,W], alpha[1,H,W], radii[N] int32, extra=None) and, with
     debug=True, a dict of intermediates for the integer-stage parity tests."""
     cv = lambda t: None if t is None else t.to(dtype)
     pre = preprocess(cv(means3D), cv(means2D), cv(shs), cv(opacities), cv(scales), cv(rotations),
-                     cv(uvs), cv(gradient_uvs), st, dtype, color_offset=cv(color_offset))
+                     cv(uvs), cv(gradient_uvs), st, dtype, color_offset=cv(color_offset), cov3D_precomp=cv(cov3D_precomp))
     binning = bin_and_sort(pre)
     out, final_T, n_contrib, amb = render(pre, binning, cv(texture), st, dtype)
     res = (out[0:3], out[3:4], out[4:7], out[7:8], pre['radius'].to(torch.int32), None)

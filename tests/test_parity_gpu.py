@@ -237,6 +237,56 @@ def test_untextured_diff_gauss_surface(lib_built):
             assert ok, (mode, n, msg)
 
 
+def test_untextured_surface_with_cov3Ds_precomp(lib_built):
+    """`cov3Ds_precomp` on the diff_gauss surface (render/render.py:52-53,75-84; layout utils/general.py:73-82): K1 reads the
+    6-vector instead of scales / rotations, K8 returns dL/dcov3D (off-diagonals carry both symmetric halves) -- forward and all
+    gradients against autograd of the fp64 oracle fed the same covariances.  Ellipsoids with three distinct axes, so that the
+    smallest-eigenvector normal is well defined."""
+    import diff_gauss as dg
+    from oracle import texgs_torch as O
+    scene, cam, deg, bg = _scene(CASES[3])
+    dev = torch.device("cuda:0")
+    N = scene.means3D.shape[0]
+    g = torch.Generator().manual_seed(18)
+    d = torch.float64
+    sc = scene.scales.to(d).clone()
+    sc[:, 2] = sc[:, :2].min(dim=1).values * (0.2 + 0.3 * torch.rand(N, generator=g, dtype=d))     # thin but not degenerate
+    Rm = O.build_rotation(scene.rotations.to(d))
+    M = Rm * sc[:, None, :]
+    Sig = M @ M.transpose(1, 2)
+    cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], 1)
+    col = torch.rand(N, 3, generator=g)
+    target, nhat = synth.make_targets(cam.image_height, cam.image_width, seed=4)
+    st_gpu = Hh.settings_for(cam, 0, bg, device=dev, cls=dg.GaussianRasterizationSettings)
+    leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(True) for n in ["means3D", "opacities"]}
+    c_gpu = cov6.float().to(dev).requires_grad_(True)
+    col_gpu = col.to(dev).requires_grad_(True)
+    m2 = torch.zeros(N, 3, device=dev, requires_grad=True)
+    with pytest.raises(ValueError):
+        dg.GaussianRasterizer(st_gpu)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], colors_precomp=col_gpu,
+                                      scales=scene.scales.to(dev), rotations=scene.rotations.to(dev), cov3Ds_precomp=c_gpu)
+    out = dg.GaussianRasterizer(st_gpu)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                        colors_precomp=col_gpu, scales=None, rotations=None, cov3Ds_precomp=c_gpu)
+    synth.synthetic_loss(out[0], out[3], out[2], target.to(dev), nhat.to(dev)).backward()
+    ol = {n: getattr(scene, n).clone().to(d).requires_grad_(True) for n in leaves}
+    oc = cov6.float().to(d).requires_grad_(True)
+    ocol = col.to(d).requires_grad_(True)
+    st = Hh.settings_for(cam, 0, bg)
+    uvs = torch.zeros(N, 3, dtype=d); uvs[:, 2] = 1.0
+    ref = O.rasterize(ol["means3D"], None, None, ol["opacities"], None, None, uvs, torch.zeros(N, 9, dtype=d),
+                      torch.zeros(6, 1, 1, 3, dtype=d), st, color_offset=ocol - 0.5, cov3D_precomp=oc)
+    synth.synthetic_loss(ref[0], ref[3], ref[2], target.to(d), nhat.to(d)).backward()
+    assert torch.equal(out[4].cpu(), ref[4])
+    for k, name in ((0, "image"), (2, "norm"), (3, "alpha")):
+        err = float((out[k].detach().cpu().double() - ref[k]).abs().max())
+        Hh.report(f"cov3Ds_precomp/fwd/{name}", max_err=err)
+        assert err < 2e-4, (name, err)
+    for name, got, exp in (("cov3D", c_gpu.grad, oc.grad), ("colors", col_gpu.grad, ocol.grad), ("means3D", leaves["means3D"].grad, ol["means3D"].grad),
+                           ("opacities", leaves["opacities"].grad, ol["opacities"].grad)):
+        ok, msg = Hh.grad_close(got.cpu(), exp, label=f"cov3Ds_precomp/bwd/{name}")
+        assert ok, (name, msg)
+
+
 def test_fused_grad_sink_equals_autograd_accumulation(lib_built):
     """texgs.multiview fused accumulation (kernels add into the bucket) == plain autograd accumulation over 3 views."""
     from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer

@@ -73,6 +73,7 @@ int validate_frame(const TexGSFrame* f) {
     if (f->sh_degree < 0 || f->sh_degree > 3) return fail_msg("sh_degree must be in [0,3]");
     if (f->num_gaussians < 0) return fail_msg("num_gaussians < 0");
     if (f->tex_res <= 0) return fail_msg("tex_res must be positive");
+    if (f->tex_res > 7168) return fail_msg("tex_res > 7168: the blend kernels address texels with 32-bit byte offsets (6 R^2 x 12 B < 2^32)");
     if (!f->bg || !f->viewmatrix || !f->projmatrix || !f->campos) return fail_msg("frame device pointers must be non-NULL");
     return 0;
 }
@@ -95,8 +96,10 @@ int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, Tex
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom) return fail_msg("NULL argument");
     if (frame->num_gaussians == 0) return 0;
-    if (!in->means3D || !in->opacities || !in->scales || !in->rotations || !in->uvs || !in->gradient_uvs)
-        return fail_msg("per-Gaussian input pointer is NULL");
+    if (!in->means3D || !in->opacities) return fail_msg("per-Gaussian input pointer is NULL");
+    if (in->texture && (!in->uvs || !in->gradient_uvs)) return fail_msg("uvs / gradient_uvs are required with a texture");
+    if (in->cov3D_precomp && in->texture) return fail_msg("cov3D_precomp is an input of the untextured surface only (texture must be NULL)");
+    if (!in->cov3D_precomp && (!in->scales || !in->rotations)) return fail_msg("scales and rotations (or cov3D_precomp) are required");
     if (geom->scan_temp_bytes < scan_temp_bytes(frame->num_gaussians)) return fail_msg("scan_temp too small");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
@@ -159,10 +162,9 @@ static int render_forward_impl(const TexGSFrame* frame, const TexGSInputs* in, c
                                const TexGSBinning* bin, TexGSImage* img, void* stream, bool counters_zeroed) {
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !bin || !img) return fail_msg("NULL argument");
-    if (!in->texture) return fail_msg("texture is NULL");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
-    if (img->tex_bin_count && !counters_zeroed) {       // K6 counts the texture-gradient footprints per bin into it
+    if (img->tex_bin_count && in->texture && !counters_zeroed) {       // K6 counts the texture-gradient footprints per bin into it
         hipError_t e = hipMemsetAsync(img->tex_bin_count, 0, sizeof(uint32_t) * tex_bin_count(c.R), s);
         if (e != hipSuccess) return fail("tex_bin_count memset", e);
     }
@@ -213,7 +215,9 @@ int texgs_backward_render(const TexGSFrame* frame, const TexGSInputs* in, const 
                           const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !bin || !img || !grads) return fail_msg("NULL argument");
-    if (!grads->acc || !grads->dL_dtexture) return fail_msg("acc / dL_dtexture must be allocated (zero-filled)");
+    if (!(grads->want & TEXGS_WANT_ALL)) return fail_msg("TexGSGrads.want is empty: ask for TEXGS_WANT_TEXTURE and / or TEXGS_WANT_GAUSSIANS");
+    if ((grads->want & TEXGS_WANT_GAUSSIANS) && !grads->acc) return fail_msg("acc must be allocated (zero-filled) when Gaussian gradients are wanted");
+    if ((grads->want & TEXGS_WANT_TEXTURE) && in->texture && !grads->dL_dtexture) return fail_msg("dL_dtexture must be allocated (zero-filled) when the texture gradient is wanted");
     if (!img->survivors || !img->surv_qmask || !img->surv_count)
         return fail_msg("the forward of this call left no survivor lists (TexGSImage.survivors / surv_qmask / surv_count were NULL): "
                         "run the forward with them to be able to run its backward");
@@ -222,7 +226,7 @@ int texgs_backward_render(const TexGSFrame* frame, const TexGSInputs* in, const 
     if (bin->num_rendered > 0) {
         { ProfScope p(TEXGS_K_RENDER_BWD, s); launch_render_bwd(c, frame, in, geom, bin, img, grads, s); }
         if (int r = check(frame, s, "render_bwd")) return r;
-        if (tex_bins_enabled(c, img, grads)) {
+        if (tex_bins_enabled(c, in, img, grads)) {
             { ProfScope p(TEXGS_K_TEXGRAD_REDUCE, s); launch_texgrad_reduce(c, img, grads, s); }
             if (int r = check(frame, s, "texgrad_reduce")) return r;
         }
@@ -234,7 +238,9 @@ int texgs_backward_preprocess(const TexGSFrame* frame, const TexGSInputs* in, co
                               void* stream) {
     if (int r = validate_frame(frame)) return r;
     if (!in || !geom || !grads) return fail_msg("NULL argument");
+    if (!(grads->want & TEXGS_WANT_GAUSSIANS)) return 0;          // nobody reads a per-Gaussian gradient: K7 summed no moments either
     if (!grads->acc) return fail_msg("acc must be allocated");
+    if (in->cov3D_precomp && !grads->dL_dcov3D) return fail_msg("dL_dcov3D is required with cov3D_precomp");
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     { ProfScope p(TEXGS_K_PREPROCESS_BWD, s); launch_preprocess_bwd(c, frame, in, geom, grads, s); }

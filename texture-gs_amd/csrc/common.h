@@ -69,7 +69,7 @@ void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s);
 size_t tex_bin_count(int R);
-bool tex_bins_enabled(const CamConst& c, const TexGSImage* img, const TexGSGrads* gr);
+bool tex_bins_enabled(const CamConst& c, const TexGSInputs* in, const TexGSImage* img, const TexGSGrads* gr);
 void launch_texgrad_reduce(const CamConst& c, const TexGSImage* img, TexGSGrads* gr, hipStream_t s);
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s);

@@ -43,9 +43,48 @@ struct Geo {
 // Wr[r][c] (world->view rotation, column-vector form) = V[c*4 + r]
 #define WR(F, r, c) ((F).V[(c) * 4 + (r)])
 
+// Unit eigenvector of the SMALLEST eigenvalue of the symmetric 3x3 matrix S6 = (xx,xy,xz,yy,yz,zz): cyclic Jacobi, 6 sweeps,
+// everything in registers (fixed rotation order (0,1), (0,2), (1,2); the matrix is first scaled by 1 / trace so that the
+// products of a 1e-5-sized covariance stay far from underflow).  Used only with cov3D_precomp, where there is no rotation matrix
+// whose column could be taken: "the shortest axis" of the splat is this eigenvector.
+__device__ __forceinline__ void smallest_eigvec(const float* S6, float* n) {
+    const float tr = S6[0] + S6[3] + S6[5];
+    const float sc = (tr > 0.f) ? 1.0f / tr : 1.0f;
+    float a00 = S6[0] * sc, a01 = S6[1] * sc, a02 = S6[2] * sc, a11 = S6[3] * sc, a12 = S6[4] * sc, a22 = S6[5] * sc;
+    float v00 = 1.f, v01 = 0.f, v02 = 0.f, v10 = 0.f, v11 = 1.f, v12 = 0.f, v20 = 0.f, v21 = 0.f, v22 = 1.f;   // v[r][c], columns = eigenvectors
+    // one Jacobi rotation in the (p, q) plane; r is the third index.  app, aqq, apq: the 2x2 block; arp, arq: the third row's entries
+    auto rot = [](float& app, float& aqq, float& apq, float& arp, float& arq, float& v0p, float& v0q, float& v1p, float& v1q,
+                  float& v2p, float& v2q) {
+        if (fabsf(apq) < 1e-30f) return;
+        const float theta = (aqq - app) / (2.0f * apq);
+        const float t = ((theta >= 0.f) ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+        const float c = 1.0f / sqrtf(t * t + 1.0f), sn = t * c;
+        app -= t * apq; aqq += t * apq; apq = 0.f;
+        const float rp = arp, rq = arq;
+        arp = c * rp - sn * rq; arq = sn * rp + c * rq;
+        float x;
+        x = v0p; v0p = c * x - sn * v0q; v0q = sn * x + c * v0q;
+        x = v1p; v1p = c * x - sn * v1q; v1q = sn * x + c * v1q;
+        x = v2p; v2p = c * x - sn * v2q; v2q = sn * x + c * v2q;
+    };
+#pragma unroll 1
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        rot(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21);
+        rot(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22);
+        rot(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22);
+    }
+    int k = 0; float m = a00;
+    if (a11 < m) { m = a11; k = 1; }
+    if (a22 < m) { m = a22; k = 2; }
+    n[0] = (k == 0) ? v00 : ((k == 1) ? v01 : v02);
+    n[1] = (k == 0) ? v10 : ((k == 1) ? v11 : v12);
+    n[2] = (k == 0) ? v20 : ((k == 1) ? v21 : v22);
+}
+
 __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamConst& C, int i,
                                             const float* __restrict__ means, const float* __restrict__ scales,
-                                            const float* __restrict__ rots, const float* __restrict__ juv) {
+                                            const float* __restrict__ rots, const float* __restrict__ juv,
+                                            const float* __restrict__ cov6 = nullptr) {
     g.m[0] = means[3 * i + 0]; g.m[1] = means[3 * i + 1]; g.m[2] = means[3 * i + 2];
     const float mx = g.m[0], my = g.m[1], mz = g.m[2];
     g.t[0] = F.V[0] * mx + F.V[4] * my + F.V[8] * mz + F.V[12];
@@ -64,13 +103,22 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
     g.xy[0] = ((ndcx + 1.0f) * (float)C.W - 1.0f) * 0.5f;
     g.xy[1] = ((ndcy + 1.0f) * (float)C.H - 1.0f) * 0.5f;
 
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (cov6 != nullptr) {
+        // world-space covariance given (render/render.py:52-53): used as it is, scale_modifier not applied (lineage)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g.S[k] = cov6[6 * i + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { g.R[k] = 0.f; g.M[k] = 0.f; }
+        g.q[0] = g.q[1] = g.q[2] = g.q[3] = 0.f; g.s[0] = g.s[1] = g.s[2] = 0.f;
+    } else {
     // cov3D = (R diag(s)) (R diag(s))^T      (models/gaussian3d.py:17-21, utils/general.py:87-119)
     g.q[0] = rots[4 * i + 0]; g.q[1] = rots[4 * i + 1]; g.q[2] = rots[4 * i + 2]; g.q[3] = rots[4 * i + 3];
     const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
     g.R[0] = 1.0f - 2.0f * (y * y + z * z); g.R[1] = 2.0f * (x * y - r * z); g.R[2] = 2.0f * (x * z + r * y);
     g.R[3] = 2.0f * (x * y + r * z); g.R[4] = 1.0f - 2.0f * (x * x + z * z); g.R[5] = 2.0f * (y * z - r * x);
     g.R[6] = 2.0f * (x * z - r * y); g.R[7] = 2.0f * (y * z + r * x); g.R[8] = 1.0f - 2.0f * (x * x + y * y);
-    const float s0 = scales[3 * i + 0], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    s0 = scales[3 * i + 0]; s1 = scales[3 * i + 1]; s2 = scales[3 * i + 2];
     g.s[0] = C.scale_modifier * s0; g.s[1] = C.scale_modifier * s1; g.s[2] = C.scale_modifier * s2;
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)
@@ -83,6 +131,7 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
     g.S[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
     g.S[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
     g.S[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    }
 
     // EWA cov2D = (J Wr) S (J Wr)^T + 0.3 I
     const float limx = TG_FRUSTUM_CLAMP * C.tanfovx, limy = TG_FRUSTUM_CLAMP * C.tanfovy;
@@ -120,13 +169,21 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
     g.radius = (int)ceilf(3.0f * sqrtf(lam));
 
     // normal: shortest axis (first minimum), flipped to face the camera, world space
-    g.kmin = 0; float smin = s0;
-    if (s1 < smin) { smin = s1; g.kmin = 1; }
-    if (s2 < smin) { smin = s2; g.kmin = 2; }
     g.dir[0] = mx - F.cam[0]; g.dir[1] = my - F.cam[1]; g.dir[2] = mz - F.cam[2];
-    const float n0 = (g.kmin == 0) ? g.R[0] : ((g.kmin == 1) ? g.R[1] : g.R[2]);      // selects, not a runtime index:
-    const float n1 = (g.kmin == 0) ? g.R[3] : ((g.kmin == 1) ? g.R[4] : g.R[5]);      // keeps R[] in registers
-    const float n2 = (g.kmin == 0) ? g.R[6] : ((g.kmin == 1) ? g.R[7] : g.R[8]);
+    float n0, n1, n2;
+    if (cov6 != nullptr) {
+        float ev[3];
+        smallest_eigvec(g.S, ev);
+        n0 = ev[0]; n1 = ev[1]; n2 = ev[2];
+        g.kmin = -1;                                // no rotation-matrix column: K8 sends no normal gradient anywhere
+    } else {
+        g.kmin = 0; float smin = s0;
+        if (s1 < smin) { smin = s1; g.kmin = 1; }
+        if (s2 < smin) { smin = s2; g.kmin = 2; }
+        n0 = (g.kmin == 0) ? g.R[0] : ((g.kmin == 1) ? g.R[1] : g.R[2]);      // selects, not a runtime index:
+        n1 = (g.kmin == 0) ? g.R[3] : ((g.kmin == 1) ? g.R[4] : g.R[5]);      // keeps R[] in registers
+        n2 = (g.kmin == 0) ? g.R[6] : ((g.kmin == 1) ? g.R[7] : g.R[8]);
+    }
     g.sign = ((n0 * g.dir[0] + n1 * g.dir[1] + n2 * g.dir[2]) > 0.0f) ? -1.0f : 1.0f;
     g.n[0] = g.sign * n0; g.n[1] = g.sign * n1; g.n[2] = g.sign * n2;
     g.dlen = sqrtf(g.dir[0] * g.dir[0] + g.dir[1] * g.dir[1] + g.dir[2] * g.dir[2]);
@@ -138,13 +195,14 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
         g.nv[k] = WR(F, k, 0) * g.n[0] + WR(F, k, 1) * g.n[1] + WR(F, k, 2) * g.n[2];
     g.sdot = g.nv[0] * tx + g.nv[1] * ty + g.nv[2] * tz;
     const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
-    g.degen = fabsf(g.sdot) <= TG_PLANE_EPS * tn;
+    g.degen = (juv == nullptr) || fabsf(g.sdot) <= TG_PLANE_EPS * tn;      // untextured surface: no UV plane at all
     // K = Jphi * R_c2w ; R_c2w[k][c] = Wr[c][k]
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc)
-            g.K[rr * 3 + cc] = juv[9 * i + rr * 3 + 0] * WR(F, cc, 0) + juv[9 * i + rr * 3 + 1] * WR(F, cc, 1)
+            g.K[rr * 3 + cc] = (juv == nullptr) ? 0.0f
+                             : juv[9 * i + rr * 3 + 0] * WR(F, cc, 0) + juv[9 * i + rr * 3 + 1] * WR(F, cc, 1)
                              + juv[9 * i + rr * 3 + 2] * WR(F, cc, 2);
     if (g.degen) {
         g.gx = 0.0f; g.gy = 0.0f;
@@ -271,7 +329,7 @@ __global__ void __launch_bounds__(TG_BLOCK)
 k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
                  const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ uvs,
-                 const float* __restrict__ juv, const float* __restrict__ coff,
+                 const float* __restrict__ juv, const float* __restrict__ coff, const float* __restrict__ cov6,
                  float4* __restrict__ rec_test, float4* __restrict__ rec_shade, float* __restrict__ depth, int32_t* __restrict__ radii,
                  uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_D,
                  uint32_t* __restrict__ zero_words, int num_zero_words) {
@@ -283,7 +341,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     g.valid = false;
-    if (live) geo_forward(g, F, C, i, means, scales, rots, juv);
+    if (live) geo_forward(g, F, C, i, means, scales, rots, juv, cov6);
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (g.valid) {
         tile_rect(g, C, x0, y0, x1, y1);
@@ -350,7 +408,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     float4* rs = rec_shade + (size_t)i * (TEXGS_REC_SHADE_FLOATS / 4);
     rs[0] = make_float4(g.gx, g.gy, g.G[0], g.G[1]);
     rs[1] = make_float4(g.G[2], g.G[3], g.G[4], g.G[5]);
-    rs[2] = make_float4(uvs[3 * i + 0], uvs[3 * i + 1], uvs[3 * i + 2], vd[0]);
+    rs[2] = uvs ? make_float4(uvs[3 * i + 0], uvs[3 * i + 1], uvs[3 * i + 2], vd[0]) : make_float4(0.f, 0.f, 1.f, vd[0]);
     rs[3] = make_float4(vd[1], vd[2], g.t[2], g.n[0]);
     rs[4] = make_float4(g.n[1], g.n[2], 0.f, 0.f);
 }
@@ -363,11 +421,11 @@ __global__ void __launch_bounds__(K8_BLOCK)
 k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
                  const float* __restrict__ scales,
-                 const float* __restrict__ rots, const float* __restrict__ juv, const int32_t* __restrict__ radii,
-                 float* __restrict__ acc,
+                 const float* __restrict__ rots, const float* __restrict__ juv, const float* __restrict__ cov6,
+                 const int32_t* __restrict__ radii, float* __restrict__ acc,
                  float* __restrict__ d_means, float* __restrict__ d_means2D, float* __restrict__ d_shs,
                  float* __restrict__ d_op, float* __restrict__ d_scales, float* __restrict__ d_rots,
-                 float* __restrict__ d_uvs, float* __restrict__ d_coff, int accumulate) {
+                 float* __restrict__ d_uvs, float* __restrict__ d_coff, float* __restrict__ d_cov6, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K]: SH rows in, dL/dSH rows out
     const int i = blockIdx.x * K8_BLOCK + threadIdx.x;
     const int K = C.sh_coeffs;
@@ -386,16 +444,17 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
         if (!(accumulate & TEXGS_ACC_MEANS3D)) d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
         if (!(accumulate & TEXGS_ACC_MEANS2D)) d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
         if (!(accumulate & TEXGS_ACC_OPACITIES)) d_op[i] = 0.f;
-        if (!(accumulate & TEXGS_ACC_SCALES)) d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
-        if (!(accumulate & TEXGS_ACC_ROTATIONS)) d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
-        if (!(accumulate & TEXGS_ACC_UVS)) d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
+        if (d_scales && !(accumulate & TEXGS_ACC_SCALES)) d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
+        if (d_rots && !(accumulate & TEXGS_ACC_ROTATIONS)) d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
+        if (d_uvs && !(accumulate & TEXGS_ACC_UVS)) d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
+        if (d_cov6 && !(accumulate & TEXGS_ACC_COV3D)) { for (int k = 0; k < 6; ++k) d_cov6[6 * i + k] = 0.f; }
         if (d_coff && !(accumulate & TEXGS_ACC_COLOR_OFFSET)) d_coff[3 * i] = d_coff[3 * i + 1] = d_coff[3 * i + 2] = 0.f;
     }
     if (visible) {
 #define OUT(BIT, P, V) do { if (accumulate & (BIT)) (P) += (V); else (P) = (V); } while (0)
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
-    geo_forward(g, F, C, i, means, scales, rots, juv);
+    geo_forward(g, F, C, i, means, scales, rots, juv, cov6);
     // K7 left raw moment sums (common.h M_*) in this Gaussian's accumulator row; turn them into the gradients of the
     // record fields (R_* slots) here, where conic / opacity / G / g are in registers anyway, and hand the row back zeroed
     // (the scratch is all-zero between calls: no 38 MB memset per backward).
@@ -434,7 +493,7 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
 
     // (1,2) pass-through
     OUT(TEXGS_ACC_OPACITIES, d_op[i], A[R_OP]);
-    OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 0], A[R_PHI]); OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 1], A[R_PHI + 1]); OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 2], A[R_PHI + 2]);
+    if (d_uvs) { OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 0], A[R_PHI]); OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 1], A[R_PHI + 1]); OUT(TEXGS_ACC_UVS, d_uvs[3 * i + 2], A[R_PHI + 2]); }
     if (d_coff) { OUT(TEXGS_ACC_COLOR_OFFSET, d_coff[3 * i + 0], A[R_VD]); OUT(TEXGS_ACC_COLOR_OFFSET, d_coff[3 * i + 1], A[R_VD + 1]); OUT(TEXGS_ACC_COLOR_OFFSET, d_coff[3 * i + 2], A[R_VD + 2]); }
 
     // (3) conic -> cov2D (a,b,c)
@@ -568,14 +627,21 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
 #pragma unroll
     for (int k = 0; k < 3; ++k) dm[k] += dt[0] * F.V[k * 4 + 0] + dt[1] * F.V[k * 4 + 1] + dt[2] * F.V[k * 4 + 2];
     OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 0], dm[0]); OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 1], dm[1]); OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 2], dm[2]);
-    OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 0], dscale[0]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 1], dscale[1]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 2], dscale[2]);
+    if (d_cov6) {       // the given covariance: dL/dS, off-diagonal entries carrying both symmetric halves (lineage layout)
+        OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 0], dS[0]); OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 1], dS[1] + dS[3]);
+        OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 2], dS[2] + dS[6]); OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 3], dS[4]);
+        OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 4], dS[5] + dS[7]); OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 5], dS[8]);
+    }
+    if (d_scales) { OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 0], dscale[0]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 1], dscale[1]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 2], dscale[2]); }
 
     // (5) R(q) -> q
+    if (d_rots) {
     const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
     OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 0], 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]));
     OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 1], 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]));
     OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 2], 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]));
     OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 3], 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]));
+    }
 #undef OUT
     }   // visible
     if (d_shs) {            // dL/dSH: zero rows for culled Gaussians / inactive degree, then one coalesced block store
@@ -607,7 +673,7 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     uint32_t* hdr = bin_header_ptr(g, c.N, &hdr_words);
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
                        in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset,
-                       reinterpret_cast<float4*>(g->rec_test), reinterpret_cast<float4*>(g->rec_shade), g->depth, g->radii,
+                       in->cov3D_precomp, reinterpret_cast<float4*>(g->rec_test), reinterpret_cast<float4*>(g->rec_shade), g->depth, g->radii,
                        reinterpret_cast<uint2*>(g->rect),
                        g->tiles_touched, bin_block_sums_ptr(g, c.N), hdr, hdr_words);
 }
@@ -618,9 +684,9 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     const int blocks = (c.N + K8_BLOCK - 1) / K8_BLOCK;
     const size_t lds = gr->dL_dshs ? (size_t)K8_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(K8_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
-                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, g->radii, gr->acc,
-                       gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
-                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->accumulate);
+                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, in->cov3D_precomp,
+                       g->radii, gr->acc, gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
+                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->dL_dcov3D, gr->accumulate);
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

@@ -34,15 +34,18 @@ namespace {
 typedef unsigned long long ull;
 
 struct __attribute__((packed, aligned(4))) Texel3 { float x, y, z; };   // one global_load_dwordx3 per tap
-__device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, int off) {
-    return *reinterpret_cast<const Texel3*>(tex + off);
+// `boff` = BYTE offset into the texture (< 2^32: abi.hip rejects tex_res > 7168): base in SGPRs + a zero-extended 32-bit lane
+// offset is the `global_load v, v_off, s[base]` form -- no 64-bit address arithmetic per tap
+__device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, uint32_t boff) {
+    return *reinterpret_cast<const Texel3*>(reinterpret_cast<const char*>(tex) + boff);
 }
 
 // Cubemap address of direction u (not necessarily unit): face (+x,-x,+y,-y,+z,-z; NVDIFFREC/util.py:94-101
 // inverted), bilinear taps with clamp-to-edge inside the face, texel centres at (i+0.5)/R.
 struct CubeTap {
-    int   o00, o01, o10, o11;   // float offsets of the 4 taps' first channel
-    int   x0, x1, y0, y1;       // clamped tap coordinates inside the face
+    uint32_t o00, dox, doy;     // BYTE offset of tap 00's first channel; o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
+                                // (dox = 12 or 0, doy = 12 R or 0: 0 when the footprint is clamped at the face border)
+    int   x0, y0;               // clamped coordinates of tap 00 inside the face
     float fx, fy;
     // for the backward: sc/tc numerators, 0.5*R/ma, axis bookkeeping
     float sc, tc, h, rma, sm, su, sv;
@@ -69,10 +72,12 @@ __device__ __forceinline__ CubeTap cube_address(float u0, float u1, float u2, in
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int x0c = min(max(x0, 0), R - 1), x1c = min(max(x0 + 1, 0), R - 1);
     const int y0c = min(max(y0, 0), R - 1), y1c = min(max(y0 + 1, 0), R - 1);
-    t.x0 = x0c; t.x1 = x1c; t.y0 = y0c; t.y1 = y1c;
-    const int fb = t.face * R;
-    t.o00 = ((fb + y0c) * R + x0c) * 3; t.o01 = ((fb + y0c) * R + x1c) * 3;
-    t.o10 = ((fb + y1c) * R + x0c) * 3; t.o11 = ((fb + y1c) * R + x1c) * 3;
+    t.x0 = x0c; t.y0 = y0c;
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): face * R + y < 6 R < 2^24, R < 2^24
+    const uint32_t texel = __umul24((uint32_t)(t.face * R + y0c), (uint32_t)R) + (uint32_t)x0c;
+    t.o00 = (texel * 3u) << 2;
+    t.dox = (x1c != x0c) ? 12u : 0u;
+    t.doy = (y1c != y0c) ? 12u * (uint32_t)R : 0u;
     return t;
 }
 
@@ -149,7 +154,7 @@ __device__ __forceinline__ int mbcnt64(ull m) {
 // Texture bin (32x32-texel block) of a bilinear footprint, and whether the footprint is binned at all (not clamped at a face
 // border: such footprints go straight to dL_dtexture).  K6 counts with this, K7 appends with this: same inputs, same answer.
 __device__ __forceinline__ uint32_t tap_bin(const CubeTap& ct, int nb) { return (uint32_t)((ct.face * nb + (ct.y0 >> 5)) * nb + (ct.x0 >> 5)); }
-__device__ __forceinline__ bool tap_binned(const CubeTap& ct) { return ct.x1 == ct.x0 + 1 && ct.y1 == ct.y0 + 1; }
+__device__ __forceinline__ bool tap_binned(const CubeTap& ct) { return ct.dox != 0u && ct.doy != 0u; }
 
 // ---- per-wave LDS layout shared by K6 and K7 ----
 #define TG_RING 128          // survivor queue (raw list positions), power of two >= 127
@@ -215,6 +220,9 @@ struct __attribute__((aligned(16))) FwdLds {
     uint32_t cbin[8], ccnt[8];          //   64: footprint-count cache (a block's footprints fall into a handful of texture bins)
 };                                      // 10160 B -> 16 waves per CU
 
+// TAPS = false: the untextured surface (TexGSInputs.texture == NULL; render/render.py:75-84 through `diff_gauss`): the colour of a
+// pair is max(0, viewdep + 0.5), no UV step, no cubemap address, no taps.
+template <bool TAPS>
 __global__ void __launch_bounds__(64, 4)
 k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_norm,
              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -259,11 +267,14 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     Texel3 p00 = {0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
     auto finish = [&]() {
         if (lane < pn) {
-            const float w00 = (1.f - p_fx) * (1.f - p_fy), w01 = p_fx * (1.f - p_fy);
-            const float w10 = (1.f - p_fx) * p_fy,         w11 = p_fx * p_fy;
-            const float t0 = w00 * p00.x + w01 * p01.x + w10 * p10.x + w11 * p11.x;
-            const float t1 = w00 * p00.y + w01 * p01.y + w10 * p10.y + w11 * p11.y;
-            const float t2 = w00 * p00.z + w01 * p01.z + w10 * p10.z + w11 * p11.z;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            if constexpr (TAPS) {
+                const float w00 = (1.f - p_fx) * (1.f - p_fy), w01 = p_fx * (1.f - p_fy);
+                const float w10 = (1.f - p_fx) * p_fy,         w11 = p_fx * p_fy;
+                t0 = w00 * p00.x + w01 * p01.x + w10 * p10.x + w11 * p11.x;
+                t1 = w00 * p00.y + w01 * p01.y + w10 * p10.y + w11 * p11.y;
+                t2 = w00 * p00.z + w01 * p01.z + w10 * p10.z + w11 * p11.z;
+            }
             // w * colour (>= 0) goes to the owning pixel's accumulator as Q32.32 fixed point with an INTEGER LDS atomic:
             // ds_add_f32 retires ~3 cycles per LANE on gfx950 (193 cycles per wave instruction, scripts/ubench/lds_atomics.hip),
             // ds_add_u64 6 cycles per instruction.  2^-32 resolution (45 items: < 1e-8), exact and order-independent below 2^31.
@@ -279,48 +290,52 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         uint2 e_ = make_uint2(0u, 0u);
         if (lane < n_) e_ = L.q[(qhead + lane) & (FQ_CAP - 1)];
         const int jj_ = KEY_J(e_.y);
-        const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj_]);
-        const float4 d_ = L.p.D[jj_], e4 = L.p.E[jj_], f_ = L.p.F[jj_];
+        const float4 f_ = L.p.F[jj_];
         const float2 g2 = L.p.G[jj_];
-        const float dpx = (float)(wave_px + KEY_OX(e_.y)) - xy.x, dpy = (float)(wave_py + KEY_OY(e_.y)) - xy.y;
-        const float den = 1.0f + d_.x * dpx + d_.y * dpy;
-        const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-        const float u0 = f_.x + (d_.z * dpx + d_.w * dpy) * inv;
-        const float u1 = f_.y + (e4.x * dpx + e4.y * dpy) * inv;
-        const float u2 = f_.z + (e4.z * dpx + e4.w * dpy) * inv;
-        const CubeTap ct = cube_address(u0, u1, u2, a.R);
-        if (lane < n_) {
-            p00 = load_texel(tex, ct.o00); p01 = load_texel(tex, ct.o01);
-            p10 = load_texel(tex, ct.o10); p11 = load_texel(tex, ct.o11);
-        }
-        if (bin_count != nullptr) {
-            // a backward will follow: count this round's footprints per texture bin (sizes of K7's record lists) in a small
-            // per-wave LDS cache (8 entries, hashed by bin; a block's footprints fall into a handful of bins), flushed with one
-            // global atomic per entry on a conflict and at the end: global atomics execute memory-side (one per (round, bin) =
-            // 700 k per view cost 80 us).  Hit: ONE integer LDS atomic per lane, no grouping.  Miss (first touch of a bin, or
-            // a hash conflict): the lanes are grouped by bin with ballots and the group leader replaces the entry.
-            const bool binned = (lane < n_) && tap_binned(ct);
-            const uint32_t bin = tap_bin(ct, nbins_row);
-            const uint32_t ce = (bin ^ (bin >> 5)) & 7u;
-            const bool hit = binned && L.cbin[ce] == bin;
-            if (hit) atomicAdd(&L.ccnt[ce], 1u);
-            ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
-            while (pend != 0ull) {
-                const int l0 = __ffsll((long long)pend) - 1;
-                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
-                const ull m = pend & TG_BALLOT(bin == b0);
-                if (lane == l0) {
-                    const uint32_t n = (uint32_t)__popcll(m), ob = L.cbin[ce];
-                    if (ob == b0) L.ccnt[ce] += n;            // (installed by an earlier group of this round? cannot be: one group per bin)
-                    else {
-                        if (ob != 0xFFFFFFFFu) atomicAdd(bin_count + ob, L.ccnt[ce]);
-                        L.cbin[ce] = b0; L.ccnt[ce] = n;
+        if constexpr (TAPS) {
+            const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj_]);
+            const float4 d_ = L.p.D[jj_], e4 = L.p.E[jj_];
+            const float dpx = (float)(wave_px + KEY_OX(e_.y)) - xy.x, dpy = (float)(wave_py + KEY_OY(e_.y)) - xy.y;
+            const float den = 1.0f + d_.x * dpx + d_.y * dpy;
+            const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+            const float u0 = f_.x + (d_.z * dpx + d_.w * dpy) * inv;
+            const float u1 = f_.y + (e4.x * dpx + e4.y * dpy) * inv;
+            const float u2 = f_.z + (e4.z * dpx + e4.w * dpy) * inv;
+            const CubeTap ct = cube_address(u0, u1, u2, a.R);
+            // every lane loads: a lane without an item decoded entry (0, 0) -> survivor slot 0 of the chunk (a real record or
+            // zeros), whose address is as valid as any (clamped coordinates); predicating the loads cost 12 register clears
+            p00 = load_texel(tex, ct.o00); p01 = load_texel(tex, ct.o00 + ct.dox);
+            p10 = load_texel(tex, ct.o00 + ct.doy); p11 = load_texel(tex, ct.o00 + ct.doy + ct.dox);
+            p_fx = ct.fx; p_fy = ct.fy;
+            if (bin_count != nullptr) {
+                // a backward will follow: count this round's footprints per texture bin (sizes of K7's record lists) in a small
+                // per-wave LDS cache (8 entries, hashed by bin; a block's footprints fall into a handful of bins), flushed with one
+                // global atomic per entry on a conflict and at the end: global atomics execute memory-side (one per (round, bin) =
+                // 700 k per view cost 80 us).  Hit: ONE integer LDS atomic per lane, no grouping.  Miss (first touch of a bin, or
+                // a hash conflict): the lanes are grouped by bin with ballots and the group leader replaces the entry.
+                const bool binned = (lane < n_) && tap_binned(ct);
+                const uint32_t bin = tap_bin(ct, nbins_row);
+                const uint32_t ce = (bin ^ (bin >> 5)) & 7u;
+                const bool hit = binned && L.cbin[ce] == bin;
+                if (hit) atomicAdd(&L.ccnt[ce], 1u);
+                ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
+                while (pend != 0ull) {
+                    const int l0 = __ffsll((long long)pend) - 1;
+                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
+                    const ull m = pend & TG_BALLOT(bin == b0);
+                    if (lane == l0) {
+                        const uint32_t n = (uint32_t)__popcll(m), ob = L.cbin[ce];
+                        if (ob == b0) L.ccnt[ce] += n;            // (installed by an earlier group of this round? cannot be: one group per bin)
+                        else {
+                            if (ob != 0xFFFFFFFFu) atomicAdd(bin_count + ob, L.ccnt[ce]);
+                            L.cbin[ce] = b0; L.ccnt[ce] = n;
+                        }
                     }
+                    pend &= ~m;
                 }
-                pend &= ~m;
             }
         }
-        p_w = __uint_as_float(e_.x); p_pl = KEY_PL(e_.y); p_fx = ct.fx; p_fy = ct.fy; p_vd0 = f_.w; p_vd1 = g2.x; p_vd2 = g2.y;
+        p_w = __uint_as_float(e_.x); p_pl = KEY_PL(e_.y); p_vd0 = f_.w; p_vd1 = g2.x; p_vd2 = g2.y;
         pn = n_;
     };
 
@@ -446,7 +461,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     }
     finish();
     __builtin_amdgcn_wave_barrier();
-    if (bin_count != nullptr && lane < 8 && L.cbin[lane] != 0xFFFFFFFFu) atomicAdd(bin_count + L.cbin[lane], L.ccnt[lane]);
+    if (TAPS && bin_count != nullptr && lane < 8 && L.cbin[lane] != 0xFFFFFFFFu) atomicAdd(bin_count + L.cbin[lane], L.ccnt[lane]);
     if (a.surv_cnt != nullptr && lane == 0) a.surv_cnt[4 * tile + wave] = (uint32_t)nsurv;
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
@@ -480,10 +495,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 #define BQ_CAP 128
 #endif
 #define BWD_MAX_IT 16
-#define TB_LIST_MAX (1u << 20)      // records per list the reduce kernel's fixed point can take; the rest of a longer list goes through atomics
 struct TexBinArgs {
     float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
-    uint32_t* cursor;      // [nbins] records appended so far to each list
+    uint32_t* cursor;      // [nbins] next free record of each list, ABSOLUTE (k_bin_offsets sets it to base[b] before every K7)
     const uint32_t* base;  // [nbins + 1] exclusive scan of K6's per-bin counts
     uint32_t* stats;       // [0] max records a call wanted (for the host), [1] bits of max |dL/dpixel colour| of this call
     uint32_t  cap;         // records the buffer holds; what does not fit goes to dL_dtexture directly
@@ -499,20 +513,38 @@ struct __attribute__((aligned(16))) BwdLds {
     uint8_t list[4][64];                //  256
 };                                      // 15520 B -> 10 waves per CU
 
-// footprints that cannot be binned (clamped at a face border, beyond the list / the buffer): straight into dL_dtexture
-__device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, int o00, int o01, int o10, int o11, float w00, float w01,
-                                               float w10, float w11, float x0, float x1, float x2) {
-    unsafeAtomicAdd(dtex + o00, w00 * x0); unsafeAtomicAdd(dtex + o00 + 1, w00 * x1); unsafeAtomicAdd(dtex + o00 + 2, w00 * x2);
-    unsafeAtomicAdd(dtex + o01, w01 * x0); unsafeAtomicAdd(dtex + o01 + 1, w01 * x1); unsafeAtomicAdd(dtex + o01 + 2, w01 * x2);
-    unsafeAtomicAdd(dtex + o10, w10 * x0); unsafeAtomicAdd(dtex + o10 + 1, w10 * x1); unsafeAtomicAdd(dtex + o10 + 2, w10 * x2);
-    unsafeAtomicAdd(dtex + o11, w11 * x0); unsafeAtomicAdd(dtex + o11 + 1, w11 * x1); unsafeAtomicAdd(dtex + o11 + 2, w11 * x2);
+// footprints that cannot be binned (clamped at a face border, beyond the buffer): straight into dL_dtexture.  Offsets in BYTES.
+__device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_t o00, uint32_t dox, uint32_t doy, float fx, float fy,
+                                               float x0, float x1, float x2) {
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    float* p00 = dtex + (o00 >> 2);
+    float* p01 = dtex + ((o00 + dox) >> 2);
+    float* p10 = dtex + ((o00 + doy) >> 2);
+    float* p11 = dtex + ((o00 + doy + dox) >> 2);
+    unsafeAtomicAdd(p00, w00 * x0); unsafeAtomicAdd(p00 + 1, w00 * x1); unsafeAtomicAdd(p00 + 2, w00 * x2);
+    unsafeAtomicAdd(p01, w01 * x0); unsafeAtomicAdd(p01 + 1, w01 * x1); unsafeAtomicAdd(p01 + 2, w01 * x2);
+    unsafeAtomicAdd(p10, w10 * x0); unsafeAtomicAdd(p10 + 1, w10 * x1); unsafeAtomicAdd(p10 + 2, w10 * x2);
+    unsafeAtomicAdd(p11, w11 * x0); unsafeAtomicAdd(p11 + 1, w11 * x1); unsafeAtomicAdd(p11 + 2, w11 * x2);
 }
 
+// live accumulator-row slots (common.h M_*) of the two C2 flavours: all 28 moments / without the UV chain (M_DEN, M_DN, M_PHI)
+#define TG_MOMENTS_ALL  0x0FFFFFFFu
+#define TG_MOMENTS_NOUV (0x3Fu | (0x7Fu << 21))
+
+// What a caller wants decides what is compiled in (TexGSGrads.want, texgs.h):
+//   TEX   the texture gradient (records / atomics).              false: frozen texture, or the untextured surface
+//   GEO   the per-Gaussian moments (stages C1, C2, K8 after it).  false: only the texture is trained (every Gaussian input frozen)
+//   UVG   the UV chain (dL/duv, dL/dden -> M_DEN, M_DN, M_PHI).   false: nothing upstream of uv wants a gradient, or no texture
+//   TAPS  the texture is sampled at all.                          false: untextured surface (texture == NULL)
+template <bool TEX, bool GEO, bool UVG, bool TAPS>
 __global__ void __launch_bounds__(64, 2)
 k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
              float* __restrict__ acc, float* __restrict__ dtex) {
+    static_assert(TAPS || (!TEX && !UVG), "no texture: no texture gradient and no UV chain");
+    static_assert(GEO || !UVG, "the UV chain ends in the per-Gaussian moments");
+    static_assert(TEX || GEO, "nothing to compute");
     __shared__ BwdLds L;
     const int lane = (int)threadIdx.x;
     int tile, wave;
@@ -545,11 +577,13 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     L.dpix[lane] = make_float4(dpix[0], dpix[1], dpix[2], dpix[7]);
     L.dgeo[lane] = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
     init_dummy(L.p, lane);
-    if (tb.rec != nullptr) {
+    if (TEX && tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale of THIS
-        // call (k_bin_offsets, launched just before this kernel, cleared the word).  Positive floats order like their bit patterns; the plain read first
-        // keeps 10^4 waves off one hot word.
-        const int mbits = wave_max_i(__float_as_int(fmaxf(fabsf(dpix[0]), fmaxf(fabsf(dpix[1]), fabsf(dpix[2])))));
+        // call (k_bin_offsets, launched just before this kernel, cleared the word).  Non-negative floats order like their bit
+        // patterns, and so do +inf (0x7F800000) and NaN (above it): an INTEGER maximum carries a non-finite upstream gradient to the
+        // reduce, which then adds the records with float atomics instead of fixed point (fmaxf would have dropped the NaN).  The
+        // plain read first keeps 10^4 waves off one hot word.
+        const int mbits = wave_max_i(max(max(__float_as_int(fabsf(dpix[0])), __float_as_int(fabsf(dpix[1]))), __float_as_int(fabsf(dpix[2]))));
         if (lane == 0 && (uint32_t)mbits > __hip_atomic_load(tb.stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(tb.stats + 1, (uint32_t)mbits);
     }
@@ -569,7 +603,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     // The survivors of this block's cull come from K6 (it culled exactly this list, at least as far as the last contributor):
     // chunks of 64 from the back, lane = survivor in descending list position.  The next chunk's entries are loaded one chunk ahead.
     const size_t sbase = 4 * (size_t)range.x + (size_t)wave * (size_t)todo;
-    const int ns = (int)a.surv_cnt[4 * tile + wave];
+    const int ns = min((int)a.surv_cnt[4 * tile + wave], todo);      // (a count beyond the block's region can only be a stale buffer)
     uint2 nsv = make_uint2(0u, 0xFFFFFFFFu);
     uint32_t nqm = 0u;
     if (ns - 1 - lane >= 0) { nsv = a.surv[sbase + (ns - 1 - lane)]; nqm = a.surv_qm[sbase + (ns - 1 - lane)]; }
@@ -580,9 +614,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     struct Round {                                        // what the back half needs, as few registers as possible
         bool have, binned;
         int e, pl, jj, my_leader, my_rank, axis;
-        uint32_t bin, slot0, b0, b1;                      // list slot of the group's first record; [b0, b1) = the bin's list
+        uint32_t slot0, b1;                               // absolute slot of the group's first record; end of the bin's list
         uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
-        int o00, dox, doy;                                // tap offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
+        uint32_t o00, dox, doy;                           // tap byte offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
         float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
         float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
         Texel3 t00, t01, t10, t11;
@@ -596,101 +630,120 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         R.pl = KEY_PL(key);
         const int jj = KEY_J(key);
         R.jj = jj;
-        const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj]);
-        const float4 d_ = L.p.D[jj], e4 = L.p.E[jj], f_ = L.p.F[jj];
+        const float4 f_ = L.p.F[jj];
         const float2 g2 = L.p.G[jj];
         R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
         R.vd0 = f_.w; R.vd1 = g2.x; R.vd2 = g2.y;
-        // UV Taylor step, cubemap address, tap loads
-        const float dpx = (float)(wave_px + KEY_OX(key)) - xy.x, dpy = (float)(wave_py + KEY_OY(key)) - xy.y;
-        const float den = 1.0f + d_.x * dpx + d_.y * dpy;
-        R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
-        R.nu0 = d_.z * dpx + d_.w * dpy; R.nu1 = e4.x * dpx + e4.y * dpy; R.nu2 = e4.z * dpx + e4.w * dpy;
-        const CubeTap ct = cube_address(f_.x + R.nu0 * R.inv, f_.y + R.nu1 * R.inv, f_.z + R.nu2 * R.inv, a.R);
-        const Texel3 tz = {0.f, 0.f, 0.f};
-        R.t00 = tz; R.t01 = tz; R.t10 = tz; R.t11 = tz;
-        if (R.have) {
-            R.t00 = load_texel(tex, ct.o00); R.t01 = load_texel(tex, ct.o01);
-            R.t10 = load_texel(tex, ct.o10); R.t11 = load_texel(tex, ct.o11);
-        }
-        R.axis = ct.axis; R.fx = ct.fx; R.fy = ct.fy;
-        R.ka = ct.su * ct.h; R.kb = ct.sv * ct.h;
-        const float km = ct.h * ct.rma * ct.sm;
-        R.kc = ct.sc * km; R.kd = ct.tc * km;
-        R.o00 = ct.o00; R.dox = ct.o01 - ct.o00; R.doy = ct.o10 - ct.o00;
-        // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
-        R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
-        R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
-        // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
-        // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
-        R.binned = R.have && tb.rec != nullptr && tap_binned(ct);
-        R.bin = tap_bin(ct, tb.nb);
-        bool leader = false;
-        R.my_leader = lane; R.my_rank = 0;
-        int my_n = 0;
-        ull pend = TG_BALLOT(R.binned);
-        while (pend != 0ull) {
-            const int l0 = __ffsll((long long)pend) - 1;
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)R.bin, l0);
-            const ull m = TG_BALLOT(R.binned && R.bin == b0);
-            if ((m >> lane) & 1ull) {
-                R.my_leader = l0;
-                R.my_rank = mbcnt64(m);
-                if (lane == l0) { leader = true; my_n = __popcll(m); }
+        R.binned = false;
+        if constexpr (TAPS) {
+            // UV Taylor step, cubemap address, tap loads
+            const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj]);
+            const float4 d_ = L.p.D[jj], e4 = L.p.E[jj];
+            const float dpx = (float)(wave_px + KEY_OX(key)) - xy.x, dpy = (float)(wave_py + KEY_OY(key)) - xy.y;
+            const float den = 1.0f + d_.x * dpx + d_.y * dpy;
+            R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
+            R.nu0 = d_.z * dpx + d_.w * dpy; R.nu1 = e4.x * dpx + e4.y * dpy; R.nu2 = e4.z * dpx + e4.w * dpy;
+            const CubeTap ct = cube_address(f_.x + R.nu0 * R.inv, f_.y + R.nu1 * R.inv, f_.z + R.nu2 * R.inv, a.R);
+            // every lane loads (a lane without an item decoded key 0 -> survivor slot 0, pixel (0, 0) of the block: a valid address)
+            R.t00 = load_texel(tex, ct.o00); R.t01 = load_texel(tex, ct.o00 + ct.dox);
+            R.t10 = load_texel(tex, ct.o00 + ct.doy); R.t11 = load_texel(tex, ct.o00 + ct.doy + ct.dox);
+            R.fx = ct.fx; R.fy = ct.fy;
+            if constexpr (UVG) {
+                R.axis = ct.axis;
+                R.ka = ct.su * ct.h; R.kb = ct.sv * ct.h;
+                const float km = ct.h * ct.rma * ct.sm;
+                R.kc = ct.sc * km; R.kd = ct.tc * km;
             }
-            pend &= ~m;
+            if constexpr (TEX) {
+                R.o00 = ct.o00; R.dox = ct.dox; R.doy = ct.doy;
+                // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
+                R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
+                R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
+                // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
+                // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
+                R.binned = R.have && tb.rec != nullptr && tap_binned(ct);
+                const uint32_t bin = tap_bin(ct, tb.nb);
+                bool leader = false;
+                R.my_leader = lane; R.my_rank = 0;
+                int my_n = 0;
+                ull pend = TG_BALLOT(R.binned);
+                while (pend != 0ull) {
+                    const int l0 = __ffsll((long long)pend) - 1;
+                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
+                    const ull m = TG_BALLOT(R.binned && bin == b0);
+                    if ((m >> lane) & 1ull) {
+                        R.my_leader = l0;
+                        R.my_rank = mbcnt64(m);
+                        if (lane == l0) { leader = true; my_n = __popcll(m); }
+                    }
+                    pend &= ~m;
+                }
+                R.slot0 = 0u; R.b1 = 0u;
+                if (leader) R.slot0 = atomicAdd(tb.cursor + bin, (uint32_t)my_n);
+                if (R.binned) R.b1 = tb.base[bin + 1u];
+            }
         }
-        R.slot0 = 0u; R.b0 = 0u; R.b1 = 0u;
-        if (leader) R.slot0 = atomicAdd(tb.cursor + R.bin, (uint32_t)my_n);
-        if (R.binned) { R.b0 = tb.base[R.bin]; R.b1 = tb.base[R.bin + 1u]; }
     };
     auto back = [&](Round& R) {
-        const Texel3 &t00 = R.t00, &t01 = R.t01, &t10 = R.t10, &t11 = R.t11;
-        const float w00 = (1.f - R.fx) * (1.f - R.fy), w01 = R.fx * (1.f - R.fy);
-        const float w10 = (1.f - R.fx) * R.fy,         w11 = R.fx * R.fy;
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (R.have) {
             const float w = R.w;
             const float4 dp = L.dpix[R.pl];
             const float d0 = dp.x, d1 = dp.y, d2 = dp.z;
-            const float pre0 = TG_SH_C0 * (w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x) + R.vd0 + 0.5f;
-            const float pre1 = TG_SH_C0 * (w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y) + R.vd1 + 0.5f;
-            const float pre2 = TG_SH_C0 * (w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z) + R.vd2 + 0.5f;
-            const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
+            // bilinear sample and its two derivatives in the nested form c = t00 + fx e + fy b, e = a + fy d = dc/dfx,
+            // f = b + fx d = dc/dfy with a = t01 - t00, b = t10 - t00, d = (t11 - t10) - a: 8 operations per channel for all
+            // three (the weighted-sum form took 17)
+            float tv0 = 0.f, tv1 = 0.f, tv2 = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+            if constexpr (TAPS) {
+                const float a0 = R.t01.x - R.t00.x, b0 = R.t10.x - R.t00.x, q0 = (R.t11.x - R.t10.x) - a0;
+                const float a1 = R.t01.y - R.t00.y, b1 = R.t10.y - R.t00.y, q1 = (R.t11.y - R.t10.y) - a1;
+                const float a2 = R.t01.z - R.t00.z, b2 = R.t10.z - R.t00.z, q2 = (R.t11.z - R.t10.z) - a2;
+                e0 = __fmaf_rn(R.fy, q0, a0); e1 = __fmaf_rn(R.fy, q1, a1); e2 = __fmaf_rn(R.fy, q2, a2);
+                f0 = __fmaf_rn(R.fx, q0, b0); f1 = __fmaf_rn(R.fx, q1, b1); f2 = __fmaf_rn(R.fx, q2, b2);
+                tv0 = __fmaf_rn(R.fy, b0, __fmaf_rn(R.fx, e0, R.t00.x));
+                tv1 = __fmaf_rn(R.fy, b1, __fmaf_rn(R.fx, e1, R.t00.y));
+                tv2 = __fmaf_rn(R.fy, b2, __fmaf_rn(R.fx, e2, R.t00.z));
+            }
+            const float pre0 = TG_SH_C0 * tv0 + R.vd0 + 0.5f;
+            const float pre1 = TG_SH_C0 * tv1 + R.vd1 + 0.5f;
+            const float pre2 = TG_SH_C0 * tv2 + R.vd2 + 0.5f;
             // colour -> view-dependent term and texture
             const float dc0 = (pre0 > 0.f) ? w * d0 : 0.f, dc1 = (pre1 > 0.f) ? w * d1 : 0.f, dc2 = (pre2 > 0.f) ? w * d2 : 0.f;
             x0 = TG_SH_C0 * dc0; x1 = TG_SH_C0 * dc1; x2 = TG_SH_C0 * dc2;
-            const float dLdcol = x0 * ((1.f - R.fy) * (t01.x - t00.x) + R.fy * (t11.x - t10.x))
-                               + x1 * ((1.f - R.fy) * (t01.y - t00.y) + R.fy * (t11.y - t10.y))
-                               + x2 * ((1.f - R.fy) * (t01.z - t00.z) + R.fy * (t11.z - t10.z));
-            const float dLdrow = x0 * ((1.f - R.fx) * (t10.x - t00.x) + R.fx * (t11.x - t01.x))
-                               + x1 * ((1.f - R.fx) * (t10.y - t00.y) + R.fx * (t11.y - t01.y))
-                               + x2 * ((1.f - R.fx) * (t10.z - t00.z) + R.fx * (t11.z - t01.z));
-            const float dua = dLdcol * R.ka, dub = dLdrow * R.kb;
-            const float dum = -(dLdcol * R.kc + dLdrow * R.kd);
-            float du0, du1, du2;
-            if (R.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
-            else if (R.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
-            else                  { du2 = dum; du0 = dua; du1 = dub; }
-            const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
-            // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
-            // recurrence needs from this pair, formed here where all 64 lanes work
-            const float4 c5 = L.p.C[R.jj];
-            const float4 dg = L.dgeo[R.pl];
-            L.items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
-            L.items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
-            L.items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
+            if constexpr (GEO) {
+                const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
+                // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
+                // recurrence needs from this pair, formed here where all 64 lanes work
+                const float4 c5 = L.p.C[R.jj];
+                const float4 dg = L.dgeo[R.pl];
+                L.items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
+                float du0 = 0.f;
+                if constexpr (UVG) {
+                    const float dLdcol = x0 * e0 + x1 * e1 + x2 * e2;
+                    const float dLdrow = x0 * f0 + x1 * f1 + x2 * f2;
+                    const float dua = dLdcol * R.ka, dub = dLdrow * R.kb;
+                    const float dum = -(dLdcol * R.kc + dLdrow * R.kd);
+                    float du1, du2;
+                    if (R.axis == 0)      { du0 = dum; du2 = dua; du1 = dub; }
+                    else if (R.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
+                    else                  { du2 = dum; du0 = dua; du1 = dub; }
+                    const float dden = -(du0 * R.nu0 + du1 * R.nu1 + du2 * R.nu2) * R.inv * R.inv;   // inv = 0 when den < DEN_MIN
+                    L.items[R.e * 3 + 2] = make_float4(du1, du2, R.inv, dden);
+                }
+                L.items[R.e * 3 + 1] = make_float4(dc0, dc1, dc2, du0);
+            }
         }
-        // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
-        // a face border / does not fit its list or the buffer (still correct, just slow)
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0) + (uint32_t)R.my_rank;
-        const uint32_t pos = R.b0 + slot;
-        if (R.binned && slot < TB_LIST_MAX && pos < R.b1 && pos < tb.cap) {
-            float* __restrict__ rp = tb.rec + pos;
-            rp[0] = __uint_as_float(R.fxw); rp[tb.cap] = __uint_as_float(R.fyw);
-            rp[2 * (size_t)tb.cap] = x0; rp[3 * (size_t)tb.cap] = x1; rp[4 * (size_t)tb.cap] = x2;
-        } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
-            scatter_direct(dtex, R.o00, R.o00 + R.dox, R.o00 + R.doy, R.o00 + R.dox + R.doy, w00, w01, w10, w11, x0, x1, x2);
+        if constexpr (TEX) {
+            // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
+            // a face border / does not fit the buffer (still correct, just slow)
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0) + (uint32_t)R.my_rank;
+            if (R.binned && pos < R.b1 && pos < tb.cap) {
+                float* __restrict__ rp = tb.rec + pos;
+                rp[0] = __uint_as_float(R.fxw); rp[tb.cap] = __uint_as_float(R.fyw);
+                rp[2 * (size_t)tb.cap] = x0; rp[3 * (size_t)tb.cap] = x1; rp[4 * (size_t)tb.cap] = x2;
+            } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
+                scatter_direct(dtex, R.o00, R.dox, R.doy, R.fx, R.fy, x0, x1, x2);
+            }
         }
     };
     for (int hi = ns; hi > 0; hi -= 64) {
@@ -762,6 +815,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 if (n_items > 64) back(R1);
             }
             __builtin_amdgcn_wave_barrier();
+            if constexpr (GEO) {
             // ================================================================ stage C1: per-pixel recurrence, iteration by iteration
             // dL/dalpha_i = T_i s_i - (B_i + T_final bg . dL/dcolour) / (1 - alpha_i),  B_i = sum over the contributors k BEHIND i
             // of s_k alpha_k T_k: one running sum per pixel (`behind`), back to front.  s_i (colour . dL/dcolour + geometry
@@ -820,34 +874,38 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     float part[32];
                     const float2 gxy = *reinterpret_cast<const float2*>(&L.p.A[jt]);
                     {
-                        const float4 i0 = L.items[item * 3], i1 = L.items[item * 3 + 1], i2 = L.items[item * 3 + 2];
+                        const float4 i0 = L.items[item * 3], i1 = L.items[item * 3 + 1];
                         const uint32_t key = __float_as_uint(i0.w);
                         const int pl = KEY_PL(key);
                         const float w = i0.x, P = i0.y;
                         const float dx = gxy.x - (float)(wave_px + KEY_OX(key)), dy = gxy.y - (float)(wave_py + KEY_OY(key));   // xy - pixel
                         // RAW MOMENTS about the splat centre (TexGSGrads.acc layout, texgs.h); K8, which has conic / opacity /
                         // G / g in registers anyway, turns them into dL/d(xy, conic, opacity, G, g, ...)
-                        const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
-                        const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
-                        const float dpx = -dx, dpy = -dy;                       // pixel - xy
                         const float Pdx = P * dx, Pdy = P * dy;
                         const float4 dg = L.dgeo[pl];
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) part[k] = 0.f;
                         part[M_P] = P; part[M_P + 1] = Pdx; part[M_P + 2] = Pdy;
                         part[M_P + 3] = Pdx * dx; part[M_P + 4] = Pdx * dy; part[M_P + 5] = Pdy * dy;
-                        part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
-                        part[M_DN + 0] = dn0; part[M_DN + 1] = dn0 * dpx; part[M_DN + 2] = dn0 * dpy;
-                        part[M_DN + 3] = dn1; part[M_DN + 4] = dn1 * dpx; part[M_DN + 5] = dn1 * dpy;
-                        part[M_DN + 6] = dn2; part[M_DN + 7] = dn2 * dpx; part[M_DN + 8] = dn2 * dpy;
-                        part[M_PHI] = du0; part[M_PHI + 1] = du1; part[M_PHI + 2] = du2;
+                        if constexpr (UVG) {
+                            const float4 i2 = L.items[item * 3 + 2];
+                            const float du0 = i1.w, du1 = i2.x, du2 = i2.y, inv = i2.z, dden = i2.w;
+                            const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
+                            const float dpx = -dx, dpy = -dy;                       // pixel - xy
+                            part[M_DEN] = dden; part[M_DEN + 1] = dden * dpx; part[M_DEN + 2] = dden * dpy;
+                            part[M_DN + 0] = dn0; part[M_DN + 1] = dn0 * dpx; part[M_DN + 2] = dn0 * dpy;
+                            part[M_DN + 3] = dn1; part[M_DN + 4] = dn1 * dpx; part[M_DN + 5] = dn1 * dpy;
+                            part[M_DN + 6] = dn2; part[M_DN + 7] = dn2 * dpx; part[M_DN + 8] = dn2 * dpy;
+                            part[M_PHI] = du0; part[M_PHI + 1] = du1; part[M_PHI + 2] = du2;
+                        }
                         part[M_VD] = i1.x; part[M_VD + 1] = i1.y; part[M_VD + 2] = i1.z;
                         part[M_DEPTH] = w * dg.x;
                         part[M_N] = w * dg.y; part[M_N + 1] = w * dg.z; part[M_N + 2] = w * dg.w;
-#pragma unroll
-                        for (int k = M_N + 3; k < 32; ++k) part[k] = 0.f;
                     }
                     float lo, hi;
-                    static_assert(M_N + 3 == 28, "the butterfly below skips slots 28..31");
-                    reduce32_rows16<28>(part, lane, lo, hi);      // 28 moments (common.h M_*); lane holds slots transposed_index(lane & 15) and 16 + that
+                    static_assert(M_N + 3 == 28, "the live-slot masks above cover slots 0..27");
+                    // lane holds slots transposed_index(lane & 15) and 16 + that
+                    reduce32_rows16_masked<UVG ? TG_MOMENTS_ALL : TG_MOMENTS_NOUV>(part, lane, lo, hi);
                     if (live) {
                         float* row = acc + (size_t)gid * TEXGS_ACC_FLOATS + transposed_index(sub);
                         if (lo != 0.f) unsafeAtomicAdd(row, lo);
@@ -856,14 +914,17 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            }   // GEO
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ texture-gradient lists
-// Exclusive scan of K6's per-bin footprint counts -> list offsets (one workgroup; nbins = 6144 at R = 1024).
+// Exclusive scan of K6's per-bin footprint counts -> list offsets and the lists' fill cursors (absolute: K7's returning atomic on a
+// cursor IS the record's position) (one workgroup; nbins = 6144 at R = 1024).
 __global__ void __launch_bounds__(1024)
-k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ stats) {
+k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ cursor,
+              uint32_t* __restrict__ stats) {
     // one pass: thread t owns the `per` consecutive counts [t * per, (t + 1) * per) -- serial inside the thread, one wave scan,
     // one cross-wave step (6 144 bins at R = 1024: 6 per thread).  Chunks of 1 024 x BO_MAX bins if there are more.
     constexpr int BO_MAX = 32;
@@ -888,7 +949,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
         uint32_t run = s_carry + incl - sum;
         for (int w = 0; w < wv; ++w) run += s_w[w];
 #pragma unroll
-        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) base[i0 + k] = run; run += v[k]; }
+        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) { base[i0 + k] = run; cursor[i0 + k] = run; } run += v[k]; }
         __syncthreads();
         if (tid == 1023) s_carry = run;
         __syncthreads();
@@ -903,32 +964,45 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
 // One workgroup per 32x32-texel bin: sum the bin's records into a 33x33-texel LDS tile (footprints anchored in the bin
 // reach one texel past its right / bottom edge, still inside the face), then add every non-zero texel of the tile to
 // dL_dtexture[6,R,R,3] once -- 99 consecutive dwords per tile row, i.e. coalesced memory-side requests; neighbouring
-// bins overlap in that one-texel seam, hence atomics.  Leaves the cursor at 0 for the next call.
+// bins overlap in that one-texel seam, hence atomics.
 // The tile is 64-bit FIXED POINT: LDS float atomics retire ~3 cycles per lane on gfx950 (ds_add_f32: 193 cycles per wave
 // instruction, ds_add_u64: 6; scripts/ubench/lds_atomics.hip), which made the first version of this kernel 1.8 ms.  Scale:
 // every record value is bounded by C0 * max|dL/dpixel colour| OF THIS CALL (k_bin_offsets clears stats[1], K7 raises it)
-// and is mapped to < 2^42, so 2^20 records per bin cannot overflow (lists are cut there; the rest went through atomics);
-// resolution 2^-42 of the image-wide bound, sums exact and order-independent.
+// and is mapped to < 2^42, so 2^20 records cannot overflow; a longer list is summed in segments of 2^20 records with the tile
+// written out in between; resolution 2^-42 of the image-wide bound, sums exact and order-independent.
+// A NON-FINITE bound (an inf / NaN upstream gradient, e.g. under a GradScaler overflow) has no fixed-point scale: the bin's
+// records are then added with float atomics, which carry inf / NaN to exactly the texels the atomic path would have reached.
 #define TB_EDGE 33
 #define TB_ROW 37       // texels per tile row in LDS: the pad puts rows y and y + 1 (taps 00 / 10 of one record) 30 banks apart; measured 180 -> 162 us
+#define TB_SEG (1u << 20)
 __global__ void __launch_bounds__(256)
 k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __shared__ long long s_tile[TB_EDGE * TB_ROW * 3];           // [row][col (padded)][channel], 2^42-scaled fixed point
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const uint32_t filled = tb.cursor[b];
+    const uint32_t b0 = tb.base[b], b1 = tb.base[b + 1];
+    const uint32_t filled = tb.cursor[b] - b0;                   // (the cursor is absolute; K7 bumped it once per record it wanted to append)
     if (filled == 0u) return;                                  // uniform per workgroup
-    for (int k = tid; k < TB_EDGE * TB_ROW * 3; k += 256) s_tile[k] = 0ll;
-    __syncthreads();
-    const float bound = TG_SH_C0 * __uint_as_float(tb.stats[1]);
+    const uint32_t room = (b0 < tb.cap) ? min(b1, tb.cap) - b0 : 0u;      // records of this list that exist (K7's own test)
+    const uint32_t cnt = min(filled, room);
+    const float* __restrict__ rp = tb.rec + b0;
+    const size_t cap = tb.cap;
+    const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
+    const uint32_t bbits = tb.stats[1];
+    if (bbits >= 0x7F800000u) {                                // inf / NaN upstream gradient: float atomics, record by record
+        for (uint32_t i = (uint32_t)tid; i < cnt; i += 256u) {
+            const uint32_t fxw = __float_as_uint(rp[i]), fyw = __float_as_uint(rp[cap + i]);
+            const float fx = __uint_as_float(fxw & ~31u), fy = __uint_as_float(fyw & ~31u);
+            const uint32_t y = (uint32_t)by * 32u + (fyw & 31u), x = (uint32_t)bx * 32u + (fxw & 31u);
+            const uint32_t o00 = ((((uint32_t)face * (uint32_t)R + y) * (uint32_t)R + x) * 3u) << 2;
+            scatter_direct(dtex, o00, 12u, 12u * (uint32_t)R, fx, fy, rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
+        }
+        return;
+    }
+    const float bound = TG_SH_C0 * __uint_as_float(bbits);
     int e = 0;
     (void)frexpf(bound, &e);                                   // bound < 2^e
     const double up = (double)ldexpf(1.0f, 42 - e);
     const float down = ldexpf(1.0f, e - 42);
-    const uint32_t b0 = tb.base[b], b1 = tb.base[b + 1];
-    const uint32_t room = (b0 < tb.cap) ? min(b1, tb.cap) - b0 : 0u;      // records of this list that exist (K7's own test)
-    const uint32_t cnt = min(min(filled, room), TB_LIST_MAX);
-    const float* __restrict__ rp = tb.rec + b0;
-    const size_t cap = tb.cap;
     // float -> int64 without the 11-instruction generic conversion: |v| < 2^42, so v + 1.5 * 2^52 (exact in double) carries
     // round(v) in its mantissa; subtracting the bias as integers leaves the two's-complement value
     const double magic = 6755399441055744.0;
@@ -946,30 +1020,34 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         TB_ADD(t + TB_ROW * 3 + 3, w11 * dx0); TB_ADD(t + TB_ROW * 3 + 4, w11 * dx1); TB_ADD(t + TB_ROW * 3 + 5, w11 * dx2);
 #undef TB_ADD
     };
-    // two records per thread in flight (10 loads)
-    uint32_t i = (uint32_t)tid;
-    for (; i + 256u < cnt; i += 512u) {
-        const uint32_t i2 = i + 256u;
-        const uint32_t fxa = __float_as_uint(rp[i]), fya = __float_as_uint(rp[cap + i]);
-        const float xa0 = rp[2 * cap + i], xa1 = rp[3 * cap + i], xa2 = rp[4 * cap + i];
-        const uint32_t fxb = __float_as_uint(rp[i2]), fyb = __float_as_uint(rp[cap + i2]);
-        const float xb0 = rp[2 * cap + i2], xb1 = rp[3 * cap + i2], xb2 = rp[4 * cap + i2];
-        add_record(fxa, fya, xa0, xa1, xa2);
-        add_record(fxb, fyb, xb0, xb1, xb2);
+    for (uint32_t s0 = 0u; s0 < cnt; s0 += TB_SEG) {             // one trip unless the list is longer than 2^20 records
+        const uint32_t s1 = min(cnt, s0 + TB_SEG);
+        for (int k = tid; k < TB_EDGE * TB_ROW * 3; k += 256) s_tile[k] = 0ll;
+        __syncthreads();
+        // two records per thread in flight (10 loads)
+        uint32_t i = s0 + (uint32_t)tid;
+        for (; i + 256u < s1; i += 512u) {
+            const uint32_t i2 = i + 256u;
+            const uint32_t fxa = __float_as_uint(rp[i]), fya = __float_as_uint(rp[cap + i]);
+            const float xa0 = rp[2 * cap + i], xa1 = rp[3 * cap + i], xa2 = rp[4 * cap + i];
+            const uint32_t fxb = __float_as_uint(rp[i2]), fyb = __float_as_uint(rp[cap + i2]);
+            const float xb0 = rp[2 * cap + i2], xb1 = rp[3 * cap + i2], xb2 = rp[4 * cap + i2];
+            add_record(fxa, fya, xa0, xa1, xa2);
+            add_record(fxb, fyb, xb0, xb1, xb2);
+        }
+        if (i < s1) add_record(__float_as_uint(rp[i]), __float_as_uint(rp[cap + i]), rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
+        __syncthreads();
+        for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
+            const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
+            const long long q = s_tile[row * (TB_ROW * 3) + c];
+            if (q == 0ll) continue;
+            const int y = by * 32 + row, xq = bx * 96 + c;
+            if (y >= R || xq >= R * 3) continue;
+            // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles, hence atomics
+            unsafeAtomicAdd(dtex + ((size_t)(face * R + y) * R) * 3 + xq, (float)q * down);
+        }
+        __syncthreads();
     }
-    if (i < cnt) add_record(__float_as_uint(rp[i]), __float_as_uint(rp[cap + i]), rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
-    __syncthreads();
-    const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
-    for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
-        const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
-        const long long q = s_tile[row * (TB_ROW * 3) + c];
-        if (q == 0ll) continue;
-        const int y = by * 32 + row, xq = bx * 96 + c;
-        if (y >= R || xq >= R * 3) continue;
-        // rows / columns 0 and 32 of the tile are shared with the neighbouring bins' tiles, hence atomics
-        unsafeAtomicAdd(dtex + ((size_t)(face * R + y) * R) * 3 + xq, (float)q * down);
-    }
-    if (tid == 0) tb.cursor[b] = 0u;
 }
 
 inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
@@ -993,8 +1071,8 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
 inline TexBinArgs make_bins(const CamConst& c, const TexGSImage* img, const TexGSGrads* gr) {
     TexBinArgs tb;
     tb.nb = (c.R + 31) >> 5;
-    const bool on = img->tex_bin_count != nullptr && gr->tex_bins != nullptr && gr->tex_bin_cursor != nullptr &&
-                    gr->tex_bin_base != nullptr && gr->tex_rec_cap > 0;
+    const bool on = (gr->want & TEXGS_WANT_TEXTURE) && img->tex_bin_count != nullptr && gr->tex_bins != nullptr &&
+                    gr->tex_bin_cursor != nullptr && gr->tex_bin_base != nullptr && gr->tex_rec_cap > 0;
     tb.rec = on ? gr->tex_bins : nullptr;
     tb.cursor = on ? gr->tex_bin_cursor : nullptr;
     tb.base = on ? gr->tex_bin_base : nullptr;
@@ -1013,22 +1091,41 @@ size_t tex_bin_count(int R) {
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s) {
     const PixArgs a = make_pix(c, f, in, g, b, img);
-    hipLaunchKernelGGL(k_render_fwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
-                       img->out_norm, img->out_alpha, img->final_T, img->n_contrib, img->tex_bin_count);
+    if (in->texture)
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
+                           img->out_norm, img->out_alpha, img->final_T, img->n_contrib, img->tex_bin_count);
+    else
+        hipLaunchKernelGGL(k_render_fwd<false>, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
+                           img->out_norm, img->out_alpha, img->final_T, img->n_contrib, (uint32_t*)nullptr);
 }
 
+// Which flavour of K7 a call gets (see the template's comment): the texture gradient only when it is wanted and there is a texture,
+// the per-Gaussian stages only when a Gaussian gradient is wanted; the UV chain rides with the per-Gaussian stages of the textured
+// operator.
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     const PixArgs a = make_pix(c, f, in, g, b, img);
     const TexBinArgs tb = make_bins(c, img, gr);
-    if (tb.rec)      // list offsets from the counts the forward left (one small workgroup)
+    const bool taps = in->texture != nullptr;
+    const bool tex = taps && (gr->want & TEXGS_WANT_TEXTURE) && gr->dL_dtexture != nullptr;
+    const bool geo = (gr->want & TEXGS_WANT_GAUSSIANS) != 0;
+    if (!tex && !geo) return;
+    if (tex && tb.rec)      // list offsets + cursors from the counts the forward left (one small workgroup)
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
-                           gr->tex_bin_base, tb.stats);
-    hipLaunchKernelGGL(k_render_bwd, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, tb, img->final_T,
-                       img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture);
+                           gr->tex_bin_base, gr->tex_bin_cursor, tb.stats);
+    const dim3 grid(blend_grid(a.num_tiles)), blk(64);
+#define K7_LAUNCH(TEX, GEO, UVG, TAPS) hipLaunchKernelGGL((k_render_bwd<TEX, GEO, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
+        img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
+    if (!taps)            K7_LAUNCH(false, true, false, false);
+    else if (tex && geo)  K7_LAUNCH(true, true, true, true);
+    else if (tex)         K7_LAUNCH(true, false, false, true);
+    else                  K7_LAUNCH(false, true, true, true);
+#undef K7_LAUNCH
 }
 
-bool tex_bins_enabled(const CamConst& c, const TexGSImage* img, const TexGSGrads* gr) { return make_bins(c, img, gr).rec != nullptr; }
+bool tex_bins_enabled(const CamConst& c, const TexGSInputs* in, const TexGSImage* img, const TexGSGrads* gr) {
+    return in->texture != nullptr && gr->dL_dtexture != nullptr && make_bins(c, img, gr).rec != nullptr;
+}
 
 void launch_texgrad_reduce(const CamConst& c, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     const TexBinArgs tb = make_bins(c, img, gr);

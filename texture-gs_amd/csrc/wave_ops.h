@@ -148,27 +148,36 @@ __device__ __forceinline__ float reduce32_bankfirst(float (&v)[32], int lane) {
 // 16-lane version: sums v[0..31] over each DPP row (16 lanes) separately.  On return lane l holds, for its row, the total of
 // slot transposed_index(l & 15) in `lo` and of slot 16 + transposed_index(l & 15) in `hi` (the four steps of
 // reduce32_bankfirst before its cross-row exchanges: lane^4, lane^8 bank-masked, lane^1, lane^2 quad_perm).
-// NLIVE (a multiple of 4): slots >= NLIVE are known to be zero in every lane; their exchanges are not issued.
-template <int NLIVE = 32>
-__device__ __forceinline__ void reduce32_rows16(float (&v)[32], int lane, float& lo, float& hi) {
-    static_assert(NLIVE % 4 == 0 && NLIVE > 0 && NLIVE <= 32, "NLIVE");
+// LIVE: bit k set = slot k may be non-zero in some lane; an exchange whose slots are all dead is not issued (the result is the
+// constant 0).  The 28 moments of the full backward: 0x0FFFFFFF; without the UV chain 13 slots are live and 15 of the 29 exchanges go.
+template <uint32_t LIVE = 0xFFFFFFFFu>
+__device__ __forceinline__ void reduce32_rows16_masked(float (&v)[32], int lane, float& lo, float& hi) {
     const bool b0 = lane & 1, b1 = lane & 2;
     float a[16], b[8], c[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = (2 * i < NLIVE) ? pair_xor4(v[2 * i], v[2 * i + 1]) : 0.f;
+    for (int i = 0; i < 16; ++i) a[i] = ((LIVE >> (2 * i)) & 3u) ? pair_xor4(v[2 * i], v[2 * i + 1]) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = (4 * i < NLIVE) ? pair_xor8(a[2 * i], a[2 * i + 1]) : 0.f;
+    for (int i = 0; i < 8; ++i) b[i] = ((LIVE >> (4 * i)) & 15u) ? pair_xor8(a[2 * i], a[2 * i + 1]) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float keep = b0 ? b[2 * i + 1] : b[2 * i], send = b0 ? b[2 * i] : b[2 * i + 1];
-        c[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+        if ((LIVE >> (8 * i)) & 255u) {
+            const float keep = b0 ? b[2 * i + 1] : b[2 * i], send = b0 ? b[2 * i] : b[2 * i + 1];
+            c[i] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+        } else c[i] = 0.f;
     }
-    {
+    lo = 0.f; hi = 0.f;
+    if (LIVE & 0xFFFFu) {
         const float keep = b1 ? c[1] : c[0], send = b1 ? c[0] : c[1];
         lo = keep + dpp_mov<DPP_QUAD_XOR2>(send);
     }
-    {
+    if (LIVE >> 16) {
         const float keep = b1 ? c[3] : c[2], send = b1 ? c[2] : c[3];
         hi = keep + dpp_mov<DPP_QUAD_XOR2>(send);
     }
+}
+// NLIVE (a multiple of 4): slots >= NLIVE are known to be zero in every lane.
+template <int NLIVE = 32>
+__device__ __forceinline__ void reduce32_rows16(float (&v)[32], int lane, float& lo, float& hi) {
+    static_assert(NLIVE % 4 == 0 && NLIVE > 0 && NLIVE <= 32, "NLIVE");
+    reduce32_rows16_masked<(NLIVE == 32) ? 0xFFFFFFFFu : ((1u << (NLIVE & 31)) - 1u)>(v, lane, lo, hi);
 }

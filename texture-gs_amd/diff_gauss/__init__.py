@@ -1,12 +1,14 @@
 """Drop-in for the reference's `diff_gauss` extension module (imported at render/render.py:4, called :75-84): the
 same tile rasterizer WITHOUT the texture -- colours from per-Gaussian SH (`shs f32[N,(deg+1)^2,3]`, DC first) or from
-`colors_precomp f32[N,3]` -- returning the same 6-tuple (image, depth, norm, alpha, radii, extra).
+`colors_precomp f32[N,3]`, covariances from (scales, rotations) or from `cov3Ds_precomp f32[N,6]`
+(render/render.py:52-53; layout of strip_lowerdiag, utils/general.py:73-82) -- returning the same 6-tuple
+(image, depth, norm, alpha, radii, extra).
 
-It runs on the textured operator's kernels: a 1x1 zero cubemap makes the texture term vanish and the per-Gaussian
-colour enters through the operator's `color_offset` input (C0*SH_DC, or colors_precomp - 0.5 so that
-max(0, offset + 0.5) is the given colour).  `means2D.grad[:, :2]` is the lineage's dL/d(ndc xy) that stage-1
-densification reads (models/gaussian3d.py:334-336).  SURVEY.md section 8f-1: built for import compatibility and
-stages 1-2; not tuned (the texture machinery idles)."""
+It runs the UNTEXTURED flavours of the textured operator's kernels (TexGSInputs.texture == NULL, texgs.h): no UV step, no
+cubemap address, no taps, no texture-gradient machinery; the per-Gaussian colour enters through the operator's `color_offset`
+input (C0*SH_DC, or colors_precomp - 0.5 so that max(0, offset + 0.5) is the given colour).  `means2D.grad[:, :2]` is the
+lineage's dL/d(ndc xy) that stage-1 densification reads (models/gaussian3d.py:334-336).  With cov3Ds_precomp the splat normal
+is the eigenvector of the smallest eigenvalue and carries no gradient (a selection, like the shortest-axis choice)."""
 import torch
 from torch import nn
 
@@ -26,14 +28,13 @@ class GaussianRasterizer(nn.Module):
         if (shs is None) == (colors_precomp is None):
             raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
         if cov3Ds_precomp is not None:
-            raise NotImplementedError("cov3Ds_precomp (cfg.compute_cov3D_python, render/render.py:52-53) is not built; "
-                                      "pass scales and rotations")
-        if scales is None or rotations is None:
-            raise ValueError("Please provide scales and rotations")
+            if scales is not None or rotations is not None:
+                raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        elif scales is None or rotations is None:
+            raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         if extra_attrs is not None:
-            raise NotImplementedError("extra_attrs blending is not built yet")
-        N = means3D.shape[0]
-        dev = means3D.device
+            raise NotImplementedError("extra_attrs is always None in the reference (render/render.py:84); blending of extra "
+                                      "per-Gaussian attributes is not built")
         if means2D is None:
             means2D = torch.zeros_like(means3D)
         rest = None
@@ -43,10 +44,7 @@ class GaussianRasterizer(nn.Module):
                 rest = shs[:, 1:, :].contiguous()
         else:
             offset = colors_precomp - 0.5
-        uvs = torch.zeros(N, 3, device=dev)
-        uvs[:, 2] = 1.0
-        juv = torch.zeros(N, 9, device=dev)
-        tex = torch.zeros(6, 1, 1, 3, device=dev)
         color, depth, norm, alpha, radii = _RasterizeGaussians.apply(
-            means3D, means2D, rest, opacities, scales, rotations, uvs, juv, tex, st, offset.contiguous())
+            means3D, means2D, rest, opacities, scales, rotations, None, None, None, st, offset.contiguous(), None,
+            cov3Ds_precomp)
         return color, depth, norm, alpha, radii, None

@@ -6,13 +6,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8
 REC_SHADE_FLOATS = 20
 TEXBIN_RECORD_FLOATS = 5
 ACC_FLOATS = 32
+WANT_TEXTURE, WANT_GAUSSIANS, WANT_ALL = 1, 2, 3
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -26,7 +27,7 @@ class Frame(C.Structure):
 
 class Inputs(C.Structure):
     _fields_ = [("means3D", _fp), ("shs", _fp), ("opacities", _fp), ("scales", _fp), ("rotations", _fp),
-                ("uvs", _fp), ("gradient_uvs", _fp), ("texture", _fp), ("color_offset", _fp)]
+                ("uvs", _fp), ("gradient_uvs", _fp), ("texture", _fp), ("color_offset", _fp), ("cov3D_precomp", _fp)]
 
 
 class Geom(C.Structure):
@@ -49,7 +50,7 @@ class Grads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp), ("dL_dnorm", _fp), ("dL_dalpha", _fp), ("acc", _fp),
                 ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dshs", _fp), ("dL_dopacities", _fp),
                 ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_duvs", _fp), ("dL_dtexture", _fp),
-                ("dL_dcolor_offset", _fp), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_base", _fp),
+                ("dL_dcolor_offset", _fp), ("dL_dcov3D", _fp), ("want", C.c_uint32), ("tex_bins", _fp), ("tex_bin_cursor", _fp), ("tex_bin_base", _fp),
                 ("tex_rec_cap", C.c_uint32),
                 ("accumulate", C.c_int32)]
 

@@ -18,10 +18,15 @@ from . import _lib
 import os as _os
 USE_TEX_BINS = _os.environ.get("TEXGS_TEX_BINS", "1") != "0"       # binned two-pass texture gradient
 TEX_REC_CAP = int(_os.environ.get("TEXGS_REC_CAP", "0"))           # fixed record capacity (tests); 0 = adaptive
-DIRECT_LEAF_GRADS = _os.environ.get("TEXGS_DIRECT_LEAF_GRADS", "1") != "0"   # add into a leaf's existing .grad in place
+# OPT-IN fast path: add into a leaf's existing .grad in place instead of handing autograd a temporary.  Off by default because
+# it is not what autograd does: torch.autograd.grad() would then mutate .grad, and tensor hooks / post-accumulate-grad hooks /
+# DDP reducer hooks on those leaves would not fire (leaves that carry hooks are skipped even when it is on).  The supported fused
+# path is an explicit texgs.multiview.GradBucket sink.
+DIRECT_LEAF_GRADS = _os.environ.get("TEXGS_DIRECT_LEAF_GRADS", "0") != "0"
+# upper bound of ONE record buffer; there is one per (device, stream) that runs backwards (a depth-3 ViewPipeline holds three)
 TEX_REC_BYTES_MAX = int(float(_os.environ.get("TEXGS_BIN_GB_MAX", "4")) * (1 << 30))
 # per-Gaussian gradient outputs in the order / bit positions of TEXGS_ACC_* (texgs.h)
-_ACC_BITS = dict(means3D=1, means2D=2, shs=4, opacities=8, scales=16, rotations=32, uvs=64, color_offset=128)
+_ACC_BITS = dict(means3D=1, means2D=2, shs=4, opacities=8, scales=16, rotations=32, uvs=64, color_offset=128, cov3D=256)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -159,10 +164,14 @@ def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
 
 
 def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None,
-                for_backward=True):
-    """Run K1..K6.  Returns (outputs, state).  No autograd here.  `for_backward`: K6 also counts the texture-gradient
-    footprints per texture bin (the exact list sizes of backward_raw's binned texture gradient); without the counts a
-    backward still works, through atomics."""
+                for_backward=True, cov3D_precomp=None, count_bins=None):
+    """Run K1..K6.  Returns (outputs, state).  No autograd here.
+
+    `for_backward`: K6 leaves the per-block survivor lists its backward replays.  `count_bins` (default: for_backward and
+    there is a texture): K6 also counts the texture-gradient footprints per texture bin (the exact list sizes of
+    backward_raw's binned texture gradient); a caller that will not ask for dL/dtexture saves that work.
+    `texture=None`: the untextured surface (diff_gauss, render/render.py:75-84): uvs / gradient_uvs may be None too.
+    `cov3D_precomp` f32[N,6] (untextured surface only): used instead of scales / rotations."""
     lib = _lib.load()
     device = means3D.device
     if device.type != "cuda":
@@ -173,20 +182,37 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise ValueError("means3D must be [N,3]")
     opacities = _f32c(opacities, "opacities", device)
-    scales = _f32c(scales, "scales", device)
-    rotations = _f32c(rotations, "rotations", device)
-    uvs = _f32c(uvs, "uvs", device)
-    gradient_uvs = _f32c(gradient_uvs, "gradient_uvs", device)
-    texture = _f32c(texture, "texture", device)
-    if opacities.numel() != N or scales.shape != (N, 3) or rotations.shape != (N, 4) or uvs.shape != (N, 3) \
-            or gradient_uvs.numel() != 9 * N:
-        raise ValueError("per-Gaussian inputs must have exactly N rows "
-                         f"(N={N}; opacities {tuple(opacities.shape)}, scales {tuple(scales.shape)}, "
-                         f"rotations {tuple(rotations.shape)}, uvs {tuple(uvs.shape)}, "
-                         f"gradient_uvs {tuple(gradient_uvs.shape)})")
-    if texture.dim() != 4 or texture.shape[0] != 6 or texture.shape[1] != texture.shape[2] or texture.shape[3] != 3:
-        raise ValueError(f"texture must be [6,R,R,3], got {tuple(texture.shape)}")
-    R = texture.shape[1]
+    if opacities.numel() != N:
+        raise ValueError(f"per-Gaussian inputs must have exactly N rows (N={N}; opacities {tuple(opacities.shape)})")
+    if cov3D_precomp is not None:
+        if texture is not None:
+            raise ValueError("cov3D_precomp is an input of the untextured surface only")
+        cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp", device)
+        if cov3D_precomp.shape != (N, 6):
+            raise ValueError(f"cov3D_precomp must be [N,6], got {tuple(cov3D_precomp.shape)}")
+        scales = rotations = None
+    else:
+        scales = _f32c(scales, "scales", device)
+        rotations = _f32c(rotations, "rotations", device)
+        if scales.shape != (N, 3) or rotations.shape != (N, 4):
+            raise ValueError("per-Gaussian inputs must have exactly N rows "
+                             f"(N={N}; scales {tuple(scales.shape)}, rotations {tuple(rotations.shape)})")
+    if texture is not None:
+        uvs = _f32c(uvs, "uvs", device)
+        gradient_uvs = _f32c(gradient_uvs, "gradient_uvs", device)
+        texture = _f32c(texture, "texture", device)
+        if uvs.shape != (N, 3) or gradient_uvs.numel() != 9 * N:
+            raise ValueError("per-Gaussian inputs must have exactly N rows "
+                             f"(N={N}; uvs {tuple(uvs.shape)}, gradient_uvs {tuple(gradient_uvs.shape)})")
+        if texture.dim() != 4 or texture.shape[0] != 6 or texture.shape[1] != texture.shape[2] or texture.shape[3] != 3:
+            raise ValueError(f"texture must be [6,R,R,3], got {tuple(texture.shape)}")
+        R = texture.shape[1]
+    else:
+        uvs = gradient_uvs = None
+        R = 1
+    if count_bins is None:
+        count_bins = for_backward
+    count_bins = bool(count_bins and for_backward and texture is not None)
     K = 0
     if shs is not None:
         shs = _f32c(shs, "shs", device)
@@ -204,12 +230,12 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     H, W = int(st.image_height), int(st.image_width)
     tiles = ((W + _lib.TILE - 1) // _lib.TILE) * ((H + _lib.TILE - 1) // _lib.TILE)
     stream = torch.cuda.current_stream(device).cuda_stream
-    keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset]
+    keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, cov3D_precomp]
 
     with torch.cuda.device(device):
         frame = _make_frame(st, N, K, R, device, keep)
         inputs = _lib.Inputs(_ptr(means3D), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(rotations),
-                             _ptr(uvs), _ptr(gradient_uvs), _ptr(texture), _ptr(color_offset))
+                             _ptr(uvs), _ptr(gradient_uvs), _ptr(texture), _ptr(color_offset), _ptr(cov3D_precomp))
         i32, f32, u8 = torch.int32, torch.float32, torch.uint8
         n1 = max(N, 1)
         # Everything the kernels keep between forward and backward lives in TWO allocations (one sized by N / the image, one by
@@ -228,7 +254,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         fix.add("n_contrib", (H, W), i32)
         fix.add("ranges", (tiles, 2), i32)              # zero-filled by K3
         fix.add("tile_order", (tiles,), i32)
-        if for_backward and USE_TEX_BINS:
+        if count_bins and USE_TEX_BINS:
             fix.add("tex_bin_count", (int(lib.texgs_tex_bin_count(R)),), i32)
         if for_backward:
             fix.add("surv_count", (4 * tiles,), i32)
@@ -327,8 +353,12 @@ class _Tensors(dict):
         return default if v is None else v
 
 
-def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None, before_accumulate=None):
+def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=None, before_accumulate=None,
+                 want=_lib.WANT_ALL):
     """Run K7+K8.  Returns grads (means3D, means2D, shs, opacities, scales, rotations, uvs, texture).
+
+    `want` (TEXGS_WANT_* bits): WANT_TEXTURE = dL/dtexture, WANT_GAUSSIANS = every per-Gaussian gradient.  What is not wanted
+    is not computed (K7 is compiled in four flavours, K8 is skipped without WANT_GAUSSIANS) and comes back as None.
 
     `before_accumulate` (optional callable): invoked between K7 + bin reduce and K8 -- the point where a multi-view
     pipeline makes this stream wait for the previous view's K8 (texgs.multiview.ViewPipeline).
@@ -345,6 +375,12 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     f32 = dict(dtype=torch.float32, device=device)
     N, K, R = s.N, s.K, s.R
     stream = torch.cuda.current_stream(device).cuda_stream
+    textured = s.tensors["keep"][7] is not None
+    has_cov = s.tensors["keep"][9] is not None
+    want &= _lib.WANT_ALL if textured else _lib.WANT_GAUSSIANS
+    want_g, want_t = bool(want & _lib.WANT_GAUSSIANS), bool(want & _lib.WANT_TEXTURE)
+    if not want:
+        return (None,) * 8
 
     def g(t, shape):
         if t is None:
@@ -357,16 +393,26 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     with torch.cuda.device(device):
         skey = (device.index, int(stream))
         sc = _SCRATCH.pop(skey, None) or _StreamScratch()     # re-cached only after a successful call (an exception drops it)
-        if sc.acc is None or sc.acc.shape[0] < max(N, 1):
-            sc.acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
-        acc = sc.acc
+        acc = None
+        if want_g:
+            if sc.acc is None or sc.acc.shape[0] < max(N, 1):
+                sc.acc = torch.zeros(max(N, 1), _lib.ACC_FLOATS, **f32)
+            acc = sc.acc
         sinks = sinks or {}
         has_coff = s.tensors["keep"][8] is not None
-        shapes = dict(means3D=(N, 3), means2D=(N, 3), opacities=(N, 1), scales=(N, 3), rotations=(N, 4), uvs=(N, 3))
-        if K > 0:
-            shapes["shs"] = (N, K, 3)
-        if has_coff:
-            shapes["color_offset"] = (N, 3)
+        shapes = {}
+        if want_g:
+            shapes = dict(means3D=(N, 3), means2D=(N, 3), opacities=(N, 1))
+            if has_cov:
+                shapes["cov3D"] = (N, 6)
+            else:
+                shapes.update(scales=(N, 3), rotations=(N, 4))
+            if textured:
+                shapes["uvs"] = (N, 3)
+            if K > 0:
+                shapes["shs"] = (N, K, 3)
+            if has_coff:
+                shapes["color_offset"] = (N, 3)
         # one allocation for every per-Gaussian output without a sink
         fresh = [n for n in shapes if n not in sinks]
         flat = torch.empty(sum(math.prod(shapes[n]) for n in fresh), **f32) if fresh else None
@@ -381,16 +427,18 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
                 cnt = math.prod(shp)
                 outs[n] = flat[off:off + cnt].view(shp)
                 off += cnt
-        tex_sink = sinks.get("texture")
-        d_tex = tex_sink if tex_sink is not None else torch.zeros(6, R, R, 3, **f32)
+        tex_sink = sinks.get("texture") if want_t else None
+        d_tex = None
+        if want_t:
+            d_tex = tex_sink if tex_sink is not None else torch.zeros(6, R, R, 3, **f32)
         bins = None
-        if USE_TEX_BINS and s.tensors.get("tex_bin_count") is not None:
+        if want_t and USE_TEX_BINS and s.tensors.get("tex_bin_count") is not None:
             bins = sc.bins if (sc.bins is not None and sc.bins.R == R) else _TexBins(lib, device, R)
             sc.bins = None
             bins.before_call(s.D)
-        grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(outs["means3D"]), _ptr(outs["means2D"]),
-                           _ptr(outs.get("shs")), _ptr(outs["opacities"]), _ptr(outs["scales"]), _ptr(outs["rotations"]),
-                           _ptr(outs["uvs"]), _ptr(d_tex), _ptr(outs.get("color_offset")),
+        grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(outs.get("means3D")), _ptr(outs.get("means2D")),
+                           _ptr(outs.get("shs")), _ptr(outs.get("opacities")), _ptr(outs.get("scales")), _ptr(outs.get("rotations")),
+                           _ptr(outs.get("uvs")), _ptr(d_tex), _ptr(outs.get("color_offset")), _ptr(outs.get("cov3D")), want,
                            _ptr(bins.rec) if bins else None, _ptr(bins.cursor) if bins else None,
                            _ptr(bins.base) if bins else None, bins.cap if bins else 0, mask)
         if before_accumulate is None:
@@ -408,8 +456,9 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     _SCRATCH[skey] = sc
     res = {n: (None if n in sinks else outs[n]) for n in shapes}
     s.tensors["d_color_offset"] = res.get("color_offset")
-    return (res["means3D"], res["means2D"], res.get("shs"), res["opacities"], res["scales"], res["rotations"], res["uvs"],
-            None if tex_sink is not None else d_tex)
+    s.tensors["d_cov3D"] = res.get("cov3D")
+    return (res.get("means3D"), res.get("means2D"), res.get("shs"), res.get("opacities"), res.get("scales"), res.get("rotations"),
+            res.get("uvs"), None if tex_sink is not None else d_tex)
 
 
 def _leaf_grad_sink(t):
@@ -417,26 +466,41 @@ def _leaf_grad_sink(t):
     temporary, no AccumulateGrad pass), else None."""
     if t is None or not (t.is_leaf and t.requires_grad):
         return None
+    if getattr(t, "_backward_hooks", None) or getattr(t, "_post_accumulate_grad_hooks", None):
+        return None             # a hook must see the gradient: let autograd deliver it
     gr = t.grad
     if gr is None or gr.dtype != torch.float32 or not gr.is_contiguous() or gr.shape != t.shape or gr.device != t.device:
         return None
     return gr
 
 
+# inputs of _RasterizeGaussians.apply by position; the per-Gaussian ones decide TEXGS_WANT_GAUSSIANS
+_ARG = dict(means3D=0, means2D=1, shs=2, opacities=3, scales=4, rotations=5, uvs=6, gradient_uvs=7, texture=8, st=9,
+            color_offset=10, grad_sink=11, cov3D_precomp=12)
+_GAUSSIAN_ARGS = ("means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "color_offset", "cov3D_precomp")
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, color_offset=None,
-                grad_sink=None):
+                grad_sink=None, cov3D_precomp=None):
         ctx.grad_sink = grad_sink
         ctx.set_materialize_grads(False)     # outputs without an upstream gradient arrive as None, not as zero-filled tensors
         # the inputs by name: the backward looks at them again (bucket slices / leaf .grad buffers to accumulate into)
         ctx.named = dict(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales,
-                         rotations=rotations, uvs=uvs, texture=texture, color_offset=color_offset)
-        outs, state = forward_raw(st, means3D.detach(), None if shs is None else shs.detach(),
-                                  opacities.detach(), scales.detach(), rotations.detach(), uvs.detach(),
-                                  gradient_uvs.detach(), texture.detach(),
-                                  None if color_offset is None else color_offset.detach(),
-                                  for_backward=any(ctx.needs_input_grad))
+                         rotations=rotations, uvs=uvs, texture=texture, color_offset=color_offset, cov3D=cov3D_precomp)
+        # what the backward will be asked for decides what the forward prepares and what the backward computes: the texture
+        # gradient (K6's per-bin footprint counts, K7's records, the bin reduce) only if the texture wants one; the per-Gaussian
+        # stages (K7's recurrence + moment sums, K8) only if some per-Gaussian input does (texgs.h TEXGS_WANT_*)
+        nig = tuple(ctx.needs_input_grad) + (False,) * len(_ARG)      # (apply() may be called without the trailing optional inputs)
+        want = (_lib.WANT_TEXTURE if (texture is not None and nig[_ARG["texture"]]) else 0) \
+            | (_lib.WANT_GAUSSIANS if any(nig[_ARG[n]] for n in _GAUSSIAN_ARGS) else 0)
+        ctx.want = want
+        ctx.nargs = len(ctx.needs_input_grad)
+        det = lambda t: None if t is None else t.detach()
+        outs, state = forward_raw(st, means3D.detach(), det(shs), opacities.detach(), det(scales), det(rotations), det(uvs),
+                                  det(gradient_uvs), det(texture), det(color_offset), for_backward=bool(want),
+                                  cov3D_precomp=det(cov3D_precomp), count_bins=bool(want & _lib.WANT_TEXTURE))
         color, depth, norm, alpha, radii = outs
         ctx.state = state
         # the backward re-reads the inputs through raw pointers (K8 recomputes geometry, K7 re-fetches texels): remember
@@ -444,7 +508,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         # not a silently wrong gradient
         ctx.versions = [(t, t._version) for t in state.tensors["keep"] if t is not None]
         ctx.op_shape = opacities.shape
-        ctx.juv_shape = gradient_uvs.shape
         ctx.mark_non_differentiable(radii)
         return color, depth, norm, alpha, radii
 
@@ -459,9 +522,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise RuntimeError("an input of the rasterizer was modified in place between its forward and backward "
                                    "(the backward re-reads inputs through saved pointers); clone it before modifying")
         # where the gradients go: (1) the slices of a texgs.multiview.GradBucket (fused multi-view accumulation) when one is
-        # attached; (2) otherwise, for an input that is a LEAF whose .grad already exists, that .grad itself -- the kernels add
-        # into it, which is what AccumulateGrad would do with a temporary (a 75 MB zero-fill + add for the texture); (3) fresh
-        # tensors handed back to autograd for everything else.
+        # attached; (2) opt-in (TEXGS_DIRECT_LEAF_GRADS=1), for an input that is a hook-free LEAF whose .grad already exists,
+        # that .grad itself; (3) fresh tensors handed back to autograd for everything else (the default).
         sinks, bucket = {}, False
         if ctx.grad_sink is not None:
             sinks = {k: g for k, g in ((k, ctx.grad_sink.sink_for(v)) for k, v in ctx.named.items() if v is not None)
@@ -471,14 +533,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             sinks = {k: g for k, g in ((k, _leaf_grad_sink(v)) for k, v in ctx.named.items()) if g is not None}
         d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, d_tex = backward_raw(
             s, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=sinks or None,
-            before_accumulate=getattr(ctx.grad_sink, "before_accumulate", None) if bucket else None)
+            before_accumulate=getattr(ctx.grad_sink, "before_accumulate", None) if bucket else None, want=ctx.want)
         d_coff = s.tensors.get("d_color_offset")
+        d_cov = s.tensors.get("d_cov3D")
         ctx.state = None
         ctx.versions = None
         ctx.named = None
         if d_op is not None:
             d_op = d_op.reshape(ctx.op_shape)
-        return (d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, None, d_tex, None, d_coff, None)
+        return (d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, None, d_tex, None, d_coff, None, d_cov)[:ctx.nargs]
 
 
 class GaussianRasterizer(nn.Module):
