@@ -81,6 +81,9 @@ __device__ __forceinline__ void smallest_eigvec(const float* S6, float* n) {
     n[2] = (k == 0) ? v20 : ((k == 1) ? v21 : v22);
 }
 
+// COV: the world covariance is an input (cov6 = TexGSInputs.cov3D_precomp) -- a compile-time flavour so that the common path
+// carries neither the branch nor the eigenvector code (K1 went 36 -> 64 us when it did)
+template <bool COV = false>
 __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamConst& C, int i,
                                             const float* __restrict__ means, const float* __restrict__ scales,
                                             const float* __restrict__ rots, const float* __restrict__ juv,
@@ -104,7 +107,7 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
     g.xy[1] = ((ndcy + 1.0f) * (float)C.H - 1.0f) * 0.5f;
 
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (cov6 != nullptr) {
+    if constexpr (COV) {
         // world-space covariance given (render/render.py:52-53): used as it is, scale_modifier not applied (lineage)
 #pragma unroll
         for (int k = 0; k < 6; ++k) g.S[k] = cov6[6 * i + k];
@@ -171,7 +174,7 @@ __device__ __forceinline__ void geo_forward(Geo& g, const Frame& F, const CamCon
     // normal: shortest axis (first minimum), flipped to face the camera, world space
     g.dir[0] = mx - F.cam[0]; g.dir[1] = my - F.cam[1]; g.dir[2] = mz - F.cam[2];
     float n0, n1, n2;
-    if (cov6 != nullptr) {
+    if constexpr (COV) {
         float ev[3];
         smallest_eigvec(g.S, ev);
         n0 = ev[0]; n1 = ev[1]; n2 = ev[2];
@@ -325,6 +328,7 @@ __device__ __forceinline__ void sh_rows_out(float* __restrict__ g, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ K1
+template <bool COV>
 __global__ void __launch_bounds__(TG_BLOCK)
 k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
@@ -341,7 +345,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
     g.valid = false;
-    if (live) geo_forward(g, F, C, i, means, scales, rots, juv, cov6);
+    if (live) geo_forward<COV>(g, F, C, i, means, scales, rots, juv, cov6);
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (g.valid) {
         tile_rect(g, C, x0, y0, x1, y1);
@@ -417,6 +421,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
 #ifndef K8_BLOCK
 #define K8_BLOCK 256
 #endif
+template <bool COV>
 __global__ void __launch_bounds__(K8_BLOCK)
 k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restrict__ pm, const float* __restrict__ cp,
                  const float* __restrict__ means, const float* __restrict__ shs, const float* __restrict__ opac,
@@ -444,17 +449,20 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
         if (!(accumulate & TEXGS_ACC_MEANS3D)) d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
         if (!(accumulate & TEXGS_ACC_MEANS2D)) d_means2D[3 * i] = d_means2D[3 * i + 1] = d_means2D[3 * i + 2] = 0.f;
         if (!(accumulate & TEXGS_ACC_OPACITIES)) d_op[i] = 0.f;
-        if (d_scales && !(accumulate & TEXGS_ACC_SCALES)) d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
-        if (d_rots && !(accumulate & TEXGS_ACC_ROTATIONS)) d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
+        if constexpr (COV) {
+            if (!(accumulate & TEXGS_ACC_COV3D)) { for (int k = 0; k < 6; ++k) d_cov6[6 * i + k] = 0.f; }
+        } else {
+            if (!(accumulate & TEXGS_ACC_SCALES)) d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
+            if (!(accumulate & TEXGS_ACC_ROTATIONS)) d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
+        }
         if (d_uvs && !(accumulate & TEXGS_ACC_UVS)) d_uvs[3 * i] = d_uvs[3 * i + 1] = d_uvs[3 * i + 2] = 0.f;
-        if (d_cov6 && !(accumulate & TEXGS_ACC_COV3D)) { for (int k = 0; k < 6; ++k) d_cov6[6 * i + k] = 0.f; }
         if (d_coff && !(accumulate & TEXGS_ACC_COLOR_OFFSET)) d_coff[3 * i] = d_coff[3 * i + 1] = d_coff[3 * i + 2] = 0.f;
     }
     if (visible) {
 #define OUT(BIT, P, V) do { if (accumulate & (BIT)) (P) += (V); else (P) = (V); } while (0)
     const Frame F = load_frame(vm, pm, cp);
     Geo g;
-    geo_forward(g, F, C, i, means, scales, rots, juv, cov6);
+    geo_forward<COV>(g, F, C, i, means, scales, rots, juv, cov6);
     // K7 left raw moment sums (common.h M_*) in this Gaussian's accumulator row; turn them into the gradients of the
     // record fields (R_* slots) here, where conic / opacity / G / g are in registers anyway, and hand the row back zeroed
     // (the scratch is all-zero between calls: no 38 MB memset per backward).
@@ -627,15 +635,15 @@ k_preprocess_bwd(CamConst C, const float* __restrict__ vm, const float* __restri
 #pragma unroll
     for (int k = 0; k < 3; ++k) dm[k] += dt[0] * F.V[k * 4 + 0] + dt[1] * F.V[k * 4 + 1] + dt[2] * F.V[k * 4 + 2];
     OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 0], dm[0]); OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 1], dm[1]); OUT(TEXGS_ACC_MEANS3D, d_means[3 * i + 2], dm[2]);
-    if (d_cov6) {       // the given covariance: dL/dS, off-diagonal entries carrying both symmetric halves (lineage layout)
+    if constexpr (COV) {       // the given covariance: dL/dS, off-diagonal entries carrying both symmetric halves (lineage layout)
         OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 0], dS[0]); OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 1], dS[1] + dS[3]);
         OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 2], dS[2] + dS[6]); OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 3], dS[4]);
         OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 4], dS[5] + dS[7]); OUT(TEXGS_ACC_COV3D, d_cov6[6 * i + 5], dS[8]);
     }
-    if (d_scales) { OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 0], dscale[0]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 1], dscale[1]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 2], dscale[2]); }
+    if constexpr (!COV) { OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 0], dscale[0]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 1], dscale[1]); OUT(TEXGS_ACC_SCALES, d_scales[3 * i + 2], dscale[2]); }
 
     // (5) R(q) -> q
-    if (d_rots) {
+    if constexpr (!COV) {
     const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
     OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 0], 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]));
     OUT(TEXGS_ACC_ROTATIONS, d_rots[4 * i + 1], 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]));
@@ -671,11 +679,12 @@ void launch_preprocess_fwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     const size_t lds = (in->shs && c.sh_degree > 0) ? (size_t)TG_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
     int hdr_words = 0;
     uint32_t* hdr = bin_header_ptr(g, c.N, &hdr_words);
-    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
-                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset,
-                       in->cov3D_precomp, reinterpret_cast<float4*>(g->rec_test), reinterpret_cast<float4*>(g->rec_shade), g->depth, g->radii,
-                       reinterpret_cast<uint2*>(g->rect),
-                       g->tiles_touched, bin_block_sums_ptr(g, c.N), hdr, hdr_words);
+#define K1_LAUNCH(COV) hipLaunchKernelGGL(k_preprocess_fwd<COV>, dim3(blocks), dim3(TG_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos, \
+                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->uvs, in->gradient_uvs, in->color_offset, \
+                       in->cov3D_precomp, reinterpret_cast<float4*>(g->rec_test), reinterpret_cast<float4*>(g->rec_shade), g->depth, g->radii, \
+                       reinterpret_cast<uint2*>(g->rect), g->tiles_touched, bin_block_sums_ptr(g, c.N), hdr, hdr_words)
+    if (in->cov3D_precomp) K1_LAUNCH(true); else K1_LAUNCH(false);
+#undef K1_LAUNCH
 }
 
 void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
@@ -683,10 +692,12 @@ void launch_preprocess_bwd(const CamConst& c, const TexGSFrame* f, const TexGSIn
     if (c.N <= 0) return;
     const int blocks = (c.N + K8_BLOCK - 1) / K8_BLOCK;
     const size_t lds = gr->dL_dshs ? (size_t)K8_BLOCK * 3 * c.sh_coeffs * sizeof(float) : 0;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(K8_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos,
-                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, in->cov3D_precomp,
-                       g->radii, gr->acc, gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales,
-                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->dL_dcov3D, gr->accumulate);
+#define K8_LAUNCH(COV) hipLaunchKernelGGL(k_preprocess_bwd<COV>, dim3(blocks), dim3(K8_BLOCK), lds, s, c, f->viewmatrix, f->projmatrix, f->campos, \
+                       in->means3D, in->shs, in->opacities, in->scales, in->rotations, in->gradient_uvs, in->cov3D_precomp, \
+                       g->radii, gr->acc, gr->dL_dmeans3D, gr->dL_dmeans2D, gr->dL_dshs, gr->dL_dopacities, gr->dL_dscales, \
+                       gr->dL_drotations, gr->dL_duvs, gr->dL_dcolor_offset, gr->dL_dcov3D, gr->accumulate)
+    if (in->cov3D_precomp) K8_LAUNCH(true); else K8_LAUNCH(false);
+#undef K8_LAUNCH
 }
 
 void launch_mark_visible(const TexGSFrame* f, const float* means3D, uint8_t* visible, hipStream_t s) {

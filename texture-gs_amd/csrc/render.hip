@@ -506,12 +506,13 @@ struct TexBinArgs {
 
 struct __attribute__((aligned(16))) BwdLds {
     float4 items[BQ_CAP * 3 + 3];       // 6192: 3 float4 per item {T -> w, s -> dL/dpower, alpha_raw, key} {dc, du0} {du1, du2, inv, dden}; + one all-zero item
+    float4 abuf[BQ_CAP];                // 2048: {T, -, alpha_raw, key} of the NEXT segment's items (stage A runs one segment ahead of B / C)
     Planes p;                           // 6768
     float4 dpix[64];                    // 1024: dL/d(r, g, b, alpha) of the wave's pixels
     float4 dgeo[64];                    // 1024: dL/d(depth, normal)
     uint32_t task[64];                  //  256
     uint8_t list[4][64];                //  256
-};                                      // 15520 B -> 10 waves per CU
+};                                      // 17568 B -> 9 waves per CU
 
 // footprints that cannot be binned (clamped at a face border, beyond the buffer): straight into dL_dtexture.  Offsets in BYTES.
 __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_t o00, uint32_t dox, uint32_t doy, float fx, float fy,
@@ -610,7 +611,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     // ---- stage B, as two halves per round of 64 items (see the kernel header): FRONT issues everything that goes to memory,
     // BACK consumes it.  A segment has at most two rounds: both fronts first (8 tap loads + 2 returning atomics in flight), then
     // both backs.  (Starting round 0's front inside stage A, as soon as 64 items exist, was measured: K7 732 -> 771 us.)
-    int n_items = 0;
+    struct Seg { int n_items, n_it; uint32_t it_lo, it_hi, it_first; };      // it_*: lane k = ballot / first item of the k-th productive iteration
     struct Round {                                        // what the back half needs, as few registers as possible
         bool have, binned;
         int e, pl, jj, my_leader, my_rank, axis;
@@ -621,11 +622,14 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
         Texel3 t00, t01, t10, t11;
     };
-    auto front = [&](int rbase, Round& R) {
+    auto front = [&](int rbase, Round& R, int n_items) {
         R.e = rbase + lane;
         R.have = R.e < n_items;
         float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (R.have) it = L.items[R.e * 3];
+        if (R.have) {
+            it = L.abuf[R.e];
+            if constexpr (GEO) L.items[R.e * 3] = it;         // (the previous segment's stage C has read its items by now)
+        }
         const uint32_t key = __float_as_uint(it.w);
         R.pl = KEY_PL(key);
         const int jj = KEY_J(key);
@@ -770,60 +774,45 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         __builtin_amdgcn_wave_barrier();
         const int tmax = max(max(len[0], len[1]), max(len[2], len[3]));
         int t = 0;
-        while (t < tmax) {
-            // ================================================================ stage A
-            int n_it = 0;
-            n_items = 0;
-            uint32_t it_lo = 0u, it_hi = 0u, it_first = 0u;      // lane k: ballot and first item of the segment's k-th productive iteration
-            {
-                int cj = mylist[t], nj = mylist[min(t + 1, 63)], nnj = mylist[min(t + 2, 63)];
-                float4 cA = L.p.A[cj], cB = L.p.B[cj];
-                float4 nA = L.p.A[nj], nB = L.p.B[nj];
-                while (t < tmax && n_it < BWD_MAX_IT) {
-                    const float power = gauss_power(cA.z, cA.w, cB.x, cA.x - pxf, cA.y - pyf);
-                    const float araw = gauss_alpha_raw(cB.y, power);
-                    const float alpha = fminf(TG_ALPHA_MAX, araw);
-                    const bool before = __float_as_uint(cB.z) < (uint32_t)last;
-                    const bool ok = before && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-                    const ull bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(before) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
-                    const int nb = __popcll(bal);
-                    if (nb != 0) {
-                        if (n_items + nb > BQ_CAP) break;               // segment full; this iteration is re-tested in the next one
-                        if (lane == n_it) { it_lo = (uint32_t)bal; it_hi = (uint32_t)(bal >> 32); it_first = (uint32_t)n_items; }
-                        if (ok) {
-                            T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
-                            L.items[(n_items + mbcnt64(bal)) * 3] = make_float4(T, 0.f, araw, __uint_as_float(keybase | (uint32_t)cj));
-                        }
-                        n_items += nb; ++n_it;
+        // ================================================================ stage A (lock-step test loop) of ONE segment, items -> L.abuf
+        auto stage_a = [&](Seg& sg) {
+            sg.n_it = 0; sg.n_items = 0; sg.it_lo = 0u; sg.it_hi = 0u; sg.it_first = 0u;
+            int cj = mylist[min(t, 63)], nj = mylist[min(t + 1, 63)], nnj = mylist[min(t + 2, 63)];
+            float4 cA = L.p.A[cj], cB = L.p.B[cj];
+            float4 nA = L.p.A[nj], nB = L.p.B[nj];
+            while (t < tmax && sg.n_it < BWD_MAX_IT) {
+                const float power = gauss_power(cA.z, cA.w, cB.x, cA.x - pxf, cA.y - pyf);
+                const float araw = gauss_alpha_raw(cB.y, power);
+                const float alpha = fminf(TG_ALPHA_MAX, araw);
+                const bool before = __float_as_uint(cB.z) < (uint32_t)last;
+                const bool ok = before && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                const ull bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(before) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+                const int nb = __popcll(bal);
+                if (nb != 0) {
+                    if (sg.n_items + nb > BQ_CAP) break;               // segment full; this iteration is re-tested in the next one
+                    if (lane == sg.n_it) { sg.it_lo = (uint32_t)bal; sg.it_hi = (uint32_t)(bal >> 32); sg.it_first = (uint32_t)sg.n_items; }
+                    if (ok) {
+                        T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
+                        L.abuf[sg.n_items + mbcnt64(bal)] = make_float4(T, 0.f, araw, __uint_as_float(keybase | (uint32_t)cj));
                     }
-                    ++t;
-                    cj = nj; cA = nA; cB = nB;
-                    nj = nnj;
-                    nA = L.p.A[nj]; nB = L.p.B[nj];
-                    nnj = mylist[min(t + 2, 63)];
+                    sg.n_items += nb; ++sg.n_it;
                 }
+                ++t;
+                cj = nj; cA = nA; cB = nB;
+                nj = nnj;
+                nA = L.p.A[nj]; nB = L.p.B[nj];
+                nnj = mylist[min(t + 2, 63)];
             }
-            __builtin_amdgcn_wave_barrier();
-            if (n_items == 0) continue;
-            // ================================================================ stage B
-            static_assert(BQ_CAP <= 128, "stage B is unrolled for at most two rounds per segment");
-            {
-                Round R0, R1;
-                front(0, R0);
-                if (n_items > 64) front(64, R1);
-                back(R0);
-                if (n_items > 64) back(R1);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if constexpr (GEO) {
+        };
+        auto stage_c = [&](const Seg& sg) {
             // ================================================================ stage C1: per-pixel recurrence, iteration by iteration
             // dL/dalpha_i = T_i s_i - (B_i + T_final bg . dL/dcolour) / (1 - alpha_i),  B_i = sum over the contributors k BEHIND i
             // of s_k alpha_k T_k: one running sum per pixel (`behind`), back to front.  s_i (colour . dL/dcolour + geometry
             // channels) comes ready-made from stage B; this loop leaves w = alpha T and P = dL/dpower in the item.
-            for (int k = 0; k < n_it; ++k) {
-                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)it_lo, k);
-                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)it_hi, k);
-                const int it0 = __builtin_amdgcn_readlane((int)it_first, k);
+            for (int k = 0; k < sg.n_it; ++k) {
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)sg.it_lo, k);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)sg.it_hi, k);
+                const int it0 = __builtin_amdgcn_readlane((int)sg.it_first, k);
                 if (((((ull)bhi << 32) | blo) >> lane) & 1ull) {
                     const int it = it0 + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
                     const float4 i0 = L.items[it * 3];
@@ -841,13 +830,13 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             int ntask;
             {
                 const int itk = lane >> 2, qq = lane & 3;
-                const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)it_lo);
-                const uint32_t bhi = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)it_hi);
-                const uint32_t f0 = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)it_first);
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)sg.it_lo);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)sg.it_hi);
+                const uint32_t f0 = (uint32_t)__builtin_amdgcn_ds_bpermute(itk << 2, (int)sg.it_first);
                 const ull b = ((ull)bhi << 32) | blo;
                 const int c = __popc((uint32_t)(b >> (16 * qq)) & 0xFFFFu);
                 const int below = __popcll(b & ((1ull << (16 * qq)) - 1ull));
-                const bool havet = (itk < n_it) && (c > 0);
+                const bool havet = (itk < sg.n_it) && (c > 0);
                 const ull tm = TG_BALLOT(havet);
                 ntask = __popcll(tm);
                 if (havet) L.task[mbcnt64(tm)] = (f0 + (uint32_t)below) | ((uint32_t)c << 8);       // first item | item count << 8
@@ -914,7 +903,37 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            }   // GEO
+        };
+        // Segment pipeline: A(n + 1) runs BETWEEN the two halves of B(n).  The taps of segment n are gathers that miss the L2 (1-2 us
+        // each; 43 % of this kernel's wave-cycles were s_waitcnt on them) and stage A is a few hundred instructions without one
+        // vector-memory operation -- so every tap of segment n is in flight while the next segment's lists are walked, and the
+        // in-order vmcnt the back half waits on counts nothing that was issued in between.  (Scheduling barriers: left alone, the
+        // machine scheduler interleaved both back halves and waited for all eight taps first.)  No look-ahead across chunks: the
+        // next chunk's planes are not in LDS yet.
+        constexpr int NR = (BQ_CAP + 63) / 64;          // rounds of 64 items per segment, all of them in flight together
+        static_assert(BQ_CAP <= 192, "item indices travel in 8 bits (task words), and index BQ_CAP is the all-zero item");
+        Seg nxt;
+        stage_a(nxt);
+        while (nxt.n_items > 0) {
+            const Seg cur = nxt;
+            __builtin_amdgcn_wave_barrier();
+            // ================================================================ stage B, front halves
+            Round R[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (r == 0 || r * 64 < cur.n_items) front(r * 64, R[r], cur.n_items);
+            __builtin_amdgcn_sched_barrier(0);
+            nxt.n_items = 0; nxt.n_it = 0;
+            if (t < tmax) stage_a(nxt);
+            // ================================================================ stage B, back halves
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                __builtin_amdgcn_sched_barrier(0);      // back(r) waits for round r's loads only
+                if (r == 0 || r * 64 < cur.n_items) back(R[r]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (GEO) stage_c(cur);
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
