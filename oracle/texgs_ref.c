@@ -41,6 +41,16 @@
 #define MA_MIN 1e-20f
 #define SH_C0 0.28209479177387814f
 #define REC 24
+/* -DTEXGS_REF_VARIANT (tests only): the blend loops with a differently-rounded exp and reciprocal -- a second "fp32
+ * implementation" of the same contract, used on the CPU to check that texgs_ref_ambiguity explains every difference between
+ * two such implementations (tests/test_c_oracle.py) before that is asked of the HIP kernels. */
+#ifdef TEXGS_REF_VARIANT
+#define EXPF(x) exp2f((x) * 1.44269504088896f)
+#define RCPF(x) ((float)(1.0 / (double)(x)) * (1.0f + 5.9604645e-8f))
+#else
+#define EXPF(x) expf(x)
+#define RCPF(x) (1.0f / (x))
+#endif
 
 typedef struct {
     int H, W, N, K, R, sh_degree;
@@ -307,7 +317,7 @@ static Tap cube_address(float u0, float u1, float u2, int R) {
     else                      { t.axis = 2; m = u2; t.sm = (u2 >= 0.f) ? 1.f : -1.f; ua = u0; t.su = t.sm;  ub = u1; t.sv = -1.f; }
     const int face = 2 * t.axis + (t.sm > 0.f ? 0 : 1);
     const float ma = fmaxf(fabsf(m), MA_MIN);
-    t.rma = 1.0f / ma; t.sc = t.su * ua; t.tc = t.sv * ub;
+    t.rma = RCPF(ma); t.sc = t.su * ua; t.tc = t.sv * ub;
     const float halfR = 0.5f * (float)R;
     t.h = halfR * t.rma;
     const float col = (t.sc * t.rma + 1.0f) * halfR - 0.5f, row = (t.tc * t.rma + 1.0f) * halfR - 0.5f;
@@ -341,13 +351,13 @@ void texgs_ref_render_fwd(const RefIn *in, const float *rec, const uint32_t *poi
                 const float dx = r[0] - pxf, dy = r[1] - pyf;
                 const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
                 if (power > 0.0f) continue;
-                const float alpha = fminf(ALPHA_MAX, r[5] * expf(power));
+                const float alpha = fminf(ALPHA_MAX, r[5] * EXPF(power));
                 if (alpha < ALPHA_MIN) continue;
                 const float Tn = T * (1.0f - alpha);
                 if (Tn < T_EPS) break;
                 const float dpx = -dx, dpy = -dy;
                 const float den = 1.0f + r[6] * dpx + r[7] * dpy;
-                const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
+                const float inv = (den >= DEN_MIN) ? RCPF(den) : 0.0f;
                 const float u0 = r[14] + (r[8] * dpx + r[9] * dpy) * inv;
                 const float u1 = r[15] + (r[10] * dpx + r[11] * dpy) * inv;
                 const float u2 = r[16] + (r[12] * dpx + r[13] * dpy) * inv;
@@ -367,6 +377,106 @@ void texgs_ref_render_fwd(const RefIn *in, const float *rec, const uint32_t *poi
             out[pix] = A[0] + T * in->bg[0]; out[HW + pix] = A[1] + T * in->bg[1]; out[2 * HW + pix] = A[2] + T * in->bg[2];
             for (int ch = 3; ch < 8; ++ch) out[ch * HW + pix] = A[ch];
             final_T[pix] = T; n_contrib[pix] = last;
+        }
+    }
+}
+
+/* Ambiguity map of one forward (TEST ATTRIBUTION ONLY; same loops as texgs_ref_render_fwd, twice per pixel).
+ * Two fp32 implementations of this operator can only differ by more than rounding where a DISCRETE decision sits within
+ * rounding of its threshold.  margin[H*W] = the smallest relative distance of any such decision taken for the pixel:
+ *   alpha vs 1/255 (every tested instance), T (1 - alpha) vs 1e-4 (every instance that passed), power vs 0,
+ *   cubemap face (largest vs second largest |uv|) and den vs DEN_MIN (every contributor)
+ * -- the same list as oracle/texgs_torch.py render().  A pixel is "forward-ambiguous" when margin < tau_fwd.
+ * Gradients have two more discrete selections per contributing (pixel, Gaussian) pair: the bilinear cell (the sample is
+ * continuous across a cell edge, its uv-derivative is not) and the max(0, .) of the colour.  Flags (bytes, caller zero-fills):
+ *   gflag[N]     the Gaussian's gradient row may legitimately differ: it contributes to (or is within tau_fwd of contributing
+ *                to) a forward-ambiguous pixel, or one of its pairs is within tau_cell texels of a cell edge, or within
+ *                tau_relu of the colour clamp;
+ *   tflag[6RR]   same for a texel: tapped by a contributor of a forward-ambiguous pixel or by a pair within tau_relu of the clamp. */
+void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                         float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag) {
+    const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gxn * gyn; ++tile) {
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const int tx0 = (tile % gxn) * TILE, ty0 = (tile / gxn) * TILE;
+        for (int ly = 0; ly < TILE; ++ly) for (int lx = 0; lx < TILE; ++lx) {
+            const int px = tx0 + lx, py = ty0 + ly;
+            if (px >= W || py >= H) continue;
+            const float pxf = (float)px, pyf = (float)py;
+            float mpix = INFINITY;
+            for (int pass = 0; pass < 2; ++pass) {
+                /* pass 0: the pixel's margin.  pass 1: flags; in a forward-ambiguous pixel everything that contributes -- or is
+                   within tau_fwd of contributing, or comes after a T-threshold stop that is within tau_fwd of not happening --
+                   may carry a different gradient */
+                const int pix_amb = (pass == 1) && (mpix < tau_fwd);
+                int past_marginal_stop = 0;
+                float T = 1.0f;
+                for (uint32_t k = r0; k < r1; ++k) {
+                    const uint32_t id = point_list[k];
+                    const float *r = rec + (size_t)id * REC;
+                    const float dx = r[0] - pxf, dy = r[1] - pyf;
+                    const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
+                    float m = INFINITY;
+                    if (fabsf(power) < 1e-5f) m = 0.0f;
+                    const float araw = r[5] * expf(power);
+                    if (power <= 0.0f || m == 0.0f) m = fminf(m, fabsf(araw - ALPHA_MIN) / ALPHA_MIN);
+                    const int pass_alpha = (power <= 0.0f) && (fminf(ALPHA_MAX, araw) >= ALPHA_MIN);
+                    int contributes = pass_alpha;
+                    float Tn = T;
+                    if (pass_alpha) {
+                        const float alpha = fminf(ALPHA_MAX, araw);
+                        Tn = T * (1.0f - alpha);
+                        const float m_T = fabsf(Tn - T_EPS) / T_EPS * 0.2f;      /* T is a long product: 5x wider band than alpha's */
+                        m = fminf(m, m_T);
+                        if (Tn < T_EPS && !past_marginal_stop) {
+                            if (pass == 0 || m_T >= tau_fwd) { if (pass == 0) mpix = fminf(mpix, m); break; }
+                            past_marginal_stop = 1;          /* pass 1, marginal stop: the other implementation may blend on */
+                        }
+                    }
+                    if (pass == 0) {
+                        if (contributes) {
+                            const float dpx = -dx, dpy = -dy;
+                            const float den = 1.0f + r[6] * dpx + r[7] * dpy;
+                            const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
+                            float a0 = fabsf(r[14] + (r[8] * dpx + r[9] * dpy) * inv), a1 = fabsf(r[15] + (r[10] * dpx + r[11] * dpy) * inv);
+                            float a2 = fabsf(r[16] + (r[12] * dpx + r[13] * dpy) * inv), t;
+                            if (a0 < a1) { t = a0; a0 = a1; a1 = t; }
+                            if (a1 < a2) { t = a1; a1 = a2; a2 = t; }
+                            if (a0 < a1) { t = a0; a0 = a1; a1 = t; }
+                            m = fminf(m, (a0 - a1) / fmaxf(a0, MA_MIN));
+                            m = fminf(m, fabsf(den - DEN_MIN));
+                        }
+                        mpix = fminf(mpix, m);
+                    } else {
+                        const int marginal = pix_amb && (m < tau_fwd || past_marginal_stop);      /* may contribute on the other side */
+                        if (contributes || marginal) {
+                            const float dpx = -dx, dpy = -dy;
+                            const float den = 1.0f + r[6] * dpx + r[7] * dpy;
+                            const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
+                            const float u0 = r[14] + (r[8] * dpx + r[9] * dpy) * inv;
+                            const float u1 = r[15] + (r[10] * dpx + r[11] * dpy) * inv;
+                            const float u2 = r[16] + (r[12] * dpx + r[13] * dpy) * inv;
+                            const Tap ct = cube_address(u0, u1, u2, in->R);
+                            const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+                            const float w10 = (1.f - ct.fx) * ct.fy, w11 = ct.fx * ct.fy;
+                            float m_relu = INFINITY;
+                            for (int ch = 0; ch < 3; ++ch) {
+                                const float tv = w00 * in->tex[ct.o00 + ch] + w01 * in->tex[ct.o01 + ch] + w10 * in->tex[ct.o10 + ch]
+                                               + w11 * in->tex[ct.o11 + ch];
+                                m_relu = fminf(m_relu, fabsf(SH_C0 * tv + r[17 + ch] + 0.5f));
+                            }
+                            const float m_cell = fminf(fminf(ct.fx, 1.0f - ct.fx), fminf(ct.fy, 1.0f - ct.fy));
+                            if (pix_amb || m_cell < tau_cell || m_relu < tau_relu) gflag[id] = 1;
+                            if (pix_amb || m_relu < tau_relu) {
+                                tflag[ct.o00 / 3] = 1; tflag[ct.o01 / 3] = 1; tflag[ct.o10 / 3] = 1; tflag[ct.o11 / 3] = 1;
+                            }
+                        }
+                    }
+                    if (contributes) T = Tn;
+                }
+            }
+            margin[py * W + px] = mpix;
         }
     }
 }
@@ -405,14 +515,14 @@ void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *poi
                 const float dx = r[0] - pxf, dy = r[1] - pyf;
                 const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
                 if (power > 0.0f) continue;
-                const float Gs = expf(power), araw = r[5] * Gs, alpha = fminf(ALPHA_MAX, araw);
+                const float Gs = EXPF(power), araw = r[5] * Gs, alpha = fminf(ALPHA_MAX, araw);
                 if (alpha < ALPHA_MIN) continue;
                 T = T / (1.0f - alpha);
                 const float w = alpha * T;
                 const float dpx = -dx, dpy = -dy;
                 const float den = 1.0f + r[6] * dpx + r[7] * dpy;
                 const int good = den >= DEN_MIN;
-                const float inv = good ? 1.0f / den : 0.0f;
+                const float inv = good ? RCPF(den) : 0.0f;
                 const float nu0 = r[8] * dpx + r[9] * dpy, nu1 = r[10] * dpx + r[11] * dpy, nu2 = r[12] * dpx + r[13] * dpy;
                 const float u0 = r[14] + nu0 * inv, u1 = r[15] + nu1 * inv, u2 = r[16] + nu2 * inv;
                 const Tap ct = cube_address(u0, u1, u2, in->R);

@@ -10,6 +10,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libtexgs_ref.so")
+LIB_VARIANT = os.path.join(HERE, "libtexgs_ref_variant.so")       # differently-rounded build of the blend loops (Makefile)
 REC = 24
 
 
@@ -20,12 +21,22 @@ class RefIn(C.Structure):
 
 
 _lib = None
+_lib_variant = None
+
+
+def load_variant():
+    global _lib_variant
+    if _lib_variant is None:
+        load()
+        _lib_variant = C.CDLL(LIB_VARIANT)
+    return _lib_variant
 
 
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "texgs_ref.c")):
+        src_t = os.path.getmtime(os.path.join(HERE, "texgs_ref.c"))
+        if not all(os.path.exists(f) and os.path.getmtime(f) >= src_t for f in (LIB, LIB_VARIANT)):
             subprocess.check_call(["make", "-s", "-C", HERE])
         _lib = C.CDLL(LIB)
         _lib.texgs_ref_preprocess.restype = C.c_uint32
@@ -107,6 +118,39 @@ class RefRun:
                                      _p(g["shs"]), _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["uvs"]))
         self.acc = acc
         return g
+
+    def variant_render(self, dout=None):
+        """The blend loops of the differently-rounded build on THIS run's records / lists: (out[8,H,W], grads or None)."""
+        lib = load_variant()
+        out = np.zeros((8, self.H, self.W), np.float32)
+        fT = np.ones((self.H, self.W), np.float32)
+        nc = np.zeros((self.H, self.W), np.uint32)
+        lib.texgs_ref_render_fwd(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(out), _p(fT), _p(nc))
+        if dout is None:
+            return out, nc, None
+        N, K, R = self.N, self.K, self.R
+        dout = np.ascontiguousarray(dout.astype(np.float32))
+        acc = np.zeros((max(N, 1), REC), np.float64)
+        dtex = np.zeros((6, R, R, 3), np.float32)
+        lib.texgs_ref_render_bwd(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(fT), _p(nc), _p(dout),
+                                 _p(acc), _p(dtex))
+        g = dict(means3D=np.zeros((N, 3), np.float32), means2D=np.zeros((N, 3), np.float32),
+                 shs=np.zeros((N, K, 3), np.float32) if K else None, opacities=np.zeros((N, 1), np.float32),
+                 scales=np.zeros((N, 3), np.float32), rotations=np.zeros((N, 4), np.float32),
+                 uvs=np.zeros((N, 3), np.float32), texture=dtex)
+        self.lib.texgs_ref_preprocess_bwd(C.byref(self.inp), _p(self.radii), _p(acc), _p(g["means3D"]), _p(g["means2D"]),
+                                          _p(g["shs"]), _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["uvs"]))
+        return out, nc, g
+
+    def ambiguity(self, tau_fwd=2e-5, tau_cell=1e-4, tau_relu=1e-5):
+        """After forward(): (margin[H,W], gflag[N] bool, tflag[6,R,R] bool) -- where two fp32 implementations of the operator may
+        legitimately differ by more than rounding (texgs_ref_ambiguity in texgs_ref.c says which decisions are looked at)."""
+        margin = np.full((self.H, self.W), np.inf, np.float32)
+        gflag = np.zeros(max(self.N, 1), np.uint8)
+        tflag = np.zeros(6 * self.R * self.R, np.uint8)
+        self.lib.texgs_ref_ambiguity(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges),
+                                     C.c_float(tau_fwd), C.c_float(tau_cell), C.c_float(tau_relu), _p(margin), _p(gflag), _p(tflag))
+        return margin, gflag[:self.N].astype(bool), tflag.reshape(6, self.R, self.R).astype(bool)
 
     @property
     def threads(self):

@@ -2,12 +2,14 @@
 
 Bit-exact (integer / index work): radii, tile rects, tiles_touched, offsets, D, unsorted keys, sorted keys, point list,
 tile ranges -- at small sizes AND at BASELINE's full sizes (configs[1] 100k/512^2 and configs[2] 300k/1024^2, 800x800).
-Floating point at full size: >= 99.97 % of pixels within 1e-4 of the C oracle (the rest are threshold decisions that
-hardware exp/rcp decide differently: alpha >= 1/255, T >= 1e-4, bilinear cell), worst pixel < 5e-3; gradients by
-helpers.grad_close with the full-size bars (global rel-L2 <= 1e-2, <= 0.15 % outlier rows).  The bars are ~5x the slack
-measured on MI355X (profiles/r03_parity_report.jsonl: C3 1.6e-6 of pixels / worst 9.9e-4, C5 5.5e-5 / 4.3e-4; worst
-gradient global rel-L2 7.1e-3 (C5 uvs), worst outlier fraction 7.5e-4).  Plus size-independent properties on the GPU
-outputs themselves."""
+Floating point at full size, by ATTRIBUTION (no outlier budgets): the C oracle computes, for the same inputs, where two fp32
+implementations may legitimately differ -- pixels with a discrete decision (alpha >= 1/255, T >= 1e-4, power <= 0, cubemap
+face, den >= DEN_MIN) within rounding of its threshold, and gradient rows (Gaussians / texels) with a (pixel, Gaussian) pair
+within rounding of a bilinear-cell edge or of the colour clamp (oracle/texgs_ref.c texgs_ref_ambiguity, thresholds in
+helpers.py).  EVERY other pixel must be within 1e-4 (depth 4e-4) -- north_star's tolerance, literally -- with n_contrib
+identical, ambiguous pixels < 0.1 % of the image; EVERY unflagged gradient row within 1e-3 relative + 1e-4 of the largest
+entry: zero unexplained outliers.  Measured figures: profiles/r04_parity_report.jsonl.  Plus size-independent properties on
+the GPU outputs themselves."""
 import math
 
 import numpy as np
@@ -38,6 +40,7 @@ def _run(name):
     st = Hh.settings_for(cam, 3, bg)
     ref = CR.RefRun(scene, st)
     ref.forward()
+    ref.amb = ref.ambiguity(tau_fwd=Hh.TAU_FWD, tau_cell=Hh.tau_cell(R), tau_relu=Hh.tau_relu(R))
     outs, s = Hh.hip_debug_state(scene, cam, 3, bg)
     _cache.clear()                      # keep only one full-size scene alive
     _cache[name] = (scene, cam, bg, ref, outs, s)
@@ -81,19 +84,11 @@ def test_integer_stages_bit_exact(lib_built, name):
 
 @pytest.mark.parametrize("name", ["small", "c2", "c3"])
 def test_forward_full_size_vs_c_oracle(lib_built, name):
+    """north_star: per-pixel RGB / alpha within 1e-4 -- asserted on EVERY pixel the C oracle does not mark ambiguous."""
     scene, cam, bg, ref, outs, s = _run(name)
-    got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
-    exp = torch.tensor(ref.out)
-    err = (got - exp).abs()
-    scale = torch.ones(8, 1, 1); scale[3] = 4.0
-    bad = (err > 1e-4 * scale).any(dim=0)
+    got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0)
     nc = s.tensors["n_contrib"].cpu().numpy().astype(np.uint32)
-    Hh.report(f"hip_vs_c32/{name}/fwd", pixels_over_1e4th_frac=float(bad.float().mean()), worst_pixel=float((err / scale).max()),
-              median_err=float(err.median()), p999_err=float(err.flatten().kthvalue(int(0.999 * err.numel())).values),
-              n_contrib_agree_frac=float((nc == ref.n_contrib).mean()))
-    assert float(bad.float().mean()) < 3e-4, float(bad.float().mean())
-    assert float((err / scale).max()) < 5e-3
-    assert float((nc == ref.n_contrib).mean()) > 0.9995
+    Hh.forward_attributed(f"hip_vs_c32/{name}/fwd", got, ref, ref.amb[0], n_contrib=nc)
 
 
 @pytest.mark.parametrize("name", ["small", "c3"])
@@ -107,10 +102,11 @@ def test_backward_full_size_vs_c_oracle(lib_built, name):
     res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(),
                        dout[4:7].to(dev).contiguous(), dout[7:8].to(dev).contiguous())
     gref = ref.backward(dout.numpy())
+    _, gflag, tflag = ref.amb
     names = ["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
     for name_, got in zip(names, res[:8]):
-        ok, msg = Hh.grad_close(got.cpu(), torch.tensor(gref[name_]), label=f"hip_vs_c32/{name}/bwd/{name_}")
-        assert ok, (name_, msg)
+        Hh.grad_attributed(f"hip_vs_c32/{name}/bwd/{name_}", got.cpu(), torch.tensor(gref[name_]),
+                           tflag if name_ == "texture" else gflag)
 
 
 def test_size_independent_properties_full_size(lib_built):
