@@ -199,6 +199,19 @@ int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, Tex
  * that order, neither of which depends on D -- and only then waits for D, so the device is busy during the sync. */
 int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream);
 
+/* The same readback, also returning K1's 64-bit GEOMETRY FINGERPRINT: a hash of everything the tile binning (K2-K5), K6's
+ * survivor lists and its per-bin footprint counts are functions of (depth bits, tile rect, test record and the UV-Taylor part of
+ * the shading record of every Gaussian).  Two forwards with equal fingerprints, image size and texture resolution have identical
+ * TexGSBinning contents, survivor lists and tex_bin_count: the second may run texgs_render_forward on the first one's buffers
+ * (the reference renders every training view twice, models/texture_gaussian3d.py:318 and :375-389 -- same camera, same
+ * Gaussians, sh_degree 0 the second time).  Equality of a 64-bit hash, i.e. a 2^-64 chance of a false match per comparison.
+ * sort_first != 0: launch K2 before waiting (as texgs_read_num_rendered does); 0: only wait -- the caller expects to re-use
+ * existing lists and calls texgs_depth_sort_scan itself if the fingerprint turns out different. */
+int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, uint64_t* fingerprint_out,
+                             int32_t sort_first, void* stream);
+/* K2 alone: depth sort of the Gaussians + exclusive scan of tiles_touched in depth-rank order (writes geom->offsets, scan_temp). */
+int texgs_depth_sort_scan(TexGSGeom* geom, int32_t num_gaussians, void* stream);
+
 /* K3 duplicate-with-keys (in depth-rank order), K4 stable 2-pass radix sort of the D instances by tile id (the list is then
  * ordered by (tile, depth bits, index) exactly like the lineage's one 32+ceil(log2 T)-bit sort), K5 tile ranges + tile
  * launch order, K6 16x16-tile alpha-blend with cubemap fetch.  Second half of _C.rasterize_gaussians. */

@@ -168,3 +168,151 @@ def test_nonfinite_upstream_gradient_reaches_the_texture(lib_built):
         _, s = forward_raw(st, *args)
         again = backward_raw(s, dimg, None, None, None)[7]
         assert bool(torch.isfinite(again).all()) and Hh.rel_err(again, clean) < 1e-6
+
+
+def _reference_iteration(dev, scene, cam_tensors, deg, target, nhat, recompute_activations):
+    """models/texture_gaussian3d.py:318,375-389,410: render at the active degree, render again at degree 0 (same camera, same
+    Gaussians), ONE backward of the summed losses.  recompute_activations: sigmoid / exp / normalize are evaluated again for the
+    second render, as the reference's property getters do."""
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    H, W, tfx, tfy, bg, vm, pm, cp = cam_tensors
+    raw = dict(means3D=scene.means3D.clone(), shs=scene.shs.clone(), uvs=scene.uvs.clone(), texture=scene.texture.clone(),
+               rotations=scene.rotations.clone(), scales=scene.scales.log(),
+               opacities=torch.log(scene.opacities.clamp(1e-6, 1 - 1e-6) / (1 - scene.opacities.clamp(1e-6, 1 - 1e-6))))
+    raw = {k: v.to(dev).requires_grad_(True) for k, v in raw.items()}
+    juv = scene.gradient_uvs.to(dev)
+
+    def acts():
+        return dict(opacities=torch.sigmoid(raw["opacities"]), scales=torch.exp(raw["scales"]),
+                    rotations=torch.nn.functional.normalize(raw["rotations"]))
+    a1 = acts()
+    a2 = acts() if recompute_activations else a1
+    outs = []
+    loss = 0.0
+    for d, a in ((deg, a1), (0, a2)):
+        st = GaussianRasterizationSettings(H, W, tfx, tfy, bg, 1.0, vm, pm, d, cp, False, False)
+        m2 = torch.zeros_like(raw["means3D"], requires_grad=True) + 0
+        out = GaussianRasterizer(st)(means3D=raw["means3D"], means2D=m2, shs=raw["shs"], opacities=a["opacities"],
+                                     scales=a["scales"], rotations=a["rotations"], uvs=raw["uvs"], gradient_uvs=juv,
+                                     texture=raw["texture"], extra_attrs=None)
+        outs.append([o.detach().clone() for o in out[:5]])
+        loss = loss + (2.0 if d == 0 else 1.0) * synth.synthetic_loss(out[0], out[3], out[2], target, nhat)
+    loss.backward()
+    return outs, {k: v.grad.clone() for k, v in raw.items()}
+
+
+@pytest.mark.parametrize("recompute", [False, True])
+def test_second_forward_shares_geometry_bit_identically(lib_built, recompute):
+    """The reference renders every training view twice per iteration; the second render (sh_degree 0) finds K1's geometry
+    fingerprint unchanged and re-uses the first one's tile lists / survivor lists / footprint counts (K1 + K6 only).  Images,
+    radii and every gradient of the two-forwards-one-backward iteration are BIT-IDENTICAL to the same iteration with the cache
+    off -- also when the activations are recomputed for the second render (new tensors, same values: the reference's getters)."""
+    from texgs import rasterizer as RZ
+    import math
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(6000, 128, seed=77, scale_mean=0.02, random_jacobian=True)
+    cam = synth.fibonacci_cameras(6, 320, 240)[4]
+    cam_t = (240, 320, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.tensor([0.1, 0.2, 0.3], device=dev),
+             cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), cam.camera_center.to(dev))
+    target, nhat = synth.make_targets(240, 320, seed=2)
+    target, nhat = target.to(dev), nhat.to(dev)
+    saved = RZ.GEOM_CACHE
+    try:
+        RZ.GEOM_CACHE = False
+        RZ.release_scratch()
+        outs0, g0 = _reference_iteration(dev, scene, cam_t, 3, target, nhat, recompute)
+        RZ.GEOM_CACHE = True
+        RZ.release_scratch()
+        before = RZ.geometry_cache_stats()
+        outs1, g1 = _reference_iteration(dev, scene, cam_t, 3, target, nhat, recompute)
+        after = RZ.geometry_cache_stats()
+    finally:
+        RZ.GEOM_CACHE = saved
+        RZ.release_scratch()
+    assert after["hits"] - before["hits"] == 1 and after["misses"] - before["misses"] == 1
+    for a, b in zip(outs0, outs1):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert not torch.equal(outs1[0][0], outs1[1][0])               # (the two renders do differ: sh_degree 3 vs 0)
+    for k in g0:
+        if k == "texture":      # clamped-at-the-border footprints go through float atomics (order-dependent): not bitwise
+            assert Hh.rel_err(g1[k], g0[k]) < 1e-6, k
+        else:
+            assert Hh.rel_err(g1[k], g0[k]) < 2e-6, k              # (accumulator-row atomics: order-dependent last bits)
+
+
+def test_changed_geometry_is_not_shared(lib_built):
+    """Same camera tensors, one Gaussian moved by one ulp-sized step / a different opacity: the fingerprint differs, lists are rebuilt."""
+    from texgs import rasterizer as RZ
+    from texgs.rasterizer import forward_raw
+    dev, scene, st, _, _ = _setup(seed=3)
+    t = lambda x: x.to(dev)
+    args = [t(scene.means3D), t(scene.shs), t(scene.opacities), t(scene.scales), t(scene.rotations), t(scene.uvs),
+            t(scene.gradient_uvs), t(scene.texture)]
+    RZ.release_scratch()
+    s0 = RZ.geometry_cache_stats()
+    o1, _ = forward_raw(st, *args)
+    o2, st2 = forward_raw(st, *args)
+    assert st2.shared_geometry and torch.equal(o1[0], o2[0])
+    args[2] = args[2].clone(); args[2][17] *= 0.5                  # one opacity
+    o3, st3 = forward_raw(st, *args)
+    assert not st3.shared_geometry
+    args[0] = args[0].clone(); args[0][5, 0] += 1e-3               # one centre
+    o4, st4 = forward_raw(st, *args)
+    assert not st4.shared_geometry
+    s1 = RZ.geometry_cache_stats()
+    assert s1["hits"] - s0["hits"] == 1 and s1["misses"] - s0["misses"] == 3
+    RZ.GEOM_CACHE = False
+    try:
+        o5, st5 = forward_raw(st, *args)
+    finally:
+        RZ.GEOM_CACHE = True
+    assert torch.equal(o4[0], o5[0]) and torch.equal(o4[4], o5[4])
+    RZ.release_scratch()
+
+
+def test_forward_only_callers_stop_paying_for_the_handoff(lib_built):
+    """retexture.py:27 / visual_step render with parameters that require grad and never call backward: after two such graphs were
+    dropped, the forward leaves K6's hand-off (survivor lists, footprint counts) to the backward; a backward that does arrive
+    then builds it itself, the gradients are those of an ordinary forward + backward, and the forwards switch back."""
+    from texgs import rasterizer as RZ
+    from texgs.rasterizer import GaussianRasterizer
+    dev, scene, st, target, nhat = _setup(seed=21)
+    juv = scene.gradient_uvs.to(dev)
+
+    def fwd(leaves):
+        return GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=None, shs=leaves["shs"], opacities=leaves["opacities"],
+                                      scales=leaves["scales"], rotations=leaves["rotations"], uvs=leaves["uvs"],
+                                      gradient_uvs=juv, texture=leaves["texture"], extra_attrs=None)
+
+    def run_with_backward():
+        leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(True) for n in NAMES}
+        out = fwd(leaves)
+        synth.synthetic_loss(out[0], out[3], out[2], target, nhat).backward()
+        return [o.detach().clone() for o in out[:4]], {n: leaves[n].grad.clone() for n in NAMES}
+    saved = RZ.GEOM_CACHE
+    RZ.GEOM_CACHE = False                  # (every call here is the same view: keep the two mechanisms apart)
+    try:
+        RZ._UNUSED_STREAK.clear()
+        ref_out, ref_g = run_with_backward()
+        leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(True) for n in NAMES}
+        for _ in range(3):                 # three graphs built and dropped
+            out = fwd(leaves)
+            del out
+        assert RZ._UNUSED_STREAK.get(dev.index, 0) >= 2
+        h0 = RZ.geometry_cache_stats()["late_handoffs"]
+        got_out, got_g = run_with_backward()           # forward in lazy mode, backward builds the hand-off
+        assert RZ.geometry_cache_stats()["late_handoffs"] == h0 + 1
+        assert RZ._UNUSED_STREAK.get(dev.index, 0) == 0
+        for a, b in zip(ref_out, got_out):
+            assert torch.equal(a, b)
+        for n in NAMES:
+            assert Hh.rel_err(got_g[n], ref_g[n]) < 2e-6, n
+        _, again_g = run_with_backward()               # back to the ordinary path
+        assert RZ.geometry_cache_stats()["late_handoffs"] == h0 + 1
+        for n in NAMES:
+            assert Hh.rel_err(again_g[n], ref_g[n]) < 2e-6, n
+    finally:
+        RZ.GEOM_CACHE = saved
+        RZ._UNUSED_STREAK.clear()
+        RZ.release_scratch()

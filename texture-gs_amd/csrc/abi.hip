@@ -123,39 +123,55 @@ thread_local Readback g_rb_dev[RB_MAX_DEVICES];   // one pinned word + event per
                                                   // device that was current when they were created
 }
 
-// D = sum of tiles_touched (K1 accumulates it): asynchronous copy into pinned memory, then K2 -- depth sort + scan, which
-// WRITE geom->offsets and geom->scan_temp -- is launched, and only then the host waits: the device stays busy during the one
-// unavoidable device->host sync.  (So this "read" also runs K2; the name is the lineage's step it replaces.)
-int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream) {
+// D = sum of tiles_touched and the geometry fingerprint (K1 leaves per-workgroup partial sums of both): asynchronous copy into
+// pinned memory; with sort_first, K2 -- depth sort + scan, which WRITE geom->offsets and geom->scan_temp -- is launched before
+// the host waits, so the device stays busy during the one unavoidable device->host sync.
+int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, uint64_t* fingerprint_out,
+                             int32_t sort_first, void* stream) {
     if (!geom || !host_out) return fail_msg("NULL argument");
     *host_out = 0;
+    if (fingerprint_out) *fingerprint_out = 0;
     if (num_gaussians <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RB_MAX_DEVICES) return fail_msg("hipGetDevice failed");
     Readback& g_rb = g_rb_dev[dev];
-    // K1 left one partial sum of tiles_touched per workgroup (no atomics, nothing to zero-fill): copy them, add them up here
-    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK;
-    if (g_rb.words < nblk) {
+    // K1 left three partial sums per workgroup (no atomics, nothing to zero-fill): copy them, add them up here
+    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK, nw = 3 * nblk;
+    if (g_rb.words < nw) {
         if (g_rb.host) (void)hipHostFree(g_rb.host);
         g_rb.host = nullptr;
-        g_rb.words = nblk < 4096 ? 4096 : nblk * 2;
+        g_rb.words = nw < 4096 ? 4096 : nw * 2;
         if (hipHostMalloc((void**)&g_rb.host, g_rb.words * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { g_rb.words = 0; return fail_msg("hipHostMalloc failed"); }
     }
     if (!g_rb.ev && hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming) != hipSuccess) return fail_msg("hipEventCreate failed");
-    hipError_t e = hipMemcpyAsync(g_rb.host, bin_block_sums_ptr(geom, num_gaussians), nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    hipError_t e = hipMemcpyAsync(g_rb.host, bin_block_sums_ptr(geom, num_gaussians), nw * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return fail("num_rendered readback", e);
     e = hipEventRecord(g_rb.ev, s);
     if (e != hipSuccess) return fail("num_rendered event", e);
-    TexGSFrame f0; memset(&f0, 0, sizeof(f0)); f0.num_gaussians = num_gaussians;
-    if (int r = depth_sort_scan(&f0, const_cast<TexGSGeom*>(geom), s)) return r;
+    if (sort_first) {
+        TexGSFrame f0; memset(&f0, 0, sizeof(f0)); f0.num_gaussians = num_gaussians;
+        if (int r = depth_sort_scan(&f0, const_cast<TexGSGeom*>(geom), s)) return r;
+    }
     e = hipEventSynchronize(g_rb.ev);
     if (e != hipSuccess) return fail("num_rendered sync", e);
     unsigned long long total = 0ull;
-    for (size_t k = 0; k < nblk; ++k) total += g_rb.host[k];
+    uint32_t fa = 0u, fb = 0u;
+    for (size_t k = 0; k < nblk; ++k) { total += g_rb.host[3 * k]; fa += g_rb.host[3 * k + 1]; fb += g_rb.host[3 * k + 2]; }
     if (total > 0xFFFFFFFFull) return fail_msg("num_rendered exceeds 2^32 - 1 instances");
     *host_out = (uint32_t)total;
+    if (fingerprint_out) *fingerprint_out = ((uint64_t)fb << 32) | (uint64_t)fa;
     return 0;
+}
+
+int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream) {
+    return texgs_read_num_rendered2(geom, num_gaussians, host_out, nullptr, 1, stream);
+}
+
+int texgs_depth_sort_scan(TexGSGeom* geom, int32_t num_gaussians, void* stream) {
+    if (!geom) return fail_msg("NULL argument");
+    TexGSFrame f0; memset(&f0, 0, sizeof(f0)); f0.num_gaussians = num_gaussians;
+    return depth_sort_scan(&f0, geom, (hipStream_t)stream);
 }
 
 static int render_forward_impl(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,

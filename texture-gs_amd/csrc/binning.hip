@@ -335,13 +335,13 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // ---- scratch layouts ------------------------------------------------------------------------------------------------
 // scan_temp (Gaussian level, sized by scan_temp_bytes(N)):
 //   [0]        header zero-filled by K1: 4 x gtable of the depth passes
-//   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)]), block_D (u32[ceil(N / 256)])
+//   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)]), block_D (u32[ceil(N / 256)][3])
 // sort_temp (instance level, sized by sort_temp_bytes(capacity, T)):
 //   [0]        header zero-filled by K3: 3 x gtable of the tile passes
 //   then       3 x table, elem_tmp (u64[capacity])
 struct GaussScratch {
     uint32_t* tables;       // 4 passes
-    uint32_t* block_D;      // [ceil(N / 256)] K1's per-workgroup sums of tiles_touched (the host adds them up: D)
+    uint32_t* block_D;      // [ceil(N / 256)][3] K1's per-workgroup sums {tiles_touched, fingerprint lo, hi} (the host adds them up)
     uint32_t *key_a, *key_b, *val_a, *val_b, *bsum;
     size_t header_bytes;
 };
@@ -380,7 +380,7 @@ inline void pass_geometry(uint32_t n, uint32_t& blocks, uint32_t& per) {
 size_t scan_temp_bytes(int N) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     return zero_header_bytes(4, 0) + align256(4 * (size_t)RS_MAX_BLOCKS * 256 * 4) + 4 * align256(n * 4)
-         + align256(((n + SC_PER - 1) / SC_PER) * 4 + 256) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * 4);
+         + align256(((n + SC_PER - 1) / SC_PER) * 4 + 256) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * 12);
 }
 
 constexpr int TILE_PASSES_MAX = 3;      // tile ids up to 2^24 in digits of at most 8 bits (the count / scatter kernels index 256-entry LDS tables)

@@ -338,7 +338,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_D,
                  uint32_t* __restrict__ zero_words, int num_zero_words) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
-    __shared__ uint32_t s_tt[TG_BLOCK / 64];
+    __shared__ uint32_t s_tt[3 * (TG_BLOCK / 64)];
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
     const bool live = i < C.N;
     for (int k = i; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // count tables of the depth sort (K2)
@@ -360,23 +360,27 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
         for (int k = threadIdx.x; k < count; k += TG_BLOCK) s_sh[k] = shs[first + k];
         __syncthreads();
     }
-    {   // D = sum of tiles_touched: one partial sum per workgroup; the host reads them back (while the depth sort runs) and adds
-        uint32_t tt = (live && g.valid) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
-        for (int d = 32; d >= 1; d >>= 1) tt += __shfl_xor(tt, d, 64);
-        if ((threadIdx.x & 63) == 0) s_tt[threadIdx.x >> 6] = tt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t sum = 0u;
-            for (int w = 0; w < TG_BLOCK / 64; ++w) sum += s_tt[w];
-            block_D[blockIdx.x] = sum;
-        }
+    // Two things leave this kernel as one partial sum per workgroup (no atomics, nothing to zero; the host reads them back while
+    // the depth sort runs and adds them up): D = sum of tiles_touched, and a 64-bit FINGERPRINT of what the tile binning, K6's
+    // survivor lists and its per-bin footprint counts are functions of -- depth bits, tile rect, the whole test record and the
+    // UV-Taylor part of the shading record of every Gaussian (view-dependent colour, depth and normal of the shading record do not
+    // enter).  A second forward of the same geometry (models/texture_gaussian3d.py:375-389: same camera, sh_degree 0) finds the
+    // same fingerprint and re-uses the first one's lists (texgs/rasterizer.py); two wrapping 32-bit sums of per-Gaussian hashes.
+    uint32_t tt = 0u, ha = 0u, hb = 0u;
+    if (live) {
+        ha = (uint32_t)i * 0x9E3779B1u + 0x85EBCA77u;
+        hb = ((uint32_t)i * 0xC2B2AE3Du) ^ 0x27D4EB2Fu;
     }
-    if (!live) return;
-    if (!g.valid) {
+    auto mix = [&](uint32_t w) {
+        ha = (ha ^ w) * 0x01000193u;
+        hb = __builtin_rotateleft32(hb ^ w, 13) * 5u + 0xE6546B64u;
+    };
+    if (live && !g.valid) {
         radii[i] = 0; tiles_touched[i] = 0; rect[i] = make_uint2(0u, 0u);
         depth[i] = __uint_as_float(0xFFFFFFFFu);   // sort key of a culled Gaussian: after every visible one
-        return;                                   // record left unwritten: never gathered (no instances)
+        mix(0xFFFFFFFFu);                          // record left unwritten: never gathered (no instances)
     }
+    if (live && g.valid) {
     // view-dependent colour: SH bands 1..deg at the (unit) view direction
     float vd[3] = {0.f, 0.f, 0.f};
     if (na > 0) {
@@ -392,9 +396,11 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     }
     if (coff) { vd[0] += coff[3 * i + 0]; vd[1] += coff[3 * i + 1]; vd[2] += coff[3 * i + 2]; }
     radii[i] = g.radius;
-    tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+    tt = (uint32_t)((x1 - x0) * (y1 - y0));
+    tiles_touched[i] = tt;
     depth[i] = g.t[2];
-    rect[i] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+    const uint2 rc = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+    rect[i] = rc;
     // The record is split by who reads it (render.hip): the TEST part (32 B) is fetched for every (8x8 block, instance) pair,
     // the SHADING part (80 B) only for instances that survive the block cull.
     // conic pre-scaled for the blend kernels' falloff exponent: power = ah dx^2 + bh dx dy + ch dy^2 (render.hip gauss_power)
@@ -406,15 +412,36 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     const float cmid = 0.5f * (g.a + g.c);
     const float clam = cmid + sqrtf(fmaxf(0.1f, cmid * cmid - g.det));
     const float rcull = (thr < 0.0f) ? (sqrtf(-2.0f * thr * clam) * 1.001f + 0.01f) : -1.0f;
+    const float4 t0 = make_float4(g.xy[0], g.xy[1], -0.5f * g.conic[0], -g.conic[1]);
+    const float4 t1 = make_float4(-0.5f * g.conic[2], op, rcull, thr);
+    const float4 s0 = make_float4(g.gx, g.gy, g.G[0], g.G[1]);
+    const float4 s1 = make_float4(g.G[2], g.G[3], g.G[4], g.G[5]);
+    const float4 s2 = uvs ? make_float4(uvs[3 * i + 0], uvs[3 * i + 1], uvs[3 * i + 2], vd[0]) : make_float4(0.f, 0.f, 1.f, vd[0]);
     float4* rt = rec_test + (size_t)i * (TEXGS_REC_TEST_FLOATS / 4);
-    rt[0] = make_float4(g.xy[0], g.xy[1], -0.5f * g.conic[0], -g.conic[1]);
-    rt[1] = make_float4(-0.5f * g.conic[2], op, rcull, thr);
+    rt[0] = t0; rt[1] = t1;
     float4* rs = rec_shade + (size_t)i * (TEXGS_REC_SHADE_FLOATS / 4);
-    rs[0] = make_float4(g.gx, g.gy, g.G[0], g.G[1]);
-    rs[1] = make_float4(g.G[2], g.G[3], g.G[4], g.G[5]);
-    rs[2] = uvs ? make_float4(uvs[3 * i + 0], uvs[3 * i + 1], uvs[3 * i + 2], vd[0]) : make_float4(0.f, 0.f, 1.f, vd[0]);
+    rs[0] = s0; rs[1] = s1; rs[2] = s2;
     rs[3] = make_float4(vd[1], vd[2], g.t[2], g.n[0]);
     rs[4] = make_float4(g.n[1], g.n[2], 0.f, 0.f);
+    mix(__float_as_uint(g.t[2])); mix(rc.x); mix(rc.y);
+    mix(__float_as_uint(t0.x)); mix(__float_as_uint(t0.y)); mix(__float_as_uint(t0.z)); mix(__float_as_uint(t0.w));
+    mix(__float_as_uint(t1.x)); mix(__float_as_uint(t1.y)); mix(__float_as_uint(t1.z)); mix(__float_as_uint(t1.w));
+    mix(__float_as_uint(s0.x)); mix(__float_as_uint(s0.y)); mix(__float_as_uint(s0.z)); mix(__float_as_uint(s0.w));
+    mix(__float_as_uint(s1.x)); mix(__float_as_uint(s1.y)); mix(__float_as_uint(s1.z)); mix(__float_as_uint(s1.w));
+    mix(__float_as_uint(s2.x)); mix(__float_as_uint(s2.y)); mix(__float_as_uint(s2.z));
+    }
+    // avalanche, then the three workgroup sums
+    ha ^= ha >> 15; ha *= 0x2C1B3C6Du; ha ^= ha >> 12;
+    hb ^= hb >> 16; hb *= 0x85EBCA6Bu; hb ^= hb >> 13;
+    if (!live) { ha = 0u; hb = 0u; }
+    for (int d = 32; d >= 1; d >>= 1) { tt += __shfl_xor(tt, d, 64); ha += __shfl_xor(ha, d, 64); hb += __shfl_xor(hb, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s_tt[threadIdx.x >> 6] = tt; s_tt[TG_BLOCK / 64 + (threadIdx.x >> 6)] = ha; s_tt[2 * (TG_BLOCK / 64) + (threadIdx.x >> 6)] = hb; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t sum = 0u;
+        for (int w = 0; w < TG_BLOCK / 64; ++w) sum += s_tt[threadIdx.x * (TG_BLOCK / 64) + w];
+        block_D[3 * blockIdx.x + threadIdx.x] = sum;          // {tiles_touched, fingerprint lo, fingerprint hi}
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K8

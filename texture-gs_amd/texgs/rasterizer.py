@@ -59,7 +59,30 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
     return t.contiguous()
 
 
+# Two forwards of the same geometry share the tile binning and K6's survivor lists (the reference renders every training view
+# twice: models/texture_gaussian3d.py:318 and :375-389 -- same camera, same Gaussians, sh_degree 0 the second time; visual_step
+# :499-511 likewise).  Decided by K1's geometry fingerprint (texgs.h texgs_read_num_rendered2), so recomputed activations
+# (sigmoid / exp outputs are new tensors on every render() call) share too.  One entry per (device, stream).
+GEOM_CACHE = _os.environ.get("TEXGS_GEOM_CACHE", "1") != "0"
+# A forward that autograd may or may not differentiate (retexture.py:27 / visual_step build a graph and never call backward)
+# leaves K6's hand-off to the backward once two graphs in a row were dropped unused; the first backward that does arrive
+# produces the hand-off itself (one more K6) and switches the forwards back.
+LAZY_HANDOFF = _os.environ.get("TEXGS_LAZY_HANDOFF", "1") != "0"
 _CAPACITY_HINT = {}
+_GEOM = {}                  # (device index, stream) -> _GeomEntry of the last forward that built lists there
+_UNUSED_STREAK = {}         # device index -> autograd forwards in a row whose state was dropped without a backward
+
+
+class _GeomEntry:
+    __slots__ = ("ints", "cam_key", "fingerprint", "D", "bin", "arenas", "handoff", "counts", "cap")
+
+
+def geometry_cache_stats():
+    """{'hits': n, 'misses': n} of the shared-geometry path since import (diagnostics / tests)."""
+    return dict(_GEOM_STATS)
+
+
+_GEOM_STATS = {"hits": 0, "misses": 0, "late_handoffs": 0}
 # Backward scratch, ONE entry per (device, HIP stream): the moment accumulators (grow-only, sliced [:N]; all-zero between
 # calls: K8 clears what it read) and the texture-gradient bins of the last resolution used on that stream.  A stream runs
 # its views in order, so its scratch is never shared by two views in flight.  release_scratch() drops entries (ViewPipeline
@@ -76,10 +99,11 @@ class _StreamScratch:
 
 
 def release_scratch(device=None, stream=None):
-    """Free the backward scratch cached for (device, stream); None = every device / every stream."""
-    for key in list(_SCRATCH):
-        if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == int(stream)):
-            del _SCRATCH[key]
+    """Free the backward scratch and the shared-geometry entry cached for (device, stream); None = every device / stream."""
+    for cache in (_SCRATCH, _GEOM):
+        for key in list(cache):
+            if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == int(stream)):
+                del cache[key]
 
 
 def scratch_bytes():
@@ -146,7 +170,16 @@ class _TexBins:
 class _State:
     """Everything one forward leaves behind for its backward (per call: no global scratch, two forwards may
     be alive before a backward, models/texture_gaussian3d.py:318,378,410)."""
-    __slots__ = ("frame", "inputs", "geom", "bin", "img", "tensors", "N", "K", "R", "H", "W", "D")
+    __slots__ = ("frame", "inputs", "geom", "bin", "img", "tensors", "N", "K", "R", "H", "W", "D", "cap", "tiles",
+                 "want_counts", "lazy", "backward_ran", "shared_geometry", "__weakref__")
+
+    def __del__(self):          # the forwards' hand-off predictor (LAZY_HANDOFF): was this autograd forward ever differentiated?
+        try:
+            if getattr(self, "lazy", False):
+                dev = self.tensors["keep"][0].device.index
+                _UNUSED_STREAK[dev] = 0 if self.backward_ran else _UNUSED_STREAK.get(dev, 0) + 1
+        except Exception:
+            pass
 
 
 def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
@@ -164,8 +197,10 @@ def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
 
 
 def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None,
-                for_backward=True, cov3D_precomp=None, count_bins=None):
+                for_backward=True, cov3D_precomp=None, count_bins=None, lazy=False):
     """Run K1..K6.  Returns (outputs, state).  No autograd here.
+
+    `lazy` (the autograd path sets it): the hand-off may be left to the backward (see LAZY_HANDOFF).
 
     `for_backward`: K6 leaves the per-block survivor lists its backward replays.  `count_bins` (default: for_backward and
     there is a texture): K6 also counts the texture-gradient footprints per texture bin (the exact list sizes of
@@ -231,6 +266,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     tiles = ((W + _lib.TILE - 1) // _lib.TILE) * ((H + _lib.TILE - 1) // _lib.TILE)
     stream = torch.cuda.current_stream(device).cuda_stream
     keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, cov3D_precomp]
+    handoff = bool(for_backward) and not (lazy and LAZY_HANDOFF and _UNUSED_STREAK.get(device.index, 0) >= 2)
+    want_counts = bool(count_bins and USE_TEX_BINS)
 
     with torch.cuda.device(device):
         frame = _make_frame(st, N, K, R, device, keep)
@@ -238,6 +275,13 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
                              _ptr(uvs), _ptr(gradient_uvs), _ptr(texture), _ptr(color_offset), _ptr(cov3D_precomp))
         i32, f32, u8 = torch.int32, torch.float32, torch.uint8
         n1 = max(N, 1)
+        # a forward that may share an earlier one's lists: same sizes, same camera tensors -- K1's fingerprint decides
+        gints = (N, H, W, R if texture is not None else 0, float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier),
+                 cov3D_precomp is not None)
+        cam_key = tuple((t.data_ptr(), t._version) for t in (st.viewmatrix, st.projmatrix, st.campos))
+        gkey = (device.index, int(stream))
+        entry = _GEOM.get(gkey) if GEOM_CACHE else None
+        candidate = entry is not None and entry.ints == gints and entry.cam_key == cam_key
         # Everything the kernels keep between forward and backward lives in TWO allocations (one sized by N / the image, one by
         # the instance capacity): ~20 separate torch.empty calls were ~0.1 ms of host time per view.  Tensor views of the
         # pieces are made on demand (tests, diagnostics).
@@ -252,26 +296,30 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         fix.add("scan_temp", (scan_bytes,), u8)
         fix.add("final_T", (H, W), f32)
         fix.add("n_contrib", (H, W), i32)
-        fix.add("ranges", (tiles, 2), i32)              # zero-filled by K3
-        fix.add("tile_order", (tiles,), i32)
-        if count_bins and USE_TEX_BINS:
-            fix.add("tex_bin_count", (int(lib.texgs_tex_bin_count(R)),), i32)
-        if for_backward:
-            fix.add("surv_count", (4 * tiles,), i32)
+
+        def add_lists(ar):              # per-tile pieces of the lists (the candidate path adds them only if it has to build lists)
+            ar.add("ranges", (tiles, 2), i32)              # zero-filled by K3
+            ar.add("tile_order", (tiles,), i32)
+            if want_counts and handoff:
+                ar.add("tex_bin_count", (int(lib.texgs_tex_bin_count(R)),), i32)
+            if handoff:
+                ar.add("surv_count", (4 * tiles,), i32)
+        if not candidate:
+            add_lists(fix)
         fix.commit()
         radii = torch.empty(N, dtype=i32, device=device)          # K1 writes every entry (0 for culled)
         geom = _lib.Geom(fix.ptr("rec"), fix.ptr("rec_shade"), fix.ptr("depth"), _ptr(radii), fix.ptr("rect"),
                          fix.ptr("tiles_touched"), fix.ptr("offsets"), fix.ptr("scan_temp"), scan_bytes)
         # everything is allocated BEFORE the one device->host sync, the D-sized buffers from a capacity hint
-        # (largest D seen on this device x 1.25): texgs_forward then runs K1 -> sync -> K3..K6 with no host work between
+        # (largest D seen on this device x 1.25): K1 -> sync (K2 runs meanwhile) -> K3..K6 with little host work between
         out_color = torch.empty(3, H, W, dtype=f32, device=device)
         out_depth = torch.empty(1, H, W, dtype=f32, device=device)
         out_norm = torch.empty(3, H, W, dtype=f32, device=device)
         out_alpha = torch.empty(1, H, W, dtype=f32, device=device)
         img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), fix.ptr("final_T"),
-                         fix.ptr("n_contrib"), fix.ptr("tex_bin_count"), None, None, fix.ptr("surv_count"))
+                         fix.ptr("n_contrib"), None, None, None, None)
 
-        def alloc_bin(cap):
+        def alloc_bin(cap, lists_ar):
             c1 = max(cap, 1)
             sort_bytes = lib.texgs_sort_temp_bytes(cap, tiles)
             ar = _Arena(device)
@@ -279,34 +327,110 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             ar.add("keys_sorted", (c1,), torch.int64)
             ar.add("point_list", (c1,), i32)
             ar.add("sort_temp", (sort_bytes,), u8)
-            if for_backward:        # K6 -> K7 hand-off of the per-block survivor lists: four blocks per tile, each at most the tile's list length
+            if lists_ar is None:
+                add_lists(ar)
+            if handoff:        # K6 -> K7 hand-off of the per-block survivor lists: four blocks per tile, each at most the tile's list length
                 ar.add("survivors", (4 * c1, 2), i32)
                 ar.add("surv_qmask", (4 * c1,), torch.int16)
             ar.commit()
-            b = _lib.Binning(0, ar.ptr("keys_unsorted"), ar.ptr("keys_sorted"), ar.ptr("point_list"), fix.ptr("ranges"),
-                             fix.ptr("tile_order"), ar.ptr("sort_temp"), sort_bytes)
+            la = lists_ar if lists_ar is not None else ar
+            b = _lib.Binning(0, ar.ptr("keys_unsorted"), ar.ptr("keys_sorted"), ar.ptr("point_list"), la.ptr("ranges"),
+                             la.ptr("tile_order"), ar.ptr("sort_temp"), sort_bytes)
+            img.tex_bin_count, img.surv_count = la.ptr("tex_bin_count"), la.ptr("surv_count")
             img.survivors, img.surv_qmask = ar.ptr("survivors"), ar.ptr("surv_qmask")
             return b, ar
         hint_key = (device.index, N, H, W)
         cap = _CAPACITY_HINT.get(hint_key, max(4 * N, 1024))
-        binning, bin_ar = alloc_bin(cap)
-        d_host = C.c_uint32(0)
-        rc = lib.texgs_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning), cap, C.byref(img),
-                               C.byref(d_host), stream)
-        D = int(d_host.value)
-        if rc == _lib.ERR_CAPACITY:             # rare: grow and run the second half
-            cap = int(D * 1.25) + 1024
-            binning, bin_ar = alloc_bin(cap)
+        binning = bin_ar = None
+        if not candidate:
+            binning, bin_ar = alloc_bin(cap, fix)
+        d_host, fp_host = C.c_uint32(0), C.c_uint64(0)
+        _lib.check(lib.texgs_preprocess_forward(C.byref(frame), C.byref(inputs), C.byref(geom), stream), "texgs_preprocess_forward")
+        _lib.check(lib.texgs_read_num_rendered2(C.byref(geom), N, C.byref(d_host), C.byref(fp_host), 0 if candidate else 1, stream),
+                   "texgs_read_num_rendered")
+        D, fp = int(d_host.value), int(fp_host.value)
+        shared = None
+        if candidate and fp == entry.fingerprint and D == entry.D:
+            # same geometry as the forward that built `entry`: its lists are this forward's lists; K6 alone, no hand-off work
+            _GEOM_STATS["hits"] += 1
+            shared = entry
+            binning = _lib.Binning(D, *entry.bin)
+            _lib.check(lib.texgs_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning), C.byref(img),
+                                                stream), "texgs_render_forward")
+            if for_backward and entry.handoff and (entry.counts or not want_counts):
+                img.survivors, img.surv_qmask, img.surv_count = entry.handoff
+                img.tex_bin_count = entry.counts if want_counts else None
+            cap = entry.cap
+        else:
+            _GEOM_STATS["misses"] += 1
+            if candidate:           # expected to share, cannot: build the lists after all (K2 was not started before the sync)
+                binning, bin_ar = alloc_bin(max(cap, int(D * 1.25) + 1024), None)
+                cap = max(cap, int(D * 1.25) + 1024)
+                _lib.check(lib.texgs_depth_sort_scan(C.byref(geom), N, stream), "texgs_depth_sort_scan")
+            elif D > cap:           # rare: grow
+                cap = int(D * 1.25) + 1024
+                binning, bin_ar = alloc_bin(cap, fix)
             binning.num_rendered = D
-            rc = lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
-                                                   C.byref(img), stream)
-        _lib.check(rc, "texgs_forward")
-        _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
+            _lib.check(lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
+                                                         C.byref(img), stream), "texgs_bin_sort_render_forward")
+            _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
+            if GEOM_CACHE:
+                e = _GeomEntry()
+                e.ints, e.cam_key, e.fingerprint, e.D, e.cap = gints, cam_key, fp, D, cap
+                e.bin = (binning.keys_unsorted, binning.keys_sorted, binning.point_list, binning.ranges, binning.tile_order,
+                         binning.sort_temp, binning.sort_temp_bytes)
+                e.arenas = (fix, bin_ar)
+                e.handoff = (img.survivors, img.surv_qmask, img.surv_count) if handoff else None
+                e.counts = img.tex_bin_count if handoff else None
+                _GEOM[gkey] = e
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
-    s.N, s.K, s.R, s.H, s.W, s.D = N, K, R, H, W, D
-    s.tensors = _Tensors((fix, bin_ar), keep=keep, radii=radii, out=(out_color, out_depth, out_norm, out_alpha))
+    s.N, s.K, s.R, s.H, s.W, s.D, s.cap, s.tiles = N, K, R, H, W, D, cap, tiles
+    s.want_counts, s.lazy, s.backward_ran, s.shared_geometry = want_counts, bool(lazy and for_backward), False, shared is not None
+    arenas = (fix,) + ((bin_ar,) if bin_ar is not None else ()) + (tuple(shared.arenas) if shared is not None else ())
+    s.tensors = _Tensors(arenas, keep=keep, radii=radii, out=(out_color, out_depth, out_norm, out_alpha))
+    if img.survivors is None:           # no hand-off in this state (forward-only call, lazy mode, or a shared entry without one)
+        s.tensors["survivors"] = None
+        s.tensors["surv_qmask"] = None
+        s.tensors["surv_count"] = None
+    if img.tex_bin_count is None:
+        s.tensors["tex_bin_count"] = None
+    s.tensors["for_backward"] = bool(for_backward)
     return (out_color, out_depth, out_norm, out_alpha, radii), s
+
+
+def _late_handoff(s: _State):
+    """The forward left no survivor lists (LAZY_HANDOFF, or lists shared from a forward that had none): produce them now with one
+    more K6 on the state's lists -- outputs into scratch (bit-identical to the forward's, which stay untouched)."""
+    lib = _lib.load()
+    device = s.tensors["keep"][0].device
+    stream = torch.cuda.current_stream(device).cuda_stream
+    i32, f32 = torch.int32, torch.float32
+    ar = _Arena(device)
+    ar.add("survivors", (4 * max(s.cap, 1), 2), i32)
+    ar.add("surv_qmask", (4 * max(s.cap, 1),), torch.int16)
+    ar.add("surv_count", (4 * s.tiles,), i32)
+    if s.want_counts:
+        ar.add("tex_bin_count", (int(lib.texgs_tex_bin_count(s.R)),), i32)
+    ar.add("scratch_out", (8, s.H, s.W), f32)
+    ar.add("final_T", (s.H, s.W), f32)
+    ar.add("n_contrib", (s.H, s.W), i32)
+    ar.commit()
+    so = ar.ptr("scratch_out")
+    hw = 4 * s.H * s.W
+    img = _lib.Image(so, so + 3 * hw, so + 4 * hw, so + 7 * hw, ar.ptr("final_T"), ar.ptr("n_contrib"), ar.ptr("tex_bin_count"),
+                     ar.ptr("survivors"), ar.ptr("surv_qmask"), ar.ptr("surv_count"))
+    _lib.check(lib.texgs_render_forward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin), C.byref(img), stream),
+               "texgs_render_forward (late hand-off)")
+    s.img.survivors, s.img.surv_qmask, s.img.surv_count = img.survivors, img.surv_qmask, img.surv_count
+    s.img.tex_bin_count = img.tex_bin_count
+    s.tensors._arenas = tuple(s.tensors._arenas) + (ar,)
+    for n in ("survivors", "surv_qmask", "surv_count", "tex_bin_count"):
+        s.tensors.pop(n, None)
+    if not s.want_counts:
+        s.tensors["tex_bin_count"] = None
+    _GEOM_STATS["late_handoffs"] += 1
+    _UNUSED_STREAK[device.index] = 0
 
 
 class _Arena:
@@ -368,7 +492,7 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     existing .grad) and writes the others into one fresh allocation; a texture sink is used the same way (dL_dtexture is
     always accumulated into).  Outputs written into a sink come back as None."""
     lib = _lib.load()
-    if s.tensors.get("survivors") is None:
+    if not s.tensors["for_backward"]:
         raise RuntimeError("this forward ran with for_backward=False (no survivor lists were kept): its backward cannot run")
     means3D = s.tensors["keep"][0]
     device = means3D.device
@@ -391,6 +515,9 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
     H, W = s.H, s.W
     dc, dd, dn, da = g(dL_dcolor, (3, H, W)), g(dL_ddepth, (1, H, W)), g(dL_dnorm, (3, H, W)), g(dL_dalpha, (1, H, W))
     with torch.cuda.device(device):
+        if s.img.survivors is None:
+            _late_handoff(s)
+        s.backward_ran = True
         skey = (device.index, int(stream))
         sc = _SCRATCH.pop(skey, None) or _StreamScratch()     # re-cached only after a successful call (an exception drops it)
         acc = None
@@ -500,7 +627,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         det = lambda t: None if t is None else t.detach()
         outs, state = forward_raw(st, means3D.detach(), det(shs), opacities.detach(), det(scales), det(rotations), det(uvs),
                                   det(gradient_uvs), det(texture), det(color_offset), for_backward=bool(want),
-                                  cov3D_precomp=det(cov3D_precomp), count_bins=bool(want & _lib.WANT_TEXTURE))
+                                  cov3D_precomp=det(cov3D_precomp), count_bins=bool(want & _lib.WANT_TEXTURE), lazy=True)
         color, depth, norm, alpha, radii = outs
         ctx.state = state
         # the backward re-reads the inputs through raw pointers (K8 recomputes geometry, K7 re-fetches texels): remember
