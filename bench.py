@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
                     help="HIP streams the views of a step are pipelined over (texgs.multiview.ViewPipeline); 1 = serial")
     ap.add_argument("--order", default=os.environ.get("TEXGS_BENCH_ORDER", "accumulate"), choices=["backward", "accumulate", "none"])
+    ap.add_argument("--surface", default="textured", choices=["textured", "diff_gauss"],
+                    help="diff_gauss = the untextured operator the reference's stages 1-2 call (render/render.py:75-84): same scene, "
+                         "colours from SH with DC, no texture (SURVEY 8f-1); reported as its own metric, not the headline")
     return ap.parse_args()
 
 
@@ -137,15 +140,21 @@ def main():
     K = 15
     scene = synth.make_scene(N, R, seed=0)
     cams = synth.fibonacci_cameras(args.num_views, W, H)
-    my_views = shard_views(args.num_views, rank, world)
+    my_views = shard_views(args.num_views, rank, world)          # (replaced below by cost-balanced sharding when world > 1)
     bg = torch.zeros(3, device=dev)
 
-    names = ["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
+    untextured = args.surface == "diff_gauss"
+    names = ["means3D", "shs", "opacities", "scales", "rotations"] + ([] if untextured else ["uvs", "texture"])
     leaves = {n: getattr(scene, n).to(dev).requires_grad_(with_bwd) for n in names}
+    if untextured:          # SH with the DC band first, as models/gaussian3d.py keeps them
+        leaves["shs"] = torch.cat([torch.zeros(N, 1, 3), scene.shs], 1).to(dev).requires_grad_(with_bwd)
     juv = scene.gradient_uvs.to(dev)
     means2D = torch.zeros(N, 3, device=dev, requires_grad=with_bwd)
-    params = [leaves[n] for n in names] + [means2D]
+    # the texture last: the flat gradient bucket is then two contiguous segments, [per-Gaussian | texture]
+    params = [leaves[n] for n in names if n != "texture"] + [means2D] + ([leaves["texture"]] if "texture" in leaves else [])
     bucket = GradBucket(params) if with_bwd else None
+    seg_tex = bucket.segment_of([leaves["texture"]]) if (with_bwd and "texture" in leaves) else None
+    seg_gauss = bucket.segment_of([p_ for p_ in params if p_ is not leaves.get("texture")]) if with_bwd else None
 
     def settings(cam):
         return GaussianRasterizationSettings(
@@ -154,7 +163,11 @@ def main():
             viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev), sh_degree=3,
             campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
     # fused gradient accumulation: the kernels add into the bucket slices (texgs.multiview), no AccumulateGrad pass
-    rasters = {v: GaussianRasterizer(settings(cams[v]), grad_sink=bucket) for v in my_views}
+    if untextured:
+        import diff_gauss as dg
+        rasters = {v: dg.GaussianRasterizer(settings(cams[v]), grad_sink=bucket) for v in my_views}
+    else:
+        rasters = {v: GaussianRasterizer(settings(cams[v]), grad_sink=bucket) for v in my_views}
 
     # fixed upstream gradients of the synthetic loss' shape: image, alpha, norm
     g = torch.Generator().manual_seed(1234)
@@ -165,6 +178,9 @@ def main():
     g_norm = (-0.1 * nh / nh.norm(dim=0, keepdim=True)).to(dev) / P
 
     def view_fwd(v):
+        if untextured:
+            return rasters[v](means3D=leaves["means3D"], means2D=means2D, shs=leaves["shs"], opacities=leaves["opacities"],
+                              scales=leaves["scales"], rotations=leaves["rotations"])
         return rasters[v](means3D=leaves["means3D"], means2D=means2D, shs=leaves["shs"],
                           opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
                           uvs=leaves["uvs"], gradient_uvs=juv, texture=leaves["texture"], extra_attrs=None)
@@ -172,6 +188,28 @@ def main():
     def view_bwd(out):
         torch.autograd.backward([out[0], out[3], out[2]], [g_img, g_alpha, g_norm])
 
+    if world > 1:
+        # views dealt by estimated cost instead of round-robin: one forward-only pass over every view gives its instance count D
+        # (what K6 / K7 time is proportional to); deterministic, so every rank computes the same partition
+        from texgs.multiview import lpt_shard_views
+        costs = []
+        with torch.no_grad():
+            for v in range(args.num_views):
+                st_v = settings(cams[v])
+                if untextured:
+                    _, s_v = forward_raw(st_v, leaves["means3D"].detach(), None, leaves["opacities"].detach(), leaves["scales"].detach(),
+                                         leaves["rotations"].detach(), None, None, None, for_backward=False)
+                else:
+                    _, s_v = forward_raw(st_v, leaves["means3D"].detach(), None, leaves["opacities"].detach(), leaves["scales"].detach(),
+                                         leaves["rotations"].detach(), leaves["uvs"].detach(), juv, leaves["texture"].detach(),
+                                         for_backward=False)
+                costs.append(s_v.D)
+        my_views = lpt_shard_views(costs, rank, world)
+        if untextured:
+            import diff_gauss as dg
+            rasters = {v: dg.GaussianRasterizer(settings(cams[v]), grad_sink=bucket) for v in my_views}
+        else:
+            rasters = {v: GaussianRasterizer(settings(cams[v]), grad_sink=bucket) for v in my_views}
     pipe = ViewPipeline(dev, depth=args.streams)
     pipe_serial = ViewPipeline(dev, depth=1)
     cursor = [0]
@@ -181,9 +219,17 @@ def main():
             bucket.zero()
         batch = [my_views[(cursor[0] + i) % len(my_views)] for i in range(args.views_per_step)]
         cursor[0] += args.views_per_step
-        p.run(batch, view_fwd, view_bwd if with_bwd else None, sink=bucket, order=args.order)
+        two = with_bwd and dist is not None and args.order == "accumulate" and seg_tex is not None
+        # the texture half of the bucket is all-reduced on a side stream as soon as the last view's texture-gradient reduce has been
+        # issued (it overlaps that view's K8 and the host's end-of-step work); the per-Gaussian half after the last K8
+        p.run(batch, view_fwd, view_bwd if with_bwd else None, sink=bucket, order=args.order,
+              texture_ready=(lambda evs: bucket.all_reduce_async(dist, seg_tex, after=evs, timing=True)) if two else None)
         if with_bwd and dist is not None:
-            bucket.all_reduce(dist)
+            if two:
+                bucket.all_reduce_async(dist, seg_gauss, timing=True)
+                bucket.wait()
+            else:
+                bucket.all_reduce(dist)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -208,6 +254,7 @@ def main():
     fence()
     t1 = time.perf_counter()
     kern_timed = _lib.profile_read()
+    comm = bucket.comm_timings() if (with_bwd and dist is not None) else []
     # the per-kernel table: two extra steps with every kernel group bracketed, views one after the other on one stream, so
     # that each duration is the kernel's own (in the pipelined region a kernel shares the GPU with other views' kernels)
     kern = dict(kern_timed)
@@ -241,9 +288,14 @@ def main():
     # ---- units of one representative launch (view my_views[0]), outside the timed region
     st0 = settings(cams[my_views[0]])
     with torch.no_grad():
-        outs, s = forward_raw(st0, leaves["means3D"].detach(), leaves["shs"].detach(), leaves["opacities"].detach(),
-                              leaves["scales"].detach(), leaves["rotations"].detach(), leaves["uvs"].detach(), juv,
-                              leaves["texture"].detach())
+        if untextured:
+            outs, s = forward_raw(st0, leaves["means3D"].detach(), leaves["shs"].detach()[:, 1:, :].contiguous(), leaves["opacities"].detach(),
+                                  leaves["scales"].detach(), leaves["rotations"].detach(), None, None, None,
+                                  color_offset=(0.28209479177387814 * leaves["shs"].detach()[:, 0, :]).contiguous())
+        else:
+            outs, s = forward_raw(st0, leaves["means3D"].detach(), leaves["shs"].detach(), leaves["opacities"].detach(),
+                                  leaves["scales"].detach(), leaves["rotations"].detach(), leaves["uvs"].detach(), juv,
+                                  leaves["texture"].detach())
         T = s.tensors["ranges"].shape[0]
         nc = s.tensors["n_contrib"].to(torch.int64)
         tx, ty = (W + 15) // 16, (H + 15) // 16
@@ -255,7 +307,7 @@ def main():
         if with_bwd:
             res = backward_raw(s, g_img, None, g_norm, g_alpha)
             n_touched = int((res[3].reshape(N, -1).abs().sum(1) > 0).sum())     # Gaussians that received a gradient
-            texels = int((res[7].abs().sum(-1) > 0).sum())
+            texels = 0 if untextured else int((res[7].abs().sum(-1) > 0).sum())
         else:
             texels = 0
     ab = algorithmic_bytes(N, K, s.D, D_eff, P, T, R, n_vis, n_touched, texels)
@@ -311,7 +363,8 @@ def main():
     # ---- the same workload through the reference-compatible call pattern: activation OUTPUTS as operator
     # inputs, a fresh non-leaf means2D per view, plain autograd (no grad_sink) -- what render/uv_tex_render.py does.
     compat = None
-    if rank == 0 and with_bwd and not args.no_kernel_table:
+    ref_iter = None
+    if rank == 0 and with_bwd and not args.no_kernel_table and not untextured:
         raw = {n: leaves[n].detach().clone().requires_grad_(True) for n in names}
         raw["scales"] = leaves["scales"].detach().log().requires_grad_(True)
         op = leaves["opacities"].detach().clamp(1e-6, 1 - 1e-6)
@@ -339,7 +392,72 @@ def main():
         compat = {"views_per_s": round(nv / (time.perf_counter() - c0), 2), "views": nv,
                   "note": "one view per call through autograd: sigmoid/exp/normalize activations + their backward, fresh "
                           "means2D, AccumulateGrad of every gradient (no fused sink); measured after the timed region"}
+
+        # ---- the reference's ITERATION after iteration 10 000 (models/texture_gaussian3d.py:318, 375-389, 410): render at the active
+        # degree, render AGAIN at sh_degree 0 (lambda_no_sh: same camera, same Gaussians, activations recomputed by the getters),
+        # one backward of both losses.  With the shared-geometry path the second render is K1 + K6 on the first one's lists.
+        from texgs import rasterizer as RZ
+        st_pairs = {v: (compat_settings[v], compat_settings[v]._replace(sh_degree=0)) for v in compat_settings}
+
+        def ref_iteration(v):
+            outs = []
+            for st_ in st_pairs[v]:
+                m2 = torch.zeros_like(raw["means3D"], requires_grad=True) + 0
+                m2.retain_grad()
+                outs.append(GaussianRasterizer(st_)(
+                    means3D=raw["means3D"], means2D=m2, shs=raw["shs"], opacities=torch.sigmoid(raw["opacities"]),
+                    scales=torch.exp(raw["scales"]), rotations=torch.nn.functional.normalize(raw["rotations"]),
+                    uvs=raw["uvs"], gradient_uvs=juv, texture=raw["texture"], extra_attrs=None))
+            torch.autograd.backward([outs[0][0], outs[0][3], outs[0][2], outs[1][0]], [g_img, g_alpha, g_norm, 2.0 * g_img])
+        ref_iter = {}
+        saved_gc = RZ.GEOM_CACHE
+        for label, on in (("separate_geometry", False), ("shared_geometry", True)):
+            RZ.GEOM_CACHE = on
+            RZ.release_scratch(dev)
+            vs = list(compat_settings)[:nv]
+            for v in vs[:3]:
+                ref_iteration(v)
+            torch.cuda.synchronize(dev)
+            c0 = time.perf_counter()
+            for v in vs:
+                ref_iteration(v)
+            torch.cuda.synchronize(dev)
+            ref_iter[label + "_ms_per_iteration"] = round(1e3 * (time.perf_counter() - c0) / len(vs), 4)
+        RZ.GEOM_CACHE = saved_gc
+        ref_iter["iterations"] = nv
+        ref_iter["note"] = ("2 renders (sh_degree 3, then 0) + 1 backward per iteration through plain autograd, one view per iteration; "
+                            "shared = the second render re-uses the first one's tile / survivor lists (K1 geometry fingerprint)")
         del raw
+
+    # ---- forward-only callers that build a graph (retexture.py:27, visual_step: parameters require grad, backward never runs)
+    retex = None
+    if rank == 0 and not with_bwd and not args.no_kernel_table and not untextured:
+        from texgs import rasterizer as RZ
+        saved_gc = RZ.GEOM_CACHE
+        RZ.GEOM_CACHE = False               # (every frame here is a different view anyway)
+        vs = my_views[:min(32, len(my_views))]
+        res = {}
+        for label, rg in (("no_grad_inputs", False), ("inputs_require_grad", True)):
+            lv = {n: leaves[n].detach().clone().requires_grad_(rg) for n in names}
+
+            def frame_(v):
+                out = GaussianRasterizer(settings(cams[v]))(means3D=lv["means3D"], means2D=None, shs=lv["shs"], opacities=lv["opacities"],
+                                                            scales=lv["scales"], rotations=lv["rotations"], uvs=lv["uvs"],
+                                                            gradient_uvs=juv, texture=lv["texture"], extra_attrs=None)
+                return out[0]
+            for v in vs[:4]:
+                frame_(v)
+            torch.cuda.synchronize(dev)
+            c0 = time.perf_counter()
+            for v in vs:
+                frame_(v)
+            torch.cuda.synchronize(dev)
+            res[label + "_views_per_s"] = round(len(vs) / (time.perf_counter() - c0), 1)
+        RZ.GEOM_CACHE = saved_gc
+        res["ratio"] = round(res["inputs_require_grad_views_per_s"] / res["no_grad_inputs_views_per_s"], 4)
+        res["note"] = ("views one after the other on one stream, a new rasterizer module per frame as render/uv_tex_render.py:40 builds; "
+                       "with inputs that require grad the forward leaves K6's hand-off to a backward that never comes (LAZY_HANDOFF)")
+        retex = res
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -347,8 +465,9 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "fwd+bwd views/sec @800x800, 300k Gaussians + 1024^2 texture; HBM GB/s vs roofline"
-                      if args.workload == "c3" else f"{mode} views/sec ({args.workload})",
+            "metric": ("fwd+bwd views/sec @800x800, 300k Gaussians + 1024^2 texture; HBM GB/s vs roofline"
+                       if args.workload == "c3" else f"{mode} views/sec ({args.workload})") if not untextured
+                      else f"{mode} views/sec ({args.workload}, untextured diff_gauss surface)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -356,12 +475,19 @@ def main():
                        "views_per_step_per_gpu": args.views_per_step, "global_views_per_step": args.views_per_step * world,
                        "num_rendered_D": s.D, "D_eff": D_eff, "parallelism": f"views sharded dp{world}",
                        "view_pipeline": f"{args.streams} HIP streams, order={args.order}" if args.streams > 1 else "serial",
+                       "view_sharding": "LPT by per-view instance count D" if world > 1 else "all views on the one GPU",
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal)")
-                                          + " SUM of one flat f32 bucket per step") if world > 1 else "none (1 GPU)"},
+                                          + " SUM of one flat f32 bucket per step, as two segments on a side stream "
+                                            "(texture after the last reduce kernel, per-Gaussian after the last K8)") if (world > 1 or force_dist) else "none (1 GPU)",
+                       "grad_allreduce_measured": ({"collectives_timed": len(comm), "bytes_per_step": int(sum(b for b, _ in comm) / max(args.steps, 1)),
+                                                    "ms_per_step_on_comm_stream": round(sum(m for _, m in comm) / max(args.steps, 1), 4),
+                                                    "world": world} if comm else None)},
             "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
             "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4),
                                         "source": "torch.cuda.Event per step on the op's stream, this rank"},
             "reference_call_pattern": compat,
+            "reference_iteration": ref_iter,
+            "retexture_pattern": retex,
             "alg_bytes_per_view": view_bytes,
             "pipeline_GBps": round(view_bytes * value / world / 1e9, 2),
             "pipeline_frac_of_hbm_peak": round(view_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),

@@ -5,6 +5,7 @@ import os
 import sys
 
 import pytest
+import numpy as np
 import torch
 import torch.multiprocessing as mp
 
@@ -277,3 +278,128 @@ def test_view_pipeline_ordering_with_recorded_streams(monkeypatch):
     with pytest.raises(RuntimeError):
         make(2).run(range(3), lambda v: v, lambda v: (_ for _ in ()).throw(RuntimeError("boom")), sink=snk, order="accumulate")
     assert snk.before_accumulate is None and log[-2:] == [("wait_stream", "main", "s0"), ("wait_stream", "main", "s1")]
+
+
+def test_lpt_shard_views_balances_and_partitions():
+    from texgs.multiview import lpt_shard_views
+    g = np.random.RandomState(0)
+    costs = list(g.randint(500_000, 1_600_000, size=64))
+    world = 8
+    parts = [lpt_shard_views(costs, r, world) for r in range(world)]
+    assert sorted(v for p in parts for v in p) == list(range(64))            # a partition
+    assert all(len(p) == 8 for p in parts)                                   # same number of views (collectives) per rank
+    loads = [sum(costs[v] for v in p) for p in parts]
+    rr = [sum(costs[v] for v in range(r, 64, world)) for r in range(world)]
+    assert max(loads) <= max(rr) and max(loads) / (sum(loads) / world) < 1.03   # better than round-robin, within 3 % of perfect
+    assert lpt_shard_views(costs, 3, world) == parts[3]                       # deterministic
+    assert [len(lpt_shard_views(costs[:10], r, 4)) for r in range(4)] == [3, 3, 2, 2]
+    with pytest.raises(ValueError):
+        lpt_shard_views(costs[:3], 0, 4)
+
+
+def _two_segment_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from texgs.multiview import GradBucket
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        a = torch.zeros(7, 3, requires_grad=True); b = torch.zeros(11, requires_grad=True); t = torch.zeros(2, 4, 4, 3, requires_grad=True)
+        bk = GradBucket([a, b, t])
+        vals = torch.randn(world, bk.flat.numel(), generator=g)
+        bk.flat.copy_(vals[rank])
+        seg_t, seg_g = bk.segment_of([t]), bk.segment_of([a, b])
+        assert seg_g == (0, 32) and seg_t == (32, 96)
+        bk.all_reduce_async(dist, seg_t)          # same order on every rank: texture first, then the rest
+        bk.all_reduce_async(dist, seg_g)
+        out = bk.wait().clone()
+        q.put((rank, bool(torch.allclose(out, vals.sum(0))), bool(torch.equal(t.grad.reshape(-1), out[32:]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_segment_allreduce_two_ranks_equals_the_sum():
+    """GradBucket.all_reduce_async on the texture segment and on the per-Gaussian segment (gloo, 2 ranks): together the whole
+    bucket is summed over the ranks, .grad views see it, segments must be runs of adjacent registered parameters."""
+    import torch.multiprocessing as mp
+    from texgs.multiview import GradBucket
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 431
+    ps = [ctx.Process(target=_two_segment_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p_ in ps:
+        p_.join(60)
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] and r[2] for r in res)
+    a = torch.zeros(3, requires_grad=True); b = torch.zeros(3, requires_grad=True); c = torch.zeros(3, requires_grad=True)
+    with pytest.raises(ValueError):
+        GradBucket([a, b, c]).segment_of([a, c])                              # not adjacent
+
+
+def test_texture_ready_hook_fires_once_between_the_last_render_and_its_accumulate(monkeypatch):
+    """The two-bucket protocol with recorded fake streams: every view's backward records a 'render done' event on its stream
+    between K7 + reduce and K8; the LAST view's hook hands texture_ready one event per stream (the latest of each), before that
+    view's wait for the previous K8 -- so the texture all-reduce can start while the last K8 is still to come."""
+    import contextlib
+    import texgs.multiview as MV
+    log = []
+
+    class FakeEvent:
+        n = 0
+
+        def __init__(self):
+            FakeEvent.n += 1
+            self.id = FakeEvent.n
+
+        def record(self, stream):
+            log.append(("record", stream.name, self.id))
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_stream(self, other):
+            log.append(("wait_stream", self.name, other.name))
+
+        def wait_event(self, ev):
+            log.append(("wait_event", self.name, ev.id))
+    main = FakeStream("main")
+    current = [main]
+
+    @contextlib.contextmanager
+    def fake_stream_ctx(s):
+        current.append(s)
+        try:
+            yield
+        finally:
+            current.pop()
+    monkeypatch.setattr(MV.torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(MV.torch.cuda, "stream", fake_stream_ctx)
+    monkeypatch.setattr(MV.torch.cuda, "current_stream", lambda dev=None: current[-1])
+    p = MV.ViewPipeline.__new__(MV.ViewPipeline)
+    p.device = torch.device("cpu")
+    p.streams = [FakeStream(f"s{k}") for k in range(3)]
+
+    class Sink:
+        before_accumulate = None
+    snk = Sink()
+
+    def bwd(v):
+        log.append(("bwd_render", current[-1].name, v))
+        snk.before_accumulate()
+        log.append(("bwd_accumulate", current[-1].name, v))
+    ready = []
+    p.run(range(5), lambda v: v, bwd, sink=snk, order="accumulate",
+          texture_ready=lambda evs: (ready.append([e.id for e in evs]), log.append(("texture_ready", current[-1].name, len(evs)))))
+    assert len(ready) == 1 and len(ready[0]) == 3                           # once, one event per stream
+    i = log.index(("texture_ready", "s1", 3))                               # view 4 runs on stream 4 % 3 = 1
+    assert log[i - 2] == ("bwd_render", "s1", 4) and log[i - 1][0] == "record" and log[i - 1][1] == "s1"
+    assert log[i + 1][0] == "wait_event" and log[i + 2] == ("bwd_accumulate", "s1", 4)
+    # the events handed over are the LATEST render-done event of each stream: views 2 (s2), 3 (s0), 4 (s1)
+    rec = {e[2]: e[1] for e in log if e[0] == "record"}
+    assert sorted(rec[e] for e in ready[0]) == ["s0", "s1", "s2"]
+    done_ids = [log[k + 1][2] for k, e in enumerate(log) if e[0] == "bwd_render"]       # the record right after every render
+    assert set(ready[0]) == {done_ids[2], done_ids[3], done_ids[4]}
+    assert snk.before_accumulate is None

@@ -18,9 +18,10 @@ SH_C0 = 0.28209479177387814
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, grad_sink=None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.grad_sink = grad_sink          # optional texgs.multiview.GradBucket (fused multi-view accumulation; not reference API)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3Ds_precomp=None, extra_attrs=None):
@@ -45,6 +46,6 @@ class GaussianRasterizer(nn.Module):
         else:
             offset = colors_precomp - 0.5
         color, depth, norm, alpha, radii = _RasterizeGaussians.apply(
-            means3D, means2D, rest, opacities, scales, rotations, None, None, None, st, offset.contiguous(), None,
+            means3D, means2D, rest, opacities, scales, rotations, None, None, None, st, offset.contiguous(), self.grad_sink,
             cov3Ds_precomp)
         return color, depth, norm, alpha, radii, None

@@ -4,8 +4,12 @@ replicated, ONE collective per step -- an all-reduce (SUM) of a single flat fp32
 GPU); this is the data-parallel layer the north star adds around the operator, nothing more.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ~143 MB bucket all-reduced once per 8-view step costs
-O(1 ms) against O(10 ms) of rendering, so no overlap machinery is needed; the bucket is flat so RCCL sees one
-large message instead of eight small ones.
+O(1-2 ms) against O(10 ms) of rendering.  The bucket is flat so RCCL sees large messages, and it is reduced as TWO
+segments on a side stream (GradBucket.all_reduce_async): the texture gradient (half the bytes) as soon as the last
+view's texture-gradient reduce kernel has been issued -- it then overlaps the remaining K8 launches and the host's
+end-of-step work --, the per-Gaussian gradients after the last K8; the compute stream waits for both only before the
+gradients are read (GradBucket.wait).  Views are dealt to ranks by estimated cost (lpt_shard_views), not round-robin:
+the step ends with the slowest rank.
 """
 from typing import List, Sequence
 
@@ -20,6 +24,28 @@ def shard_views(num_views: int, rank: int, world: int) -> List[int]:
     if not views:
         raise ValueError(f"rank {rank} gets no view: {num_views} views over {world} ranks")
     return views
+
+
+def lpt_shard_views(costs: Sequence[float], rank: int, world: int) -> List[int]:
+    """Longest-processing-time-first sharding: views sorted by estimated cost (e.g. the instance count D of the view's last
+    render: K6 / K7 time is proportional to it) are dealt, most expensive first, to the rank with the smallest load so far.
+    Deterministic (ties by view index), every view belongs to exactly one rank, every rank gets the same NUMBER of views
+    when num_views is a multiple of world (the ranks of a step must issue the same number of collectives and the driver's
+    bench counts views)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    n = len(costs)
+    if n < world:
+        raise ValueError(f"{n} views over {world} ranks")
+    order = sorted(range(n), key=lambda v: (-float(costs[v]), v))
+    quota = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    load = [0.0] * world
+    mine = [[] for _ in range(world)]
+    for v in order:
+        r = min((r for r in range(world) if len(mine[r]) < quota[r]), key=lambda r: (load[r], r))
+        mine[r].append(v)
+        load[r] += float(costs[v])
+    return sorted(mine[rank])
 
 
 class GradBucket:
@@ -87,6 +113,74 @@ class GradBucket:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
                 p.grad = self.flat[off:off + n].view_as(p)
 
+    def segment_of(self, tensors) -> tuple:
+        """(offset, count) of the contiguous run of the flat buffer that backs `tensors` (registered parameters that are adjacent
+        in the order the bucket was built with) -- e.g. the texture as one segment and everything else as the other."""
+        idx = sorted(i for i, p in enumerate(self.params) if any(p is t for t in tensors))
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError("the tensors of a segment must be registered parameters that are adjacent in the bucket")
+        off = self.slices[idx[0]][0]
+        return off, self.slices[idx[-1]][0] + self.slices[idx[-1]][1] - off
+
+    def all_reduce_async(self, dist, segment=None, after=(), timing=False):
+        """Issue the SUM all-reduce of `segment` = (offset, count) of the flat buffer (default: all of it) on the bucket's side
+        stream, ordered after the current stream's work so far and after the events in `after`; returns immediately.  Collectives
+        are issued in call order on that one stream, so every rank must call this in the same order.  wait() joins.
+        Backend "nccl" (= RCCL): in place on the device buffer.  Any other backend (gloo: the CPU tests, and the single-GPU
+        rehearsal where two ranks share a device) cannot run asynchronously: the segment is reduced here and now through a host copy."""
+        off, n = segment if segment is not None else (0, self.flat.numel())
+        buf = self.flat[off:off + n]
+        if dist.get_backend() != "nccl" or not self.flat.is_cuda:
+            for ev in after:                    # (other streams' texture-gradient kernels: the host copy must see their sums)
+                ev.synchronize()
+            self._reduce_now(dist, buf)
+            return self
+        cur = torch.cuda.current_stream(self.flat.device)
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(self.flat.device)
+            self._comm_events = []
+        self._comm.wait_stream(cur)
+        for ev in after:
+            self._comm.wait_event(ev)
+        with torch.cuda.stream(self._comm):
+            e0 = e1 = None
+            if timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self._comm)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if timing:
+                e1.record(self._comm)
+                self._comm_events.append((n * 4, e0, e1))
+        self._pending = True
+        return self
+
+    def wait(self):
+        """Make the current stream wait for every all-reduce issued with all_reduce_async (before the optimizer / zero())."""
+        if getattr(self, "_pending", False):
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
+            self._pending = False
+        return self.flat
+
+    def comm_timings(self):
+        """[(bytes, milliseconds)] of the timed asynchronous all-reduces so far (synchronises their events); clears the list."""
+        out = []
+        for nbytes, e0, e1 in getattr(self, "_comm_events", []):
+            e1.synchronize()
+            out.append((nbytes, e0.elapsed_time(e1)))
+        if getattr(self, "_comm_events", None):
+            self._comm_events.clear()
+        return out
+
+    def _reduce_now(self, dist, buf):
+        if buf.is_cuda:
+            host = torch.empty(buf.shape, dtype=torch.float32).pin_memory()
+            host.copy_(buf, non_blocking=True)
+            torch.cuda.current_stream(buf.device).synchronize()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host, non_blocking=True)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
     def all_reduce(self, dist, average_over: int = 0):
         """SUM over ranks (one collective).  average_over > 0 divides by that count afterwards (mean-of-views).
 
@@ -150,17 +244,29 @@ class ViewPipeline:
         except Exception:
             pass
 
-    def run(self, views, forward_fn, backward_fn=None, sink=None, order="accumulate"):
-        """order (what of view i+1 waits for view i when both add into `sink`):
+    def run(self, views, forward_fn, backward_fn=None, sink=None, order="accumulate", texture_ready=None):
+        """`texture_ready(events)` (optional, needs a GradBucket sink and order="accumulate"): called ONCE, from inside the last
+        view's backward, between its K7 + texture-gradient reduce and its K8 -- the point where every view's contribution to
+        dL/dtexture has been issued; `events` = one event per stream, recorded after that stream's latest K7 + reduce.  The caller
+        starts the texture segment's all-reduce there (GradBucket.all_reduce_async(..., after=events)).
+
+        order (what of view i+1 waits for view i when both add into `sink`):
         "backward"   -- its whole backward (works with any gradient path, e.g. plain autograd accumulation);
         "accumulate" -- only its accumulating kernel K8, through sink.before_accumulate (needs a GradBucket sink);
         "none"       -- nothing: every stream accumulates into its own replica of the bucket, folded at the end."""
         results = []
+        views = list(views)
         if not self.streams:                       # depth 1: the caller's stream, nothing to order
-            for v in views:
+            for i, v in enumerate(views):
                 obj = forward_fn(v)
                 if backward_fn is not None:
-                    backward_fn(obj)
+                    if texture_ready is not None and sink is not None and i == len(views) - 1:
+                        sink.before_accumulate = lambda: texture_ready([])
+                    try:
+                        backward_fn(obj)
+                    finally:
+                        if sink is not None:
+                            sink.before_accumulate = None
                 results.append(obj)
             return results
         if order not in ("backward", "accumulate", "none"):
@@ -171,6 +277,7 @@ class ViewPipeline:
         for s in self.streams:
             s.wait_stream(cur)
         prev_bwd = None
+        render_done = {}                            # stream index -> event after that stream's latest K7 + texture-gradient reduce
         try:
             for i, v in enumerate(views):
                 k = i % len(self.streams)
@@ -183,8 +290,18 @@ class ViewPipeline:
                         if order == "backward" and prev_bwd is not None:
                             s.wait_event(prev_bwd)
                         if order == "accumulate":
-                            sink.before_accumulate = (lambda ev=prev_bwd, s=s: s.wait_event(ev)) if prev_bwd is not None \
-                                else (lambda: None)
+                            last = i == len(views) - 1
+
+                            def hook(ev=prev_bwd, s=s, k=k, last=last):
+                                if texture_ready is not None:
+                                    e = torch.cuda.Event()
+                                    e.record(s)
+                                    render_done[k] = e
+                                    if last:
+                                        texture_ready([render_done[j] for j in sorted(render_done)])
+                                if ev is not None:
+                                    s.wait_event(ev)
+                            sink.before_accumulate = hook
                         backward_fn(obj)
                         prev_bwd = torch.cuda.Event()
                         prev_bwd.record(s)
