@@ -479,8 +479,9 @@ def main():
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal)")
                                           + " SUM of one flat f32 bucket per step, as two segments on a side stream "
                                             "(texture after the last reduce kernel, per-Gaussian after the last K8)") if (world > 1 or force_dist) else "none (1 GPU)",
-                       "grad_allreduce_measured": ({"collectives_timed": len(comm), "bytes_per_step": int(sum(b for b, _ in comm) / max(args.steps, 1)),
-                                                    "ms_per_step_on_comm_stream": round(sum(m for _, m in comm) / max(args.steps, 1), 4),
+                       "grad_allreduce_measured": ({"collectives_timed": len(comm), "steps_timed": len(comm) // 2,
+                                                    "bytes_per_step": int(sum(b for b, _ in comm) / max(len(comm) // 2, 1)),
+                                                    "ms_per_step_on_comm_stream": round(sum(m for _, m in comm) / max(len(comm) // 2, 1), 4),
                                                     "world": world} if comm else None)},
             "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
             "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4),

@@ -70,7 +70,22 @@ GEOM_CACHE = _os.environ.get("TEXGS_GEOM_CACHE", "1") != "0"
 LAZY_HANDOFF = _os.environ.get("TEXGS_LAZY_HANDOFF", "1") != "0"
 _CAPACITY_HINT = {}
 _GEOM = {}                  # (device index, stream) -> _GeomEntry of the last forward that built lists there
-_UNUSED_STREAK = {}         # device index -> autograd forwards in a row whose state was dropped without a backward
+# the hand-off predictor: autograd forwards are numbered; per device, the highest number whose backward ran and the numbers of
+# those dropped without one.  (Order-independent: a state that the garbage collector frees late cannot reset the streak.)
+_SERIAL = [0]
+_LAST_DIFFERENTIATED = {}
+_DROPPED = {}
+
+
+def unused_streak(dev_index):
+    """Autograd forwards on this device that were dropped without a backward since the last one that was differentiated."""
+    last = _LAST_DIFFERENTIATED.get(dev_index, -1)
+    return sum(1 for n in _DROPPED.get(dev_index, ()) if n > last)
+
+
+def reset_handoff_predictor():
+    _LAST_DIFFERENTIATED.clear()
+    _DROPPED.clear()
 
 
 class _GeomEntry:
@@ -171,13 +186,14 @@ class _State:
     """Everything one forward leaves behind for its backward (per call: no global scratch, two forwards may
     be alive before a backward, models/texture_gaussian3d.py:318,378,410)."""
     __slots__ = ("frame", "inputs", "geom", "bin", "img", "tensors", "N", "K", "R", "H", "W", "D", "cap", "tiles",
-                 "want_counts", "lazy", "backward_ran", "shared_geometry", "__weakref__")
+                 "want_counts", "lazy", "backward_ran", "shared_geometry", "serial", "__weakref__")
 
     def __del__(self):          # the forwards' hand-off predictor (LAZY_HANDOFF): was this autograd forward ever differentiated?
         try:
-            if getattr(self, "lazy", False):
+            if getattr(self, "lazy", False) and not self.backward_ran:
                 dev = self.tensors["keep"][0].device.index
-                _UNUSED_STREAK[dev] = 0 if self.backward_ran else _UNUSED_STREAK.get(dev, 0) + 1
+                last = _LAST_DIFFERENTIATED.get(dev, -1)
+                _DROPPED[dev] = [n for n in _DROPPED.get(dev, []) if n > last][-8:] + [self.serial]
         except Exception:
             pass
 
@@ -266,7 +282,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     tiles = ((W + _lib.TILE - 1) // _lib.TILE) * ((H + _lib.TILE - 1) // _lib.TILE)
     stream = torch.cuda.current_stream(device).cuda_stream
     keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, cov3D_precomp]
-    handoff = bool(for_backward) and not (lazy and LAZY_HANDOFF and _UNUSED_STREAK.get(device.index, 0) >= 2)
+    handoff = bool(for_backward) and not (lazy and LAZY_HANDOFF and unused_streak(device.index) >= 2)
     want_counts = bool(count_bins and USE_TEX_BINS)
 
     with torch.cuda.device(device):
@@ -387,8 +403,12 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D, s.cap, s.tiles = N, K, R, H, W, D, cap, tiles
     s.want_counts, s.lazy, s.backward_ran, s.shared_geometry = want_counts, bool(lazy and for_backward), False, shared is not None
+    _SERIAL[0] += 1
+    s.serial = _SERIAL[0]
     arenas = (fix,) + ((bin_ar,) if bin_ar is not None else ()) + (tuple(shared.arenas) if shared is not None else ())
-    s.tensors = _Tensors(arenas, keep=keep, radii=radii, out=(out_color, out_depth, out_norm, out_alpha))
+    # (NOT the output tensors: autograd hangs its node on them, the node holds this state -- a cycle that kept every dropped
+    #  graph's buffers alive until the garbage collector ran)
+    s.tensors = _Tensors(arenas, keep=keep, radii=radii)
     if img.survivors is None:           # no hand-off in this state (forward-only call, lazy mode, or a shared entry without one)
         s.tensors["survivors"] = None
         s.tensors["surv_qmask"] = None
@@ -430,7 +450,6 @@ def _late_handoff(s: _State):
     if not s.want_counts:
         s.tensors["tex_bin_count"] = None
     _GEOM_STATS["late_handoffs"] += 1
-    _UNUSED_STREAK[device.index] = 0
 
 
 class _Arena:
@@ -518,6 +537,8 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
         if s.img.survivors is None:
             _late_handoff(s)
         s.backward_ran = True
+        if s.lazy:
+            _LAST_DIFFERENTIATED[device.index] = max(_LAST_DIFFERENTIATED.get(device.index, -1), s.serial)
         skey = (device.index, int(stream))
         sc = _SCRATCH.pop(skey, None) or _StreamScratch()     # re-cached only after a successful call (an exception drops it)
         acc = None
@@ -624,10 +645,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             | (_lib.WANT_GAUSSIANS if any(nig[_ARG[n]] for n in _GAUSSIAN_ARGS) else 0)
         ctx.want = want
         ctx.nargs = len(ctx.needs_input_grad)
-        det = lambda t: None if t is None else t.detach()
-        outs, state = forward_raw(st, means3D.detach(), det(shs), opacities.detach(), det(scales), det(rotations), det(uvs),
-                                  det(gradient_uvs), det(texture), det(color_offset), for_backward=bool(want),
-                                  cov3D_precomp=det(cov3D_precomp), count_bins=bool(want & _lib.WANT_TEXTURE), lazy=True)
+        # (autograd does not record inside Function.forward: the inputs go in as they are, no detach() copies of the tensor objects)
+        outs, state = forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset,
+                                  for_backward=bool(want), cov3D_precomp=cov3D_precomp,
+                                  count_bins=bool(want & _lib.WANT_TEXTURE), lazy=True)
         color, depth, norm, alpha, radii = outs
         ctx.state = state
         # the backward re-reads the inputs through raw pointers (K8 recomputes geometry, K7 re-fetches texels): remember
