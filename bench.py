@@ -319,17 +319,26 @@ def main():
     dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"]) if kinfo else None        # every group launches once per view
     roofline = None
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")      # PMC pass of the same command (scripts/prof.sh)
-    if dom and args.workload == "c3" and os.path.exists(tpath):
+    traffic_source = None
+    # PMC pass of the same command (scripts/prof.sh + scripts/make_traffic.py), used only if it was measured on THESE kernel sources
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if dom and args.workload == "c3" and not untextured and tfiles:
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("traffic_bytes")
-        except Exception:
-            traffic = None
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from make_traffic import source_hash
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1])))
+            if tj.get("_kernel_source_hash") == source_hash():
+                traffic = tj.get(dom, {}).get("traffic_bytes")
+                traffic_source = (f"profiles/{tfiles[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload with --streams 1 on "
+                                  f"these kernel sources, hash {tj['_kernel_source_hash']}; {tj.get('_calibration', '')})")
+            else:
+                traffic_source = f"profiles/{tfiles[-1]} was measured on other kernel sources (hash mismatch): not used"
+        except Exception as e:          # noqa: BLE001
+            traffic_source = f"no usable traffic file ({type(e).__name__})"
     if dom:
         ach = kinfo[dom]["GBps"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload with --streams 1, scripts/prof.sh; FETCH x2)" if traffic else None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": ab[dom], "avg_launch_us": round(kinfo[dom]["avg_us"], 2)}
         if dom == DOMINANT and kern_solo_dom[1]:
             solo_us = 1e3 * kern_solo_dom[0] / kern_solo_dom[1]

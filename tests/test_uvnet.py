@@ -103,8 +103,12 @@ def test_tcnn_flat_params_round_trip_and_first_layer_bias():
                 assert torch.allclose(b, b2, atol=2e-3, rtol=1e-3)
     with pytest.raises(ValueError, match="expected"):
         unpack_tcnn_params(fp[:-1], 3, HIDDEN, 1)
-    # a module loaded from the flat form evaluates like one built from the matrices
-    net = UVNet().load_reference_state({"pre_mlp.params": fp, "mlp.params": fm})
+    # a module loaded from the flat form evaluates like one built from the matrices -- and says, loudly, that the layout it
+    # assumed is unpinned
+    with pytest.warns(RuntimeWarning, match="UNPINNED"):
+        net = UVNet().load_reference_state({"pre_mlp.params": fp, "mlp.params": fm})
+    assert net.tcnn_layout_unpinned is True
+    assert UVNet().load_reference_state(UVNet().state_dict()).tcnn_layout_unpinned is False
     ref = UVNet()
     with torch.no_grad():
         for lin, (w, b) in zip(ref._linears(), pre + mlp):
@@ -116,6 +120,42 @@ def test_tcnn_flat_params_round_trip_and_first_layer_bias():
     # the ones-padding: column 3 of the first matrix IS the bias
     x16 = torch.cat([x, torch.ones(50, 13)], 1)
     assert torch.allclose(x16 @ fp[:128 * 16].reshape(128, 16).t(), ref.pre_mlp[0](x), atol=1e-5)
+
+
+def test_tcnn_loader_rejects_detectable_mislayouts():
+    """What the loader CAN tell without the real package: wrong padding (sizes that only a 16-padded layout
+    gives), a flat tensor of another network shape, and -- on the reference-format checkpoint fixture -- that the nn.Linear form
+    loads without the unpinned flag.  A transposed square layer cannot be detected from sizes; a transposed FIRST layer
+    ([16, 128] read as [128, 16]) changes which column carries the ones-padding bias, which the round trip catches."""
+    from texgs.uvnet import unpack_tcnn_params, pack_tcnn_params, HIDDEN
+    g = torch.Generator().manual_seed(9)
+    pre = [(torch.randn(HIDDEN, 3, generator=g), torch.randn(HIDDEN, generator=g)), (torch.randn(HIDDEN, HIDDEN, generator=g), None)]
+    fp = pack_tcnn_params(pre, 3, HIDDEN)
+    # unpadded input (3 columns instead of 16), unpadded output (3 rows instead of 16), one hidden layer too many / too few
+    for bad in (torch.zeros(128 * 3 + 128 * 128), torch.zeros(128 * 16 + 128 * 128 + 3 * 128), fp[: 128 * 16], torch.cat([fp, fp])):
+        with pytest.raises(ValueError, match="expected"):
+            unpack_tcnn_params(bad, 3, HIDDEN, 1)
+    with pytest.raises(ValueError, match="expected"):
+        unpack_tcnn_params(torch.zeros(2 * 128 * 128 + 3 * 128), HIDDEN, 3, 2)            # output not padded to 16 rows
+    # first layer stored transposed ([16, 128] row-major): same element count, so sizes cannot tell -- the bias column can:
+    # reading it back gives a "bias" that is the sum of 13 random weight columns instead of the one stored column
+    t = fp.clone()
+    t[: 128 * 16] = fp[: 128 * 16].reshape(128, 16).t().reshape(-1)
+    (w, b), _ = unpack_tcnn_params(t, 3, HIDDEN, 1)
+    assert not torch.allclose(w, pre[0][0]) and not torch.allclose(b, pre[0][1])
+    # the reference-format fixture (nn.Linear keys, written by the reference's own state_dict): no flag, no warning
+    import os
+    import warnings
+    fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_stage3.pth")
+    if os.path.exists(fx):
+        ck = torch.load(fx, map_location="cpu", weights_only=False)
+        sd = ck[0] if isinstance(ck, (tuple, list)) else ck
+        uv = {k[len("uv_net."):]: v for k, v in sd.get("uv_net", sd).items() if isinstance(v, torch.Tensor) and k.startswith("uv_net.")} \
+            if not any(k.startswith("pre_mlp") for k in sd.get("uv_net", {})) else sd["uv_net"]
+        if uv and any(k.endswith("weight") for k in uv):
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                assert UVNet().load_reference_state(uv).tcnn_layout_unpinned is False
 
 
 def test_manual_backward_matches_autograd_float64():

@@ -97,8 +97,17 @@ class UVNet(nn.Module):
         # device-resident (buffers follow .to() / .cuda()): the reference moves them to the device on every call (uv_net.py:23-24)
         self.register_buffer("xyz_offset", None if xyz_offset is None else torch.as_tensor(xyz_offset, dtype=torch.float32), persistent=False)
         self.register_buffer("xyz_scale", None if xyz_scale is None else torch.as_tensor(xyz_scale, dtype=torch.float32), persistent=False)
-        self._packed = None          # W2..W4 in MFMA operand order + the parameter versions it was made from
-        self._packed_key = None
+        # W2..W4 in MFMA operand order, ONE buffer per (device, stream) that evaluates the net: a buffer is written and read on
+        # its own stream only, so no event is needed between the pack and the evaluation, and a re-pack never frees memory that
+        # another stream may still be reading (ViewPipeline runs views on several streams).  Key = (data_ptr, _version) of the
+        # three weights: updates through `.data` (p.data.copy_(), some legacy optimizers) do NOT bump _version -- call
+        # invalidate_packed() after such an update.
+        self._packed = {}
+        self.tcnn_layout_unpinned = False       # set by load_reference_state when the weights came from tiny-cuda-nn's flat layout
+
+    def invalidate_packed(self):
+        """Forget the MFMA-ordered weight copies (after changing weights in a way autograd's version counters do not see)."""
+        self._packed = {}
 
     # ---- weights --------------------------------------------------------------------------------------------------------
     def _linears(self):
@@ -108,14 +117,23 @@ class UVNet(nn.Module):
         """A reference `uv_net.state_dict()` in either form: nn.Linear keys (`pre_mlp.0.weight`, ...) or tiny-cuda-nn keys
         (`pre_mlp.params`, `mlp.params`: flat, bias-free, 16-padded -- every shipped config)."""
         if "pre_mlp.params" in state and "mlp.params" in state:
+            import warnings
             pre = unpack_tcnn_params(state["pre_mlp.params"], 3, HIDDEN, 1)
             mlp = unpack_tcnn_params(state["mlp.params"], HIDDEN, 3, 2)
             with torch.no_grad():
                 for lin, (w, b) in zip(self._linears(), pre + mlp):
                     lin.weight.copy_(w)
                     lin.bias.zero_() if b is None else lin.bias.copy_(b)
+            self.tcnn_layout_unpinned = True
+            warnings.warn("UVNet weights were read from tiny-cuda-nn's flat FullyFusedMLP parameter tensor.  That layout is restated "
+                          "from the published source and is UNPINNED here (tiny-cuda-nn cannot be installed in the build container, "
+                          "no fixture produced by it exists): check a rendered view against the reference before trusting the "
+                          "checkpoint (module.tcnn_layout_unpinned is set).", RuntimeWarning, stacklevel=2)
+            self.invalidate_packed()
             return self
         self.load_state_dict(state)
+        self.tcnn_layout_unpinned = False
+        self.invalidate_packed()
         return self
 
     def _norm_in(self, xyz):
@@ -159,11 +177,13 @@ class UVNet(nn.Module):
         uvs = torch.empty(N, 3, dtype=torch.float32, device=dev)
         juv = torch.empty(N, 9, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            if self._packed is None or self._packed_key != key:
-                self._packed = torch.empty(lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)
-                _lib.check(lib.texgs_uv_pack(C.byref(net), p(self._packed), stream), "texgs_uv_pack")
-                self._packed_key = key
-            _lib.check(lib.texgs_uv_taylor_packed(C.byref(net), p(self._packed), p(x), N, p(uvs), p(juv), stream),
+            slot = (dev.index, int(stream))
+            ent = self._packed.get(slot)
+            if ent is None or ent[0] != key:
+                buf = ent[1] if ent is not None else torch.empty(lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)
+                _lib.check(lib.texgs_uv_pack(C.byref(net), p(buf), stream), "texgs_uv_pack")       # (re-packed in place: same stream, in order)
+                self._packed[slot] = ent = (key, buf)
+            _lib.check(lib.texgs_uv_taylor_packed(C.byref(net), p(ent[1]), p(x), N, p(uvs), p(juv), stream),
                        "texgs_uv_taylor_packed")
         return uvs, juv
 
