@@ -4,8 +4,10 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 def short(n):
     for k in ("k_render_fwd", "k_render_bwd", "k_preprocess_fwd", "k_preprocess_bwd", "k_duplicate", "k_ranges", "k_texgrad_reduce"):
         if k in n: return k
-    if "onesweep" in n or "radix" in n or "sort" in n.lower(): return "radix_sort:" + n.split("(")[0][-40:]
-    if "scan" in n.lower(): return "scan:" + n.split("(")[0][-30:]
+    if "k_radix_count" in n: return "k_radix_count"
+    if "k_radix_scatter" in n: return "k_radix_scatter:" + n.split("<")[-1][:24]
+    for k in ("k_scan_sums", "k_scan_apply", "k_bin_offsets", "k_tile_order"):
+        if k in n: return k
     return n[:60]
 # stats
 for f in sorted(glob.glob(os.path.join(root, "trace*", "**", "*kernel_stats.csv"), recursive=True)):
