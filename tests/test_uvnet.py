@@ -204,11 +204,21 @@ def test_fused_forward_with_gradients(lib_built):
         errs[f"b{k + 1}"] = Hh.rel_err(l.bias.grad.cpu(), l64.bias.grad)
     Hh.report("uv_taylor/with_grad/20k", **errs)
     assert max(errs.values()) < 2e-4, errs
-    # the packed-weight cache: a second call re-uses it, an in-place weight update invalidates it
-    key = netd._packed_key
+    # the packed-weight cache (one buffer per (device, stream)): a second call re-uses it, an in-place weight update re-packs it in
+    # place, a side stream gets a buffer of its own, invalidate_packed() forgets them all
+    slot = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key, buf = netd._packed[slot]
     netd.uv_and_jacobian(xyz, emb)
-    assert netd._packed_key == key
+    assert netd._packed[slot][0] == key and netd._packed[slot][1] is buf
     with torch.no_grad():
         netd.mlp[0].weight.mul_(1.01)
     u2, _ = netd.uv_and_jacobian(xyz, emb)
-    assert netd._packed_key != key and float((u2 - uvs.detach()).abs().max()) > 1e-6
+    assert netd._packed[slot][0] != key and netd._packed[slot][1] is buf and float((u2 - uvs.detach()).abs().max()) > 1e-6
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        u3, _ = netd.uv_and_jacobian(xyz, emb)
+    side.synchronize()
+    assert len(netd._packed) == 2 and torch.equal(u3, u2)
+    netd.invalidate_packed()
+    assert netd._packed == {}
