@@ -217,3 +217,47 @@ def test_more_than_65536_tiles_three_digit_tile_sort(lib_built):
     lib = _lib.load()
     fr2 = _lib.Frame(4097 * 16, 4097 * 16, 0.3, 0.3, 1.0, 0, 0, 4, 0, 0, 1, 1, 1, 1)  # 16.8 M tiles (> 2^24): refused, not mis-sorted
     assert lib.texgs_mark_visible(C.byref(fr2), 1, 1, None) != 0 and b"2^24 tiles" in lib.texgs_last_error()
+
+
+@pytest.mark.parametrize("kind", ["one_depth", "two_clusters"])
+def test_depth_sort_with_crowded_depth_buckets(lib_built, kind):
+    """K2's in-LDS bucket sort holds 2 048 pairs; a bucket with more (many Gaussians at (nearly) the same view depth: a wall seen
+    frontally) is sorted by the single-workgroup LSD radix fallback in global memory.  one_depth: 12 000 Gaussians on 3 distinct
+    depths (range < 1 024 keys: a bucket holds one key, thousands of times: sorted by index only); two_clusters: two sheets of 48 depths and one
+    far Gaussian that stretches the range (bucket width 2^16 keys: key passes AND index passes).  Rank order, offsets, instance
+    keys, point list and ranges must be the C oracle's, bit for bit."""
+    g = torch.Generator().manual_seed(3)
+    N = 12000 if kind == "one_depth" else 9001
+    cam = synth.look_at_camera((0.0, 0.0, -3.2), 320, 240, fovx=0.9)
+    scene = synth.make_scene(N, 32, seed=8, scale_mean=0.02)
+    xy = (torch.rand(N, 2, generator=g) - 0.5) * 1.8
+    steps = torch.randint(0, 3 if kind == "one_depth" else 48, (N,), generator=g).float() * 2.0 ** -21
+    if kind == "one_depth":
+        z = -1.2 + steps
+    else:
+        z = torch.where(torch.arange(N) % 2 == 0, -1.2 + steps, 0.8 + steps)
+        z[-1] = 90.0
+    means = torch.cat([xy, z[:, None]], 1).float().contiguous()
+    scene = scene._replace(means3D=means)
+    bg = torch.zeros(3)
+    ref = CR.RefRun(scene, Hh.settings_for(cam, 2, bg))
+    ref.forward()
+    outs, s = Hh.hip_debug_state(scene, cam, 2, bg)
+    t, D = s.tensors, ref.D
+    vis = ref.radii[:N] > 0
+    keys = np.where(vis, ref.depth[:N].view(np.uint32), np.uint32(0xFFFFFFFF))
+    uk, cnt = np.unique((keys[vis].astype(np.int64) - int(keys[vis].min())) >> (0 if kind == "one_depth" else 16), return_counts=True)
+    assert cnt.max() > 2048, cnt.max()                                            # a bucket beyond the in-LDS sort's capacity
+    assert s.D == D and D > 10000
+    assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
+    order = np.argsort(keys.astype(np.uint64), kind="stable")
+    tt_rank = ref.tiles[:N][order].astype(np.int64)
+    offs = t["offsets"][:N].cpu().numpy().astype(np.uint32).astype(np.int64)
+    nv = int(vis.sum())
+    assert np.array_equal(offs[:nv], (np.cumsum(tt_rank) - tt_rank)[:nv]) and np.all(offs[nv:] == D)
+    assert np.array_equal(t["keys_sorted"][:D].cpu().numpy().view(np.uint64), ref.keys_sorted[:D])
+    assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
+    assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
+    got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
+    err = (got - torch.tensor(ref.out)).abs()
+    assert float(err[[0, 1, 2, 4, 5, 6, 7]].max()) < 2e-4 and float(err[3].max()) < 2e-3

@@ -136,8 +136,9 @@ int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint3
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RB_MAX_DEVICES) return fail_msg("hipGetDevice failed");
     Readback& g_rb = g_rb_dev[dev];
-    // K1 left three partial sums per workgroup (no atomics, nothing to zero-fill): copy them, add them up here
-    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK, nw = 3 * nblk;
+    // K1 left five words per workgroup (three partial sums + the depth-key range the device-side sort uses; no atomics, nothing to
+    // zero-fill): copy them, add the sums up here
+    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK, nw = 5 * nblk;
     if (g_rb.words < nw) {
         if (g_rb.host) (void)hipHostFree(g_rb.host);
         g_rb.host = nullptr;
@@ -157,7 +158,7 @@ int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint3
     if (e != hipSuccess) return fail("num_rendered sync", e);
     unsigned long long total = 0ull;
     uint32_t fa = 0u, fb = 0u;
-    for (size_t k = 0; k < nblk; ++k) { total += g_rb.host[3 * k]; fa += g_rb.host[3 * k + 1]; fb += g_rb.host[3 * k + 2]; }
+    for (size_t k = 0; k < nblk; ++k) { total += g_rb.host[5 * k]; fa += g_rb.host[5 * k + 1]; fb += g_rb.host[5 * k + 2]; }
     if (total > 0xFFFFFFFFull) return fail_msg("num_rendered exceeds 2^32 - 1 instances");
     *host_out = (uint32_t)total;
     if (fingerprint_out) *fingerprint_out = ((uint64_t)fb << 32) | (uint64_t)fa;

@@ -5,8 +5,9 @@
 // The lineage gets there with ONE stable LSD sort of D 64-bit keys over 32 + log2(T) bits (6 onesweep passes with
 // decoupled look-back; rocPRIM's took 210 us at C3 -- every look-back hop is a ~1 us cross-XCD round trip here).
 // This file sorts in two levels instead:
-//   1. the N GAUSSIANS by depth bits (4 x 8-bit stable passes over 8-byte pairs; culled ones carry 0xFFFFFFFF),
-//   2. an exclusive scan of tiles_touched in that depth-rank order,
+//   1. the N GAUSSIANS by (depth bits, index) (culled ones carry 0xFFFFFFFF): an MSD partition into <= 1025 depth buckets and an
+//      in-LDS sort of every bucket (round 4; rounds 2-3: four stable 8-bit passes),
+//   2. an exclusive scan of tiles_touched in that depth-rank order (inside the bucket sort + one add of the buckets in front),
 //   3. K3 emits the instances in rank order, element = (tile << 32) | rank -- already sorted by rank,
 //   4. the D INSTANCES by tile only (2 stable passes over ceil(log2 T) bits); the last pass writes keys_sorted /
 //      point_list from the rank-ordered depth / index arrays.
@@ -35,7 +36,6 @@ struct RadixTables {                    // one per pass
                                         //  atomics took one atomic per (block, digit) on 256 hot words -- 548 per word in K4 at C3)
 constexpr size_t RS_ZERO_WORDS = (size_t)(RS_MAX_BLOCKS / RS_GROUP) * 256;           // gtable of one pass
 
-__device__ __forceinline__ uint32_t digit_of(uint32_t k, int shift, uint32_t mask) { return (k >> shift) & mask; }
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
 
 // contiguous element range of block b: [b * per, min(n, (b + 1) * per)), per a multiple of 64
@@ -198,75 +198,323 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
     }
 }
 
-// ---- exclusive scan of tiles_touched in depth-rank order (two launches, 2048 elements per block)
-#ifndef SC_PER_DEF
-#define SC_PER_DEF 512          // 2048 / 1024 / 512: K2 48.6 / 46.5 / 45.2 us at C2 (same reason as RS_PER_MIN)
-#endif
-constexpr int SC_PER = SC_PER_DEF;
-constexpr int SC_ELEMS = SC_PER / RS_THREADS;      // consecutive elements per thread in k_scan_apply
-__global__ void __launch_bounds__(RS_THREADS)
-k_scan_sums(int N, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ bsum) {
-    __shared__ uint32_t s_w[4];
-    const int base = blockIdx.x * SC_PER;
-    uint32_t s = 0u;
-    {   // both gathers batched: 8 index loads in flight, then 8 value loads
-        uint32_t ids[SC_PER / RS_THREADS];
-#pragma unroll
-        for (int k = 0; k < SC_PER / RS_THREADS; ++k) { const int r = base + (int)threadIdx.x + k * RS_THREADS; ids[k] = (r < N) ? id_rank[r] : 0u; }
-#pragma unroll
-        for (int k = 0; k < SC_PER / RS_THREADS; ++k) { const int r = base + (int)threadIdx.x + k * RS_THREADS; s += (r < N) ? tiles_touched[ids[k]] : 0u; }
-    }
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+// ---- K2, round 4: depth sort of the N Gaussians + exclusive scan of tiles_touched in rank order in FOUR launches --------------
+// (round 3: four stable 8-bit radix passes = 8 launches, + 2 for the scan; every launch is one or two dependent round trips over
+// 2.4 MB on a chip it cannot fill: 64 us at C3, 46 us at C2.)  Now:
+//   k_depth_count    MSD partition, step 1: K1 left (min, max) of the valid depth keys per workgroup; bucket = (key - min) >> shift
+//                    with shift chosen so that the range spans <= NB buckets (NB = a power of two ~ N / 256; culled Gaussians, key
+//                    0xFFFFFFFF: bucket NB); per-block LDS histogram -> global bucket totals (atomics);
+//   k_depth_scatter  step 2: exclusive scan of the totals (every block, redundantly), one returning atomic per (block, non-empty
+//                    bucket) reserves the block's slots, elements go to their bucket's region in ARBITRARY order;
+//   k_depth_bucket_sort  one workgroup per bucket: the bucket's (key, index) pairs are sorted by (key, index) -- a total order, so the
+//                    arbitrary order of step 2 does not matter and the result is exactly the stable order by (depth bits, index)
+//                    of the lineage -- in registers (<= 64 pairs: one wave, bitonic network over lane shuffles), in
+//                    LDS (<= 2048, 256 threads), or by an LSD radix in global memory (more: > 2048 Gaussians in 1/NB of the depth range; slow,
+//                    correct); tiles_touched is gathered in that order and scanned inside the bucket;
+//   k_depth_prefix   one workgroup scans the buckets' tile sums.  K3 adds a rank's bucket prefix when it reads its offset (and
+//                    writes it back: geom->offsets is an output of the contract).
+// (Tried and dropped, profiles/r04_ablation.md: 8 192 buckets with a register-only sort -- the partition then pays one returning
+//  atomic per element; the scans done by "the last block to finish" -- a ticket word takes 13 ns per workgroup, same address.)
+constexpr int DS_NB_MAX = 8192;        // depth buckets (+ 1 for culled Gaussians)
+constexpr int DS_THREADS = 256;
+constexpr int DS_PER = 2048;           // elements per block of the count / scatter kernels
+constexpr int DS_CAP = 2048;           // pairs a bucket may hold to be sorted in LDS
+constexpr uint32_t DS_COPY = 4096u;    // culled pairs one workgroup of the bucket-sort kernel copies
+constexpr int DS_BLK_WORDS = 5;        // K1's per-workgroup words: tiles_touched, fingerprint lo / hi, min / max valid depth key
+
+struct DepthRange { uint32_t lo, shift, nb; };
+
+inline int depth_log2_buckets(int N) {              // NB ~ N / 256, a power of two in [64, DS_NB_MAX]: ~300 pairs per bucket.  (Finer
+    int lb = 6;                                     // buckets make the sort cheaper and the partition dearer: a block of the scatter
+    while ((1 << lb) < N / 256 && (1 << lb) < DS_NB_MAX) ++lb;      // kernel pays one returning atomic per distinct bucket it touches.)
+    return lb;
 }
-__global__ void __launch_bounds__(RS_THREADS)
-k_scan_apply(int N, int nblocks, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ tiles_touched,
-             const uint32_t* __restrict__ bsum, uint32_t* __restrict__ offs_rank) {
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {   // sum of the block sums before this block
-        uint32_t s = 0u;
-        for (int k = tid; k < (int)blockIdx.x; k += RS_THREADS) s += bsum[k];
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        if (lane == 0) s_w[wv] = s;
+
+// every block derives the same (lo, shift) from K1's per-workgroup (min, max)
+__device__ __forceinline__ DepthRange depth_range(const uint32_t* __restrict__ block_D, int nblk, int lb, uint32_t* s_red) {
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (int k = threadIdx.x; k < nblk; k += (int)blockDim.x) { mn = min(mn, block_D[DS_BLK_WORDS * k + 3]); mx = max(mx, block_D[DS_BLK_WORDS * k + 4]); }
+    for (int d = 32; d >= 1; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); }
+    const int nw = (int)blockDim.x >> 6;
+    if (nw > 1) {
+        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = mn; s_red[4 + (threadIdx.x >> 6)] = mx; }
         __syncthreads();
-        if (tid == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        mn = s_red[0]; mx = s_red[4];
+        for (int w = 1; w < nw; ++w) { mn = min(mn, s_red[w]); mx = max(mx, s_red[4 + w]); }
         __syncthreads();
     }
-    // thread t owns elements [t * SC_ELEMS, (t + 1) * SC_ELEMS) of the block (rank order)
-    const int r0 = blockIdx.x * SC_PER + tid * SC_ELEMS;
-    uint32_t v[SC_ELEMS];
-    uint32_t s = 0u;
-#pragma unroll
-    for (int k = 0; k < SC_ELEMS; ++k) { const int r = r0 + k; v[k] = (r < N) ? tiles_touched[id_rank[r]] : 0u; s += v[k]; }
-    uint32_t incl = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    const uint32_t range = (mx >= mn) ? mx - mn : 0u;
+    const int bits = range ? 32 - __clz((int)range) : 0;
+    DepthRange r; r.lo = mn; r.shift = bits > lb ? (uint32_t)(bits - lb) : 0u; r.nb = 1u << lb;
+    return r;
+}
+__device__ __forceinline__ uint32_t depth_bucket(uint32_t key, const DepthRange& r) {
+    return key == 0xFFFFFFFFu ? r.nb : ((key - r.lo) >> r.shift);
+}
+
+__global__ void __launch_bounds__(DS_THREADS)
+k_depth_count(const uint32_t* __restrict__ keys, int N, const uint32_t* __restrict__ block_D, int nblk, int lb, uint32_t* __restrict__ btot) {
+    __shared__ uint32_t s_hist[DS_NB_MAX + 1];
+    __shared__ uint32_t s_red[8];
+    const int tid = threadIdx.x;
+    const DepthRange r = depth_range(block_D, nblk, lb, s_red);
+    const int nb1 = (int)r.nb + 1;
+    for (int k = tid; k < nb1; k += DS_THREADS) s_hist[k] = 0u;
     __syncthreads();
+    const int base = blockIdx.x * DS_PER;
+    uint32_t kk[DS_PER / DS_THREADS];
+#pragma unroll
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) { const int i = base + tid + u * DS_THREADS; kk[u] = (i < N) ? keys[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) if (base + tid + u * DS_THREADS < N) atomicAdd(&s_hist[depth_bucket(kk[u], r)], 1u);
+    __syncthreads();
+    // consecutive lanes -> consecutive words: atomics on runs of addresses go through at 13x the rate of scattered ones (scripts/ubench)
+    for (int k = tid; k < nb1; k += DS_THREADS) { const uint32_t c = s_hist[k]; if (c) atomicAdd(&btot[k], c); }
+}
+
+__global__ void __launch_bounds__(DS_THREADS)
+k_depth_scatter(const uint32_t* __restrict__ keys, int N, const uint32_t* __restrict__ block_D, int nblk, int lb,
+                const uint32_t* __restrict__ btot, uint32_t* __restrict__ bcur, uint32_t* __restrict__ gbase,
+                uint32_t* __restrict__ drange, uint32_t* __restrict__ key_out, uint32_t* __restrict__ val_out) {
+    __shared__ uint32_t s_hist[DS_NB_MAX + 1];          // this block's counts, then its next free slot per bucket
+    __shared__ uint32_t s_base[DS_NB_MAX + 2];
+    __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const DepthRange r = depth_range(block_D, nblk, lb, s_red);
+    const int nb1 = (int)r.nb + 1;
+    for (int k = tid; k < nb1; k += DS_THREADS) s_hist[k] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * DS_PER;
+    uint32_t kk[DS_PER / DS_THREADS];
+#pragma unroll
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) { const int i = base + tid + u * DS_THREADS; kk[u] = (i < N) ? keys[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) if (base + tid + u * DS_THREADS < N) atomicAdd(&s_hist[depth_bucket(kk[u], r)], 1u);
+    {   // exclusive scan of the nb + 1 bucket totals (every block, redundantly: 4-8 KB of L2 reads): thread t owns `per` consecutive buckets
+        const int per = (nb1 + DS_THREADS - 1) / DS_THREADS;
+        uint32_t sum = 0u;
+        for (int k = 0; k < per; ++k) { const int bkt = tid * per + k; sum += (bkt < nb1) ? btot[bkt] : 0u; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < wv; ++w) run += s_w[w];
+        for (int k = 0; k < per; ++k) { const int bkt = tid * per + k; if (bkt <= nb1) s_base[bkt] = run; run += (bkt < nb1) ? btot[bkt] : 0u; }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int k = tid; k <= nb1; k += DS_THREADS) gbase[k] = s_base[k];
+        if (tid == 0) { drange[0] = r.lo; drange[1] = r.shift; drange[2] = r.nb; }
+    }
+    // this block's slots in every bucket it has elements for: one returning atomic per (block, bucket), consecutive lanes on consecutive words
+    for (int k = tid; k < nb1; k += DS_THREADS) { const uint32_t c = s_hist[k]; s_hist[k] = c ? s_base[k] + atomicAdd(&bcur[k], c) : 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) {
+        const int i = base + tid + u * DS_THREADS;
+        if (i < N) { const uint32_t p = atomicAdd(&s_hist[depth_bucket(kk[u], r)], 1u); key_out[p] = kk[u]; val_out[p] = (uint32_t)i; }
+    }
+}
+
+// loads that must see what this wave (or another) wrote to global memory earlier (the fallback's ping-pong passes, the last wave's scan)
+__device__ __forceinline__ uint32_t ld_coherent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One stable 8-bit LSD radix pass over n (key, val) pairs in global memory by ONE wave (rows of 64 ranked with ballot matches exactly
+// as k_radix_scatter does).  digit = ((by_val ? val : key - lo) >> shift) & 255.
+__device__ void wave_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n, uint32_t lo,
+                                bool by_val, int shift, uint32_t* s_cnt /*[256]*/) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_cnt[lane * 4 + k] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t x = by_val ? ld_coherent(vin + i) : ld_coherent(kin + i) - lo;
+        atomicAdd(&s_cnt[(x >> shift) & 255u], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // exclusive scan over the 256 digits: lane owns 4 consecutive digits
+        uint32_t c[4], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = s_cnt[lane * 4 + k]; sum += c[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_cnt[lane * 4 + k] = run; run += c[k]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t b0 = 0u; b0 < n; b0 += 64u) {
+        const uint32_t i = b0 + lane;
+        const bool have = i < n;
+        const uint32_t k = have ? ld_coherent(kin + i) : 0u, v = have ? ld_coherent(vin + i) : 0u;
+        const uint32_t d = have ? (((by_val ? v : k - lo) >> shift) & 255u) : 0xFFFFFFFFu;
+        unsigned long long peers = __ballot(have);
+        for (int bt = 0; bt < 8; ++bt) { const unsigned long long m = __ballot((d >> bt) & 1u); peers &= ((d >> bt) & 1u) ? m : ~m; }
+        uint32_t pos = 0u;
+        if (have) pos = s_cnt[d] + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        __builtin_amdgcn_wave_barrier();
+        if (have && (peers >> lane) >> 1 == 0ull) s_cnt[d] = pos + 1u;
+        __builtin_amdgcn_wave_barrier();
+        if (have) { kout[pos] = k; vout[pos] = v; }
+    }
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long x, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(DS_THREADS)
+k_depth_bucket_sort(int N, const uint32_t* __restrict__ btot, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ drange,
+                    uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
+                    const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ offs_rank, uint32_t* __restrict__ bsum, int nb) {
+    __shared__ unsigned long long s_pair[DS_CAP];          // 16 KB (LDS path; the fallback's digit table aliases it)
+    __shared__ uint32_t s_w[DS_THREADS / 64];
+    const int b = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (b >= nb) {              // culled Gaussians: they emit nothing (tiles_touched = 0), their mutual order is irrelevant; the copy is
+        const uint32_t n = btot[nb], start = gbase[nb];         // spread over N / DS_COPY workgroups (one would be the kernel's tail)
+        const uint32_t lo = (uint32_t)(b - nb) * DS_COPY, hi = min(n, lo + DS_COPY);
+        for (uint32_t i = lo + tid; i < hi; i += DS_THREADS) { key_b[start + i] = key_a[start + i]; val_b[start + i] = val_a[start + i]; offs_rank[start + i] = 0u; }
+        if (b == nb && tid == 0) bsum[nb] = 0u;
+        return;
+    }
+    const uint32_t n = btot[b], start = gbase[b];          // workgroup-uniform: every branch below is taken by all 256 threads or none
+    uint32_t total = 0u;                                     // this bucket's sum of tiles_touched (valid in thread 0 at the end)
+    if (n == 0u) {
+        // nothing
+    } else if (n <= 64u) {
+        if (wv != 0) return;
+        // ---- registers: bitonic network over the 64 lanes of one wave (21 compare-exchange steps, two shuffles each)
+        unsigned long long x = (lane < (int)n) ? (((unsigned long long)key_a[start + lane] << 32) | (unsigned long long)val_a[start + lane]) : ~0ull;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long y = shfl_xor_u64(x, j);
+                const bool up = ((lane & k) == 0), lower = ((lane & j) == 0);
+                const bool take_min = (up == lower);
+                x = take_min ? (x < y ? x : y) : (x > y ? x : y);
+            }
+        const uint32_t tt = (lane < (int)n) ? tiles_touched[(uint32_t)x] : 0u;
+        uint32_t incl = tt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (lane < (int)n) { key_b[start + lane] = (uint32_t)(x >> 32); val_b[start + lane] = (uint32_t)x; offs_rank[start + lane] = incl - tt; }
+        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    } else if (n <= (uint32_t)DS_CAP) {
+        // ---- LDS: bitonic sort of (key << 32 | index), P = next power of two, padded with the largest value
+        uint32_t P = 128u;
+        while (P < n) P <<= 1;
+        for (uint32_t i = tid; i < P; i += DS_THREADS)
+            s_pair[i] = (i < n) ? (((unsigned long long)key_a[start + i] << 32) | (unsigned long long)val_a[start + i]) : ~0ull;
+        for (uint32_t k = 2u; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                __syncthreads();
+                for (uint32_t t = tid; t < (P >> 1); t += DS_THREADS) {
+                    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+                    const unsigned long long x = s_pair[i], y = s_pair[l];
+                    if ((x > y) == ((i & k) == 0u)) { s_pair[i] = y; s_pair[l] = x; }
+                }
+            }
+        __syncthreads();
+        const uint32_t E = (P + DS_THREADS - 1) / DS_THREADS;          // consecutive ranks per thread: 1 .. 8
+        uint32_t sum = 0u;
+        for (uint32_t u = 0; u < E; ++u) {
+            const uint32_t i = tid * E + u;
+            if (i < n) {
+                const unsigned long long x = s_pair[i];
+                key_b[start + i] = (uint32_t)(x >> 32); val_b[start + i] = (uint32_t)x;
+                sum += tiles_touched[(uint32_t)x];
+            }
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < wv; ++w) run += s_w[w];
+        for (uint32_t u = 0; u < E; ++u) {
+            const uint32_t i = tid * E + u;
+            if (i < n) { offs_rank[start + i] = run; run += tiles_touched[(uint32_t)s_pair[i]]; }
+        }
+        total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    } else {
+        if (wv != 0) return;
+        // ---- fallback (one wave): LSD radix by (key, index) in global memory, ping-pong between the bucket's regions of (a) and (b)
+        uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_pair);
+        const uint32_t lo = drange[0], shift = drange[1];
+        int nbv = 0; while ((1u << nbv) < (uint32_t)N && nbv < 32) ++nbv;          // index bits
+        const int pv = (nbv + 7) / 8, pk = ((int)shift + 7) / 8;
+        uint32_t *ki = key_a + start, *vi = val_a + start, *ko = key_b + start, *vo = val_b + start;
+        for (int p = 0; p < pv + pk; ++p) {
+            wave_radix_pass(ki, vi, ko, vo, n, lo, p < pv, (p < pv ? p : p - pv) * 8, s_cnt);
+            uint32_t* t = ki; ki = ko; ko = t; t = vi; vi = vo; vo = t;
+        }
+        if (ki != key_b + start) {          // an even number of passes left the result in (a)
+            for (uint32_t i = lane; i < n; i += 64u) { key_b[start + i] = ld_coherent(ki + i); val_b[start + i] = ld_coherent(vi + i); }
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t carry = 0u;                // tiles_touched in rank order, scanned 64 at a time with a running carry
+        for (uint32_t c0 = 0u; c0 < n; c0 += 64u) {
+            const uint32_t i = c0 + lane;
+            const uint32_t tt = (i < n) ? tiles_touched[ld_coherent(val_b + start + i)] : 0u;
+            uint32_t incl = tt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+            if (i < n) offs_rank[start + i] = carry + incl - tt;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        total = carry;
+    }
+    if (tid == 0) bsum[b] = total;          // the bucket's tile sum; k_depth_prefix scans them
+}
+
+// exclusive scan of the buckets' tile sums (one workgroup; <= 8 193 values)
+__global__ void __launch_bounds__(1024)
+k_depth_prefix(int nb1, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ bpre) {
+    __shared__ uint32_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (nb1 + 1023) / 1024;            // <= 9
+    uint32_t v[9], sum = 0u;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int q = tid * per + k; v[k] = (k < per && q < nb1) ? bsum[q] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
     if (lane == 63) s_w[wv] = incl;
     __syncthreads();
-    uint32_t run = s_base + incl - s;
+    uint32_t run = incl - sum;
     for (int w = 0; w < wv; ++w) run += s_w[w];
 #pragma unroll
-    for (int k = 0; k < SC_ELEMS; ++k) { const int r = r0 + k; if (r < N) offs_rank[r] = run; run += v[k]; }
+    for (int k = 0; k < 9; ++k) { const int q = tid * per + k; if (k < per && q < nb1) bpre[q] = run; run += v[k]; }
 }
 
 // K3: one thread per depth rank; emits that Gaussian's instances, element = (tile << 32) | rank, at offs_rank[rank]...
+// offs_rank[rank] arrives as the prefix INSIDE the rank's depth bucket (k_depth_bucket_sort); the bucket's own prefix is added here
+// and the sum written back (geom->offsets = exclusive scan of tiles_touched in rank order is an output of the contract).
 // Also zero-fills `ranges` (empty tiles keep (0, 0); k_ranges runs later on the same stream).
 __global__ void __launch_bounds__(TG_BLOCK)
-k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ offs_rank,
+k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ key_rank,
+            uint32_t* __restrict__ offs_rank, const uint32_t* __restrict__ drange, const uint32_t* __restrict__ bpre,
             const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, uint64_t* __restrict__ elems,
             uint2* __restrict__ ranges, uint32_t* __restrict__ zero_words, int num_zero_words) {
     const int r = blockIdx.x * TG_BLOCK + threadIdx.x;
     for (int k = r; k < T; k += (int)gridDim.x * TG_BLOCK) ranges[k] = make_uint2(0u, 0u);
     for (int k = r; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // group count tables of the tile sort
     if (r >= N) return;
+    DepthRange dr; dr.lo = drange[0]; dr.shift = drange[1]; dr.nb = drange[2];
+    uint32_t off = offs_rank[r] + bpre[depth_bucket(key_rank[r], dr)];
+    offs_rank[r] = off;
     const uint32_t id = id_rank[r];
     if (tiles_touched[id] == 0u) return;
-    uint32_t off = offs_rank[r];
     const uint2 rc = rect[id];
     const uint32_t x0 = rc.x & 0xffffu, y0 = rc.x >> 16, x1 = rc.y & 0xffffu, y1 = rc.y >> 16;
     for (uint32_t y = y0; y < y1; ++y)
@@ -334,30 +582,36 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- scratch layouts ------------------------------------------------------------------------------------------------
 // scan_temp (Gaussian level, sized by scan_temp_bytes(N)):
-//   [0]        header zero-filled by K1: 4 x gtable of the depth passes
-//   then       4 x table, key_a, key_b, val_a, val_b (u32[N] each), bsum (u32[ceil(N / 2048)]), block_D (u32[ceil(N / 256)][3])
+//   [0]        header zero-filled by K1: btot[DS_NB_MAX + 1] bucket totals, bcur[DS_NB_MAX + 1] bucket fill counters, done[2]
+//   then       gbase[DS_NB_MAX + 2], bsum / bpre[DS_NB_MAX + 1], drange[4], key_a, key_b, val_a, val_b (u32[N] each),
+//              block_D (u32[ceil(N / 256)][5])
 // sort_temp (instance level, sized by sort_temp_bytes(capacity, T)):
 //   [0]        header zero-filled by K3: 3 x gtable of the tile passes
 //   then       3 x table, elem_tmp (u64[capacity])
 struct GaussScratch {
-    uint32_t* tables;       // 4 passes
-    uint32_t* block_D;      // [ceil(N / 256)][3] K1's per-workgroup sums {tiles_touched, fingerprint lo, hi} (the host adds them up)
-    uint32_t *key_a, *key_b, *val_a, *val_b, *bsum;
+    uint32_t *btot, *bcur;  // header (K1 zero-fills it; the `done` ticket word follows bcur)
+    uint32_t *gbase, *bsum, *bpre, *drange;
+    uint32_t* block_D;      // [ceil(N / 256)][5] K1's per-workgroup {sum of tiles_touched, fingerprint lo, hi, min / max valid depth key}
+    uint32_t *key_a, *key_b, *val_a, *val_b;
     size_t header_bytes;
 };
 inline size_t zero_header_bytes(int passes, size_t extra) { return align256((size_t)passes * RS_ZERO_WORDS * 4 + extra); }
+inline size_t depth_header_bytes() { return align256(((size_t)2 * (DS_NB_MAX + 1) + 2) * 4); }
 inline GaussScratch gauss_scratch(void* base, int N) {
     GaussScratch g;
     char* p = (char*)base;
-    g.tables = (uint32_t*)p;
-    g.header_bytes = zero_header_bytes(4, 0);
-    p += g.header_bytes + align256(4 * (size_t)RS_MAX_BLOCKS * 256 * 4);
+    g.header_bytes = depth_header_bytes();
+    g.btot = (uint32_t*)p; g.bcur = g.btot + (DS_NB_MAX + 1);
+    p += g.header_bytes;
+    g.gbase = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 2) * 4);
+    g.bsum = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 1) * 4);
+    g.bpre = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 1) * 4);
+    g.drange = (uint32_t*)p; p += 256;
     const size_t nb = align256((size_t)(N > 0 ? N : 1) * 4);
     g.key_a = (uint32_t*)p; p += nb;
     g.key_b = (uint32_t*)p; p += nb;
     g.val_a = (uint32_t*)p; p += nb;
     g.val_b = (uint32_t*)p; p += nb;
-    g.bsum = (uint32_t*)p; p += align256(((size_t)(N > 0 ? N : 1) + SC_PER - 1) / SC_PER * 4 + 256);
     g.block_D = (uint32_t*)p;
     return g;
 }
@@ -379,8 +633,8 @@ inline void pass_geometry(uint32_t n, uint32_t& blocks, uint32_t& per) {
 
 size_t scan_temp_bytes(int N) {
     const size_t n = (size_t)(N > 0 ? N : 1);
-    return zero_header_bytes(4, 0) + align256(4 * (size_t)RS_MAX_BLOCKS * 256 * 4) + 4 * align256(n * 4)
-         + align256(((n + SC_PER - 1) / SC_PER) * 4 + 256) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * 12);
+    return depth_header_bytes() + align256((size_t)(DS_NB_MAX + 2) * 4) + 2 * align256((size_t)(DS_NB_MAX + 1) * 4) + 256
+         + 4 * align256(n * 4) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * (size_t)DS_BLK_WORDS * 4);
 }
 
 constexpr int TILE_PASSES_MAX = 3;      // tile ids up to 2^24 in digits of at most 8 bits (the count / scatter kernels index 256-entry LDS tables)
@@ -393,37 +647,30 @@ size_t sort_temp_bytes(uint32_t D, uint32_t T) {
 }
 
 uint32_t* bin_block_sums_ptr(const TexGSGeom* g, int N) { return gauss_scratch(g->scan_temp, N).block_D; }
-uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // group count tables of the depth passes: K1 zero-fills them
+uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // bucket totals / fill counters of the depth sort: K1 zero-fills them
     const GaussScratch gs = gauss_scratch(g->scan_temp, N);
     *words = (int)(gs.header_bytes / 4);
-    return gs.tables;
+    return gs.btot;
 }
 
-// Gaussian level: depth sort (4 passes) + exclusive scan of tiles_touched in rank order.  Needs K1's depth keys
-// (bits of view z; 0xFFFFFFFF for culled) in g->depth.  Independent of D: runs while the host waits for the D readback.
+// Gaussian level: depth sort + exclusive scan of tiles_touched in rank order (four launches, see above).  Needs K1's depth keys
+// (bits of view z; 0xFFFFFFFF for culled) in g->depth and its per-workgroup (min, max).  Independent of D: runs while the host
+// waits for the D readback.  Result: (key_b, val_b) = depth bits / Gaussian index in rank order; g->offsets = the prefix inside
+// each rank's bucket, completed by K3 with bpre.
 int launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s) {
     if (N <= 0) return 0;
     const GaussScratch gs = gauss_scratch(g->scan_temp, N);
-    uint32_t blocks, per;
-    pass_geometry((uint32_t)N, blocks, per);
-    const uint32_t* kin = reinterpret_cast<const uint32_t*>(g->depth);
-    const uint32_t* vin = nullptr;                        // first pass: value = index
-    uint32_t* kout = gs.key_a; uint32_t* vout = gs.val_a;
-    for (int pass = 0; pass < 4; ++pass) {
-        const RadixTables t = tables_at(gs.tables, pass, 4, 0);
-        hipLaunchKernelGGL(k_radix_count<uint32_t>, dim3(blocks), dim3(RS_THREADS), 0, s, kin, (const uint32_t*)nullptr, (uint32_t)N,
-                           per, pass * 8, 255u, t);
-        hipLaunchKernelGGL((k_radix_scatter<uint32_t, 0>), dim3(blocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout,
-                           (const uint32_t*)nullptr, (uint32_t)N, per, pass * 8, 255u, 8, t, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr);
-        kin = kout; vin = vout;
-        kout = (kout == gs.key_a) ? gs.key_b : gs.key_a;
-        vout = (vout == gs.val_a) ? gs.val_b : gs.val_a;
-    }
-    // after 4 passes the sorted pairs are in (key_b, val_b)
-    const int nsb = (N + SC_PER - 1) / SC_PER;
-    hipLaunchKernelGGL(k_scan_sums, dim3(nsb), dim3(RS_THREADS), 0, s, N, gs.val_b, g->tiles_touched, gs.bsum);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(RS_THREADS), 0, s, N, nsb, gs.val_b, g->tiles_touched, gs.bsum, g->offsets);
+    const int nblk = (N + TG_BLOCK - 1) / TG_BLOCK;
+    const int blocks = (N + DS_PER - 1) / DS_PER;
+    const int lb = depth_log2_buckets(N), nb = 1 << lb;
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(g->depth);
+    hipLaunchKernelGGL(k_depth_count, dim3(blocks), dim3(DS_THREADS), 0, s, keys, N, (const uint32_t*)gs.block_D, nblk, lb, gs.btot);
+    hipLaunchKernelGGL(k_depth_scatter, dim3(blocks), dim3(DS_THREADS), 0, s, keys, N, (const uint32_t*)gs.block_D, nblk, lb,
+                       (const uint32_t*)gs.btot, gs.bcur, gs.gbase, gs.drange, gs.key_a, gs.val_a);
+    hipLaunchKernelGGL(k_depth_bucket_sort, dim3(nb + (N + (int)DS_COPY - 1) / (int)DS_COPY), dim3(DS_THREADS), 0, s, N, (const uint32_t*)gs.btot, (const uint32_t*)gs.gbase,
+                       (const uint32_t*)gs.drange, gs.key_a, gs.val_a, gs.key_b, gs.val_b, (const uint32_t*)g->tiles_touched,
+                       g->offsets, gs.bsum, nb);
+    hipLaunchKernelGGL(k_depth_prefix, dim3(1), dim3(1024), 0, s, nb + 1, (const uint32_t*)gs.bsum, gs.bpre);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -432,8 +679,9 @@ void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hi
     if (c.N <= 0 || b->num_rendered == 0) return;
     const GaussScratch gs = gauss_scratch(g->scan_temp, c.N);
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
-    hipLaunchKernelGGL(k_duplicate, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, gs.val_b, g->offsets,
-                       g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges),
+    hipLaunchKernelGGL(k_duplicate, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, (const uint32_t*)gs.val_b,
+                       (const uint32_t*)gs.key_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.bpre,
+                       (const uint32_t*)g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges),
                        reinterpret_cast<uint32_t*>(b->sort_temp), (int)(zero_header_bytes(TILE_PASSES_MAX, 0) / 4));
 }
 

@@ -338,7 +338,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
                  uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_D,
                  uint32_t* __restrict__ zero_words, int num_zero_words) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];          // [256][3K] staged SH rows (coalesced load)
-    __shared__ uint32_t s_tt[3 * (TG_BLOCK / 64)];
+    __shared__ uint32_t s_tt[5 * (TG_BLOCK / 64)];
     const int i = blockIdx.x * TG_BLOCK + threadIdx.x;
     const bool live = i < C.N;
     for (int k = i; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // count tables of the depth sort (K2)
@@ -430,17 +430,28 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     mix(__float_as_uint(s1.x)); mix(__float_as_uint(s1.y)); mix(__float_as_uint(s1.z)); mix(__float_as_uint(s1.w));
     mix(__float_as_uint(s2.x)); mix(__float_as_uint(s2.y)); mix(__float_as_uint(s2.z));
     }
-    // avalanche, then the three workgroup sums
+    // avalanche, then the workgroup's three sums and the (min, max) of its valid depth keys (the depth sort's bucket range)
     ha ^= ha >> 15; ha *= 0x2C1B3C6Du; ha ^= ha >> 12;
     hb ^= hb >> 16; hb *= 0x85EBCA6Bu; hb ^= hb >> 13;
     if (!live) { ha = 0u; hb = 0u; }
-    for (int d = 32; d >= 1; d >>= 1) { tt += __shfl_xor(tt, d, 64); ha += __shfl_xor(ha, d, 64); hb += __shfl_xor(hb, d, 64); }
-    if ((threadIdx.x & 63) == 0) { s_tt[threadIdx.x >> 6] = tt; s_tt[TG_BLOCK / 64 + (threadIdx.x >> 6)] = ha; s_tt[2 * (TG_BLOCK / 64) + (threadIdx.x >> 6)] = hb; }
+    uint32_t kmin = (live && g.valid) ? __float_as_uint(g.t[2]) : 0xFFFFFFFFu, kmax = (live && g.valid) ? __float_as_uint(g.t[2]) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) {
+        tt += __shfl_xor(tt, d, 64); ha += __shfl_xor(ha, d, 64); hb += __shfl_xor(hb, d, 64);
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+    }
+    constexpr int NW = TG_BLOCK / 64;
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s_tt[w] = tt; s_tt[NW + w] = ha; s_tt[2 * NW + w] = hb; s_tt[3 * NW + w] = kmin; s_tt[4 * NW + w] = kmax;
+    }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        uint32_t sum = 0u;
-        for (int w = 0; w < TG_BLOCK / 64; ++w) sum += s_tt[threadIdx.x * (TG_BLOCK / 64) + w];
-        block_D[3 * blockIdx.x + threadIdx.x] = sum;          // {tiles_touched, fingerprint lo, fingerprint hi}
+    if (threadIdx.x < 5) {
+        uint32_t r = s_tt[threadIdx.x * NW];
+        for (int w = 1; w < NW; ++w) {
+            const uint32_t v = s_tt[threadIdx.x * NW + w];
+            r = (threadIdx.x < 3) ? r + v : ((threadIdx.x == 3) ? min(r, v) : max(r, v));
+        }
+        block_D[5 * blockIdx.x + threadIdx.x] = r;          // {tiles_touched, fingerprint lo, fingerprint hi, min depth key, max depth key}
     }
 }
 
