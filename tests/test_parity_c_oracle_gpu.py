@@ -219,23 +219,29 @@ def test_more_than_65536_tiles_three_digit_tile_sort(lib_built):
     assert lib.texgs_mark_visible(C.byref(fr2), 1, 1, None) != 0 and b"2^24 tiles" in lib.texgs_last_error()
 
 
-@pytest.mark.parametrize("kind", ["one_depth", "two_clusters"])
-def test_depth_sort_with_crowded_depth_buckets(lib_built, kind):
-    """K2's in-LDS bucket sort holds 2 048 pairs; a bucket with more (many Gaussians at (nearly) the same view depth: a wall seen
-    frontally) is sorted by the single-workgroup LSD radix fallback in global memory.  one_depth: 12 000 Gaussians on 3 distinct
-    depths (range < 1 024 keys: a bucket holds one key, thousands of times: sorted by index only); two_clusters: two sheets of 48 depths and one
-    far Gaussian that stretches the range (bucket width 2^16 keys: key passes AND index passes).  Rank order, offsets, instance
-    keys, point list and ranges must be the C oracle's, bit for bit."""
+@pytest.mark.parametrize("kind", ["one_depth", "two_clusters", "far_outlier"])
+def test_depth_sort_with_crowded_depth_bins(lib_built, kind):
+    """K2 partitions the Gaussians into depth bins (equal width in key space between the smallest and the largest valid key), cuts
+    the bins into balanced groups and sorts every group: <= 1 024 pairs in registers, <= 2 048 in LDS, more (one BIN holds them: many
+    Gaussians at (nearly) the same view depth, a wall seen frontally) by a one-wave LSD radix in global memory.  one_depth: 12 000
+    Gaussians on 3 distinct depths (range narrower than the bin count: a bin holds one key, thousands of times: sorted by index
+    only); two_clusters: two sheets of 48 depths and one far Gaussian that stretches the range (key passes AND index passes);
+    far_outlier: 30 000 Gaussians spread over two units of depth and one at 90 -- the content falls into a few bins of several
+    ~1 000 either side of 1 024 (the widest register network and the LDS sort).  Rank order, offsets, instance keys, point list and
+    ranges must be the C oracle's, bit for bit."""
     g = torch.Generator().manual_seed(3)
-    N = 12000 if kind == "one_depth" else 9001
+    N = {"one_depth": 12000, "two_clusters": 9001, "far_outlier": 30000}[kind]
     cam = synth.look_at_camera((0.0, 0.0, -3.2), 320, 240, fovx=0.9)
     scene = synth.make_scene(N, 32, seed=8, scale_mean=0.02)
     xy = (torch.rand(N, 2, generator=g) - 0.5) * 1.8
     steps = torch.randint(0, 3 if kind == "one_depth" else 48, (N,), generator=g).float() * 2.0 ** -21
     if kind == "one_depth":
         z = -1.2 + steps
-    else:
+    elif kind == "two_clusters":
         z = torch.where(torch.arange(N) % 2 == 0, -1.2 + steps, 0.8 + steps)
+        z[-1] = 90.0
+    else:
+        z = 1.5 + 2.0 * torch.rand(N, generator=g)
         z[-1] = 90.0
     means = torch.cat([xy, z[:, None]], 1).float().contiguous()
     scene = scene._replace(means3D=means)
@@ -246,8 +252,16 @@ def test_depth_sort_with_crowded_depth_buckets(lib_built, kind):
     t, D = s.tensors, ref.D
     vis = ref.radii[:N] > 0
     keys = np.where(vis, ref.depth[:N].view(np.uint32), np.uint32(0xFFFFFFFF))
-    uk, cnt = np.unique((keys[vis].astype(np.int64) - int(keys[vis].min())) >> (0 if kind == "one_depth" else 16), return_counts=True)
-    assert cnt.max() > 2048, cnt.max()                                            # a bucket beyond the in-LDS sort's capacity
+    # the kernel's bin of a key (binning.hip depth_range / depth_bin): NB = 256 for these N
+    kv = keys[vis].astype(np.uint64)
+    lo, rng, nb = int(kv.min()), int(kv.max() - kv.min()), 256
+    bins = (kv - lo) if rng < nb else (((kv - lo) * np.uint64((nb << 32) // (rng + 1))) >> np.uint64(32))
+    assert int(bins.max()) < nb
+    cnt = np.unique(bins, return_counts=True)[1]
+    if kind == "far_outlier":
+        assert 1024 < cnt.max() <= 2048 and np.sum((cnt > 512) & (cnt <= 1024)) > 0, np.sort(cnt)[-8:]
+    else:
+        assert cnt.max() > 2048, cnt.max()                                        # a bin beyond the in-LDS sort's capacity
     assert s.D == D and D > 10000
     assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
     order = np.argsort(keys.astype(np.uint64), kind="stable")

@@ -138,7 +138,7 @@ int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint3
     Readback& g_rb = g_rb_dev[dev];
     // K1 left five words per workgroup (three partial sums + the depth-key range the device-side sort uses; no atomics, nothing to
     // zero-fill): copy them, add the sums up here
-    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK, nw = 5 * nblk;
+    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK, nw = 3 * nblk;
     if (g_rb.words < nw) {
         if (g_rb.host) (void)hipHostFree(g_rb.host);
         g_rb.host = nullptr;
@@ -158,7 +158,7 @@ int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint3
     if (e != hipSuccess) return fail("num_rendered sync", e);
     unsigned long long total = 0ull;
     uint32_t fa = 0u, fb = 0u;
-    for (size_t k = 0; k < nblk; ++k) { total += g_rb.host[5 * k]; fa += g_rb.host[5 * k + 1]; fb += g_rb.host[5 * k + 2]; }
+    for (size_t k = 0; k < nblk; ++k) { total += g_rb.host[k]; fa += g_rb.host[nblk + k]; fb += g_rb.host[2 * nblk + k]; }
     if (total > 0xFFFFFFFFull) return fail_msg("num_rendered exceeds 2^32 - 1 instances");
     *host_out = (uint32_t)total;
     if (fingerprint_out) *fingerprint_out = ((uint64_t)fb << 32) | (uint64_t)fa;

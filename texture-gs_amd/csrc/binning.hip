@@ -5,9 +5,9 @@
 // The lineage gets there with ONE stable LSD sort of D 64-bit keys over 32 + log2(T) bits (6 onesweep passes with
 // decoupled look-back; rocPRIM's took 210 us at C3 -- every look-back hop is a ~1 us cross-XCD round trip here).
 // This file sorts in two levels instead:
-//   1. the N GAUSSIANS by (depth bits, index) (culled ones carry 0xFFFFFFFF): an MSD partition into <= 1025 depth buckets and an
-//      in-LDS sort of every bucket (round 4; rounds 2-3: four stable 8-bit passes),
-//   2. an exclusive scan of tiles_touched in that depth-rank order (inside the bucket sort + one add of the buckets in front),
+//   1. the N GAUSSIANS by (depth bits, index) (culled ones carry 0xFFFFFFFF): a partition into depth bins, cut into balanced
+//      groups of consecutive bins, and a bitonic sort of every group (round 4; rounds 2-3: four stable 8-bit passes),
+//   2. an exclusive scan of tiles_touched in that depth-rank order (inside the group sort + one add of the groups in front),
 //   3. K3 emits the instances in rank order, element = (tile << 32) | rank -- already sorted by rank,
 //   4. the D INSTANCES by tile only (2 stable passes over ceil(log2 T) bits); the last pass writes keys_sorted /
 //      point_list from the rank-ordered depth / index arrays.
@@ -198,42 +198,52 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
     }
 }
 
-// ---- K2, round 4: depth sort of the N Gaussians + exclusive scan of tiles_touched in rank order in FOUR launches --------------
+// ---- K2, round 4: depth sort of the N Gaussians + exclusive scan of tiles_touched in rank order in THREE launches -------------
 // (round 3: four stable 8-bit radix passes = 8 launches, + 2 for the scan; every launch is one or two dependent round trips over
 // 2.4 MB on a chip it cannot fill: 64 us at C3, 46 us at C2.)  Now:
-//   k_depth_count    MSD partition, step 1: K1 left (min, max) of the valid depth keys per workgroup; bucket = (key - min) >> shift
-//                    with shift chosen so that the range spans <= NB buckets (NB = a power of two ~ N / 256; culled Gaussians, key
-//                    0xFFFFFFFF: bucket NB); per-block LDS histogram -> global bucket totals (atomics);
+//   k_depth_count    partition, step 1: K1 left (min, max) of the valid depth keys per workgroup; bin = (key - min) * NB / (max -
+//                    min + 1) (NB = a power of two, 128 - 256 Gaussians per bin on average; culled Gaussians, key
+//                    0xFFFFFFFF: bin NB); per-block LDS histogram -> global bin totals (atomics);
 //   k_depth_scatter  step 2: exclusive scan of the totals (every block, redundantly), one returning atomic per (block, non-empty
-//                    bucket) reserves the block's slots, elements go to their bucket's region in ARBITRARY order;
-//   k_depth_bucket_sort  one workgroup per bucket: the bucket's (key, index) pairs are sorted by (key, index) -- a total order, so the
+//                    bin) reserves the block's slots, elements go to their bin's region in ARBITRARY order.  Block 0 also cuts
+//                    the bins into GROUPS of consecutive bins: a new group starts where the running total crosses a multiple of
+//                    DS_GROUP -- the sort units are balanced whatever the depth distribution (a far outlier stretches the key
+//                    range and leaves most bins empty; equal-width sort units would then hold thousands);
+//   k_depth_group_sort  one workgroup per group: its (key, index) pairs are sorted by (key, index) -- a total order, so the
 //                    arbitrary order of step 2 does not matter and the result is exactly the stable order by (depth bits, index)
-//                    of the lineage -- in registers (<= 64 pairs: one wave, bitonic network over lane shuffles), in
-//                    LDS (<= 2048, 256 threads), or by an LSD radix in global memory (more: > 2048 Gaussians in 1/NB of the depth range; slow,
-//                    correct); tiles_touched is gathered in that order and scanned inside the bucket;
-//   k_depth_prefix   one workgroup scans the buckets' tile sums.  K3 adds a rank's bucket prefix when it reads its offset (and
-//                    writes it back: geom->offsets is an output of the contract).
-// (Tried and dropped, profiles/r04_ablation.md: 8 192 buckets with a register-only sort -- the partition then pays one returning
-//  atomic per element; the scans done by "the last block to finish" -- a ticket word takes 13 ns per workgroup, same address.)
-constexpr int DS_NB_MAX = 8192;        // depth buckets (+ 1 for culled Gaussians)
+//                    of the lineage -- in registers (<= 1024 pairs: bitonic network over lane shuffles, LDS only for the two
+//                    cross-wave distances), in LDS (<= 2048), or by an LSD radix in global memory (a single bin holds > ~1900
+//                    Gaussians, i.e. 1/NB of the depth range does; one wave, slow, correct); tiles_touched is gathered in that
+//                    order and scanned inside the group;
+//                    K3 scans the groups' tile sums (every workgroup, redundantly) and adds a rank's group prefix when it reads
+//                    its offset (and writes it back: geom->offsets is an output of the contract).
+// (Tried and dropped, profiles/r04_ablation.md: equal-width sort units; one wave per unit; the scans done by "the last block to
+//  finish" -- a ticket word takes 13 ns per workgroup, same address.)
+constexpr int DS_NB_MAX = 8192;        // depth bins (+ 1 for culled Gaussians)
 constexpr int DS_THREADS = 256;
 constexpr int DS_PER = 2048;           // elements per block of the count / scatter kernels
-constexpr int DS_CAP = 2048;           // pairs a bucket may hold to be sorted in LDS
-constexpr uint32_t DS_COPY = 4096u;    // culled pairs one workgroup of the bucket-sort kernel copies
+constexpr int DS_CAP = 2048;           // pairs a group may hold to be sorted in LDS
+constexpr uint32_t DS_GROUP = 160u;    // a group closes at the first bin boundary past a multiple of this many Gaussians
+constexpr uint32_t DS_COPY = 4096u;    // culled pairs one workgroup of the group-sort kernel copies
 constexpr int DS_BLK_WORDS = 5;        // K1's per-workgroup words: tiles_touched, fingerprint lo / hi, min / max valid depth key
+// drange words (written by block 0 of k_depth_scatter)
+enum { DR_LO = 0, DR_SCALE = 1, DR_NB = 2, DR_GROUPS = 3, DR_BITS = 4 };
 
-struct DepthRange { uint32_t lo, shift, nb; };
+struct DepthRange { uint32_t lo, scale, nb, bits; };
 
-inline int depth_log2_buckets(int N) {              // NB ~ N / 256, a power of two in [64, DS_NB_MAX]: ~300 pairs per bucket.  (Finer
-    int lb = 6;                                     // buckets make the sort cheaper and the partition dearer: a block of the scatter
-    while ((1 << lb) < N / 256 && (1 << lb) < DS_NB_MAX) ++lb;      // kernel pays one returning atomic per distinct bucket it touches.)
-    return lb;
+inline int depth_log2_bins(int N) {                 // NB = the power of two in [256, DS_NB_MAX] with 128 < N / NB <= 256.  Measured at
+    int lb = 8;                                     // C3 (N = 300 k), count + scatter + sort + K3, us: NB 512: 76, 1024: 54.5, 2048:
+    while ((N >> lb) > 256 && (1 << lb) < DS_NB_MAX) ++lb;      // 54.6, 4096: 58, 8192: 65 -- finer bins make the sort cheaper and the
+    return lb;                                      // partition dearer (one returning atomic per (block, bin) it touches)
 }
+inline int depth_max_groups(int N, int nb) { const int g = N / (int)DS_GROUP + 2; return g < nb ? g : nb; }
 
-// every block derives the same (lo, shift) from K1's per-workgroup (min, max)
+// every block derives the same (lo, scale) from K1's per-workgroup (min, max)
 __device__ __forceinline__ DepthRange depth_range(const uint32_t* __restrict__ block_D, int nblk, int lb, uint32_t* s_red) {
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    for (int k = threadIdx.x; k < nblk; k += (int)blockDim.x) { mn = min(mn, block_D[DS_BLK_WORDS * k + 3]); mx = max(mx, block_D[DS_BLK_WORDS * k + 4]); }
+    const uint32_t *bmin = block_D + 3 * (size_t)nblk, *bmax = block_D + 4 * (size_t)nblk;
+#pragma unroll 4
+    for (int k = threadIdx.x; k < nblk; k += (int)blockDim.x) { mn = min(mn, bmin[k]); mx = max(mx, bmax[k]); }
     for (int d = 32; d >= 1; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); }
     const int nw = (int)blockDim.x >> 6;
     if (nw > 1) {
@@ -244,29 +254,33 @@ __device__ __forceinline__ DepthRange depth_range(const uint32_t* __restrict__ b
         __syncthreads();
     }
     const uint32_t range = (mx >= mn) ? mx - mn : 0u;
-    const int bits = range ? 32 - __clz((int)range) : 0;
-    DepthRange r; r.lo = mn; r.shift = bits > lb ? (uint32_t)(bits - lb) : 0u; r.nb = 1u << lb;
+    DepthRange r; r.lo = mn; r.nb = 1u << lb;
+    r.bits = range ? (uint32_t)(32 - __clz((int)range)) : 0u;
+    // bin = floor((key - lo) * scale / 2^32), scale = floor(2^32 * nb / (range + 1)) -> bin <= range * nb / (range + 1) < nb;
+    // a range narrower than nb keys: bin = key - lo (scale 0)
+    r.scale = (range < r.nb) ? 0u : (uint32_t)(((unsigned long long)r.nb << 32) / ((unsigned long long)range + 1ull));
     return r;
 }
-__device__ __forceinline__ uint32_t depth_bucket(uint32_t key, const DepthRange& r) {
-    return key == 0xFFFFFFFFu ? r.nb : ((key - r.lo) >> r.shift);
+__device__ __forceinline__ uint32_t depth_bin(uint32_t key, uint32_t lo, uint32_t scale, uint32_t nb) {
+    return key == 0xFFFFFFFFu ? nb : (scale ? __umulhi(key - lo, scale) : key - lo);
 }
+__device__ __forceinline__ uint32_t depth_bin(uint32_t key, const DepthRange& r) { return depth_bin(key, r.lo, r.scale, r.nb); }
 
 __global__ void __launch_bounds__(DS_THREADS)
 k_depth_count(const uint32_t* __restrict__ keys, int N, const uint32_t* __restrict__ block_D, int nblk, int lb, uint32_t* __restrict__ btot) {
     __shared__ uint32_t s_hist[DS_NB_MAX + 1];
     __shared__ uint32_t s_red[8];
     const int tid = threadIdx.x;
-    const DepthRange r = depth_range(block_D, nblk, lb, s_red);
-    const int nb1 = (int)r.nb + 1;
-    for (int k = tid; k < nb1; k += DS_THREADS) s_hist[k] = 0u;
-    __syncthreads();
     const int base = blockIdx.x * DS_PER;
-    uint32_t kk[DS_PER / DS_THREADS];
+    uint32_t kk[DS_PER / DS_THREADS];                   // issued before the (min, max) reduction: one round trip for both
 #pragma unroll
     for (int u = 0; u < DS_PER / DS_THREADS; ++u) { const int i = base + tid + u * DS_THREADS; kk[u] = (i < N) ? keys[i] : 0u; }
+    const int nb1 = (1 << lb) + 1;
+    for (int k = tid; k < nb1; k += DS_THREADS) s_hist[k] = 0u;
+    const DepthRange r = depth_range(block_D, nblk, lb, s_red);
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < DS_PER / DS_THREADS; ++u) if (base + tid + u * DS_THREADS < N) atomicAdd(&s_hist[depth_bucket(kk[u], r)], 1u);
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) if (base + tid + u * DS_THREADS < N) atomicAdd(&s_hist[depth_bin(kk[u], r)], 1u);
     __syncthreads();
     // consecutive lanes -> consecutive words: atomics on runs of addresses go through at 13x the rate of scattered ones (scripts/ubench)
     for (int k = tid; k < nb1; k += DS_THREADS) { const uint32_t c = s_hist[k]; if (c) atomicAdd(&btot[k], c); }
@@ -274,27 +288,27 @@ k_depth_count(const uint32_t* __restrict__ keys, int N, const uint32_t* __restri
 
 __global__ void __launch_bounds__(DS_THREADS)
 k_depth_scatter(const uint32_t* __restrict__ keys, int N, const uint32_t* __restrict__ block_D, int nblk, int lb,
-                const uint32_t* __restrict__ btot, uint32_t* __restrict__ bcur, uint32_t* __restrict__ gbase,
-                uint32_t* __restrict__ drange, uint32_t* __restrict__ key_out, uint32_t* __restrict__ val_out) {
-    __shared__ uint32_t s_hist[DS_NB_MAX + 1];          // this block's counts, then its next free slot per bucket
+                const uint32_t* __restrict__ btot, uint32_t* __restrict__ bcur, uint32_t* __restrict__ gpos, uint32_t* __restrict__ gmap,
+                uint32_t* __restrict__ drange, unsigned long long* __restrict__ pair_out) {
+    __shared__ uint32_t s_hist[DS_NB_MAX + 1];          // this block's counts, then its next free slot per bin
     __shared__ uint32_t s_base[DS_NB_MAX + 2];
     __shared__ uint32_t s_red[8];
     __shared__ uint32_t s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const DepthRange r = depth_range(block_D, nblk, lb, s_red);
-    const int nb1 = (int)r.nb + 1;
-    for (int k = tid; k < nb1; k += DS_THREADS) s_hist[k] = 0u;
-    __syncthreads();
     const int base = blockIdx.x * DS_PER;
-    uint32_t kk[DS_PER / DS_THREADS];
+    const int nb = 1 << lb, nb1 = nb + 1;
+    uint32_t kk[DS_PER / DS_THREADS];                   // keys, bin totals and K1's (min, max): all loads in flight together
 #pragma unroll
     for (int u = 0; u < DS_PER / DS_THREADS; ++u) { const int i = base + tid + u * DS_THREADS; kk[u] = (i < N) ? keys[i] : 0u; }
+    for (int k = tid; k < nb1; k += DS_THREADS) { s_base[k] = btot[k]; s_hist[k] = 0u; }
+    const DepthRange r = depth_range(block_D, nblk, lb, s_red);
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < DS_PER / DS_THREADS; ++u) if (base + tid + u * DS_THREADS < N) atomicAdd(&s_hist[depth_bucket(kk[u], r)], 1u);
-    {   // exclusive scan of the nb + 1 bucket totals (every block, redundantly: 4-8 KB of L2 reads): thread t owns `per` consecutive buckets
-        const int per = (nb1 + DS_THREADS - 1) / DS_THREADS;
+    for (int u = 0; u < DS_PER / DS_THREADS; ++u) if (base + tid + u * DS_THREADS < N) atomicAdd(&s_hist[depth_bin(kk[u], r)], 1u);
+    const int per = (nb1 + DS_THREADS - 1) / DS_THREADS;
+    {   // exclusive scan of the nb + 1 bin totals in LDS (every block, redundantly): thread t owns `per` consecutive bins
         uint32_t sum = 0u;
-        for (int k = 0; k < per; ++k) { const int bkt = tid * per + k; sum += (bkt < nb1) ? btot[bkt] : 0u; }
+        for (int k = 0; k < per; ++k) { const int q = tid * per + k; sum += (q < nb1) ? s_base[q] : 0u; }
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
@@ -302,20 +316,58 @@ k_depth_scatter(const uint32_t* __restrict__ keys, int N, const uint32_t* __rest
         __syncthreads();
         uint32_t run = incl - sum;
         for (int w = 0; w < wv; ++w) run += s_w[w];
-        for (int k = 0; k < per; ++k) { const int bkt = tid * per + k; if (bkt <= nb1) s_base[bkt] = run; run += (bkt < nb1) ? btot[bkt] : 0u; }
+        for (int k = 0; k < per; ++k) { const int q = tid * per + k; if (q < nb1) { const uint32_t c = s_base[q]; s_base[q] = run; run += c; } }
+        if (tid == DS_THREADS - 1) s_base[nb1] = run;
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int k = tid; k <= nb1; k += DS_THREADS) gbase[k] = s_base[k];
-        if (tid == 0) { drange[0] = r.lo; drange[1] = r.shift; drange[2] = r.nb; }
+    // this block's slots in every bin it has elements for: one returning atomic per (block, bin), consecutive lanes on consecutive
+    // words, eight in flight per thread (the LDS store needs the atomic's result: one at a time is one round trip each)
+    for (int k0 = 0; k0 < nb1; k0 += 8 * DS_THREADS) {
+        uint32_t c[8], o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * DS_THREADS + tid; c[u] = (k < nb1) ? s_hist[k] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * DS_THREADS + tid; o[u] = c[u] ? atomicAdd(&bcur[k], c[u]) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * DS_THREADS + tid; if (k < nb1) s_hist[k] = s_base[k] + o[u]; }
     }
-    // this block's slots in every bucket it has elements for: one returning atomic per (block, bucket), consecutive lanes on consecutive words
-    for (int k = tid; k < nb1; k += DS_THREADS) { const uint32_t c = s_hist[k]; s_hist[k] = c ? s_base[k] + atomicAdd(&bcur[k], c) : 0u; }
+    if (blockIdx.x == 0) {
+        // groups of consecutive bins [0, nb): bin q opens a group when its first slot lies in another DS_GROUP-block of slots than
+        // the previous bin's.  gpos[g] = first slot of group g (gpos[G] = number of valid Gaussians), gmap[q] = group of bin q;
+        // the culled bin nb is "group" G with tile sum 0.
+        unsigned long long flags = 0ull;                // thread t owns bins [t * per, t * per + per), per <= 33
+        for (int k = 0; k < per; ++k) {
+            const int q = tid * per + k;
+            if (q < nb && (q == 0 || s_base[q] / DS_GROUP != s_base[q - 1] / DS_GROUP)) flags |= 1ull << k;
+        }
+        const uint32_t mine = (uint32_t)__popcll(flags);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        __syncthreads();                                // s_w is reused
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t g = incl - mine;                       // groups opened before this thread's bins
+        for (int w = 0; w < wv; ++w) g += s_w[w];
+        const uint32_t G = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        for (int k = 0; k < per; ++k) {
+            const int q = tid * per + k;
+            if (q < nb) {
+                if ((flags >> k) & 1ull) { gpos[g] = s_base[q]; ++g; }
+                gmap[q] = g - 1u;                       // bin 0 always opens group 0
+            }
+        }
+        if (tid == 0) {
+            gpos[G] = s_base[nb]; gpos[G + 1] = s_base[nb1];        // culled "group": [valid, N)
+            gmap[nb] = G;
+            drange[DR_LO] = r.lo; drange[DR_SCALE] = r.scale; drange[DR_NB] = r.nb; drange[DR_GROUPS] = G; drange[DR_BITS] = r.bits;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < DS_PER / DS_THREADS; ++u) {
         const int i = base + tid + u * DS_THREADS;
-        if (i < N) { const uint32_t p = atomicAdd(&s_hist[depth_bucket(kk[u], r)], 1u); key_out[p] = kk[u]; val_out[p] = (uint32_t)i; }
+        if (i < N) { const uint32_t p = atomicAdd(&s_hist[depth_bin(kk[u], r)], 1u); pair_out[p] = ((unsigned long long)kk[u] << 32) | (unsigned long long)(uint32_t)i; }
     }
 }
 
@@ -370,35 +422,126 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long x,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Bitonic sort of P = 256 * E pairs held E per thread (element i = e * 256 + tid) by one workgroup of 256: compare-exchange
+// distances j < 64 go over lane shuffles, j = 64 / 128 through LDS (the partner sits in another wave), j >= 256 stay inside the
+// thread's registers.  P = 256: 33 of the 36 steps never touch LDS or a barrier.
+template <int E>
+__device__ __forceinline__ void bitonic_regs(unsigned long long (&x)[E], unsigned long long* s_pair, int tid) {
+    constexpr uint32_t P = 256u * E;
+#pragma unroll
+    for (uint32_t k = 2u; k <= P; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            if (j >= 256u) {
+                constexpr int dummy = 0; (void)dummy;
+                const uint32_t je = j >> 8;
+#pragma unroll
+                for (uint32_t e = 0; e < (uint32_t)E; ++e) {
+                    if ((e & je) == 0u) {
+                        const uint32_t i = e * 256u + (uint32_t)tid;
+                        const bool up = (i & k) == 0u;
+                        const unsigned long long a = x[e], c = x[e | je];
+                        const bool sw = (a > c) == up;
+                        x[e] = sw ? c : a; x[e | je] = sw ? a : c;
+                    }
+                }
+            } else if (j >= 64u) {
+                __syncthreads();
+#pragma unroll
+                for (uint32_t e = 0; e < (uint32_t)E; ++e) s_pair[e * 256u + (uint32_t)tid] = x[e];
+                __syncthreads();
+#pragma unroll
+                for (uint32_t e = 0; e < (uint32_t)E; ++e) {
+                    const uint32_t i = e * 256u + (uint32_t)tid;
+                    const unsigned long long y = s_pair[i ^ j];
+                    const bool take_min = ((i & k) == 0u) == ((i & j) == 0u);
+                    x[e] = take_min ? (x[e] < y ? x[e] : y) : (x[e] > y ? x[e] : y);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < (uint32_t)E; ++e) {
+                    const uint32_t i = e * 256u + (uint32_t)tid;
+                    const unsigned long long y = shfl_xor_u64(x[e], (int)j);
+                    const bool take_min = ((i & k) == 0u) == ((i & j) == 0u);
+                    x[e] = take_min ? (x[e] < y ? x[e] : y) : (x[e] > y ? x[e] : y);
+                }
+            }
+        }
+    }
+}
+
+// sorts the group [start, start + n), n <= 256 * E, writes (key, index) and the in-group exclusive scan of tiles_touched in
+// rank order; returns the group's tile sum (in every thread)
+template <int E>
+__device__ __forceinline__ uint32_t group_sort_regs(const unsigned long long* __restrict__ pair_a, uint32_t start, uint32_t n,
+                                                     uint32_t* __restrict__ key_b, uint32_t* __restrict__ val_b,
+                                                     const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ offs_rank,
+                                                     unsigned long long* s_pair, uint32_t* s_w, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    unsigned long long x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const uint32_t i = (uint32_t)e * 256u + (uint32_t)tid; x[e] = (i < n) ? pair_a[start + i] : ~0ull; }
+    bitonic_regs<E>(x, s_pair, tid);
+    uint32_t tt[E], incl[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const uint32_t i = (uint32_t)e * 256u + (uint32_t)tid; tt[e] = (i < n) ? tiles_touched[(uint32_t)x[e]] : 0u; }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t v = tt[e];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; }
+        incl[e] = v;
+        if (lane == 63) s_w[e * 4 + wv] = v;
+    }
+    __syncthreads();
+    uint32_t run = 0u, total = 0u;
+#pragma unroll
+    for (int q = 0; q < 4 * E; ++q) { const uint32_t w = s_w[q]; total += w; }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)e * 256u + (uint32_t)tid;
+        uint32_t base = run;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t sw = s_w[e * 4 + w]; if (w < wv) base += sw; run += sw; }
+        if (i < n) { key_b[start + i] = (uint32_t)(x[e] >> 32); val_b[start + i] = (uint32_t)x[e]; offs_rank[start + i] = base + incl[e] - tt[e]; }
+    }
+    return total;
+}
+
 __global__ void __launch_bounds__(DS_THREADS)
-k_depth_bucket_sort(int N, const uint32_t* __restrict__ btot, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ drange,
-                    uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
-                    const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ offs_rank, uint32_t* __restrict__ bsum, int nb) {
-    __shared__ unsigned long long s_pair[DS_CAP];          // 16 KB (LDS path; the fallback's digit table aliases it)
-    __shared__ uint32_t s_w[DS_THREADS / 64];
+k_depth_group_sort(int N, const uint32_t* __restrict__ gpos, const uint32_t* __restrict__ drange,
+                   unsigned long long* pair_a, uint32_t* key_b, uint32_t* val_b,
+                   const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ offs_rank, uint32_t* __restrict__ bsum, int gmax) {
+    __shared__ unsigned long long s_pair[DS_CAP];          // 16 KB: the cross-wave exchanges (the fallback's digit table aliases it)
+    __shared__ uint32_t s_w[4 * (DS_CAP / DS_THREADS)];
     const int b = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (b >= nb) {              // culled Gaussians: they emit nothing (tiles_touched = 0), their mutual order is irrelevant; the copy is
-        const uint32_t n = btot[nb], start = gbase[nb];         // spread over N / DS_COPY workgroups (one would be the kernel's tail)
-        const uint32_t lo = (uint32_t)(b - nb) * DS_COPY, hi = min(n, lo + DS_COPY);
-        for (uint32_t i = lo + tid; i < hi; i += DS_THREADS) { key_b[start + i] = key_a[start + i]; val_b[start + i] = val_a[start + i]; offs_rank[start + i] = 0u; }
-        if (b == nb && tid == 0) bsum[nb] = 0u;
+    const uint32_t G = drange[DR_GROUPS];                  // <= gmax (depth_max_groups)
+    if (b >= gmax) {            // culled Gaussians: they emit nothing (tiles_touched = 0), their mutual order is irrelevant; the copy is
+        const uint32_t start = gpos[G], n = gpos[G + 1] - start;        // spread over N / DS_COPY workgroups (one would be the kernel's tail)
+        const uint32_t lo = (uint32_t)(b - gmax) * DS_COPY, hi = min(n, lo + DS_COPY);
+        for (uint32_t i = lo + tid; i < hi; i += DS_THREADS) {
+            const unsigned long long x = pair_a[start + i];
+            key_b[start + i] = (uint32_t)(x >> 32); val_b[start + i] = (uint32_t)x; offs_rank[start + i] = 0u;
+        }
+        if (b == gmax && tid == 0) bsum[G] = 0u;
         return;
     }
-    const uint32_t n = btot[b], start = gbase[b];          // workgroup-uniform: every branch below is taken by all 256 threads or none
-    uint32_t total = 0u;                                     // this bucket's sum of tiles_touched (valid in thread 0 at the end)
+    const uint32_t start = gpos[b], n = gpos[b + 1] - start;     // (loaded before G is known: b + 1 <= gmax lies inside gpos)
+    if ((uint32_t)b >= G) return;
+    // n is workgroup-uniform: every branch below is taken by all 256 threads or none
+    uint32_t total = 0u;                                     // this group's sum of tiles_touched (valid in thread 0 at the end)
     if (n == 0u) {
         // nothing
     } else if (n <= 64u) {
         if (wv != 0) return;
-        // ---- registers: bitonic network over the 64 lanes of one wave (21 compare-exchange steps, two shuffles each)
-        unsigned long long x = (lane < (int)n) ? (((unsigned long long)key_a[start + lane] << 32) | (unsigned long long)val_a[start + lane]) : ~0ull;
+        // ---- one wave: bitonic network over the 64 lanes (21 compare-exchange steps, two shuffles each)
+        unsigned long long x = (lane < (int)n) ? pair_a[start + lane] : ~0ull;
 #pragma unroll
         for (int k = 2; k <= 64; k <<= 1)
 #pragma unroll
             for (int j = k >> 1; j > 0; j >>= 1) {
                 const unsigned long long y = shfl_xor_u64(x, j);
-                const bool up = ((lane & k) == 0), lower = ((lane & j) == 0);
-                const bool take_min = (up == lower);
+                const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
                 x = take_min ? (x < y ? x : y) : (x > y ? x : y);
             }
         const uint32_t tt = (lane < (int)n) ? tiles_touched[(uint32_t)x] : 0u;
@@ -407,23 +550,27 @@ k_depth_bucket_sort(int N, const uint32_t* __restrict__ btot, const uint32_t* __
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
         if (lane < (int)n) { key_b[start + lane] = (uint32_t)(x >> 32); val_b[start + lane] = (uint32_t)x; offs_rank[start + lane] = incl - tt; }
         total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    } else if (n <= 256u) {
+        total = group_sort_regs<1>(pair_a, start, n, key_b, val_b, tiles_touched, offs_rank, s_pair, s_w, tid);
+    } else if (n <= 512u) {
+        total = group_sort_regs<2>(pair_a, start, n, key_b, val_b, tiles_touched, offs_rank, s_pair, s_w, tid);
+    } else if (n <= 1024u) {
+        total = group_sort_regs<4>(pair_a, start, n, key_b, val_b, tiles_touched, offs_rank, s_pair, s_w, tid);
     } else if (n <= (uint32_t)DS_CAP) {
-        // ---- LDS: bitonic sort of (key << 32 | index), P = next power of two, padded with the largest value
-        uint32_t P = 128u;
-        while (P < n) P <<= 1;
-        for (uint32_t i = tid; i < P; i += DS_THREADS)
-            s_pair[i] = (i < n) ? (((unsigned long long)key_a[start + i] << 32) | (unsigned long long)val_a[start + i]) : ~0ull;
-        for (uint32_t k = 2u; k <= P; k <<= 1)
+        // ---- 1025 .. 2048 pairs (one bin holds most of them): bitonic sort in LDS, every step behind a barrier; 8 pairs
+        // per thread in registers would cost every group of the launch its occupancy
+        for (uint32_t i = tid; i < (uint32_t)DS_CAP; i += DS_THREADS) s_pair[i] = (i < n) ? pair_a[start + i] : ~0ull;
+        for (uint32_t k = 2u; k <= (uint32_t)DS_CAP; k <<= 1)
             for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
                 __syncthreads();
-                for (uint32_t t = tid; t < (P >> 1); t += DS_THREADS) {
+                for (uint32_t t = tid; t < (uint32_t)DS_CAP / 2u; t += DS_THREADS) {
                     const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
                     const unsigned long long x = s_pair[i], y = s_pair[l];
                     if ((x > y) == ((i & k) == 0u)) { s_pair[i] = y; s_pair[l] = x; }
                 }
             }
         __syncthreads();
-        const uint32_t E = (P + DS_THREADS - 1) / DS_THREADS;          // consecutive ranks per thread: 1 .. 8
+        constexpr uint32_t E = DS_CAP / DS_THREADS;          // consecutive ranks per thread
         uint32_t sum = 0u;
         for (uint32_t u = 0; u < E; ++u) {
             const uint32_t i = tid * E + u;
@@ -447,17 +594,24 @@ k_depth_bucket_sort(int N, const uint32_t* __restrict__ btot, const uint32_t* __
         total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     } else {
         if (wv != 0) return;
-        // ---- fallback (one wave): LSD radix by (key, index) in global memory, ping-pong between the bucket's regions of (a) and (b)
+        // ---- fallback (one wave): LSD radix by (key, index) in global memory.  The pairs are unpacked into the group's region of
+        // (b); the passes ping-pong between it and the group's own region of pair_a seen as two u32 arrays of n
         uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_pair);
-        const uint32_t lo = drange[0], shift = drange[1];
+        const uint32_t lo = drange[DR_LO];
         int nbv = 0; while ((1u << nbv) < (uint32_t)N && nbv < 32) ++nbv;          // index bits
-        const int pv = (nbv + 7) / 8, pk = ((int)shift + 7) / 8;
-        uint32_t *ki = key_a + start, *vi = val_a + start, *ko = key_b + start, *vo = val_b + start;
+        const int pv = (nbv + 7) / 8, pk = ((int)drange[DR_BITS] + 7) / 8;          // key bits that vary at all
+        uint32_t *ki = key_b + start, *vi = val_b + start, *ko = reinterpret_cast<uint32_t*>(pair_a + start), *vo = ko + n;
+        for (uint32_t c0 = 0u; c0 < n; c0 += 64u) {         // unpack 64 at a time (the scratch half is the pairs' own storage: all 64
+            const uint32_t i = c0 + lane;                   // loads of a row are done before its stores, rows ahead are untouched)
+            if (i < n) { const unsigned long long x = pair_a[start + i]; ki[i] = (uint32_t)(x >> 32); vi[i] = (uint32_t)x; }
+        }
+        __threadfence();
+        __builtin_amdgcn_wave_barrier();
         for (int p = 0; p < pv + pk; ++p) {
             wave_radix_pass(ki, vi, ko, vo, n, lo, p < pv, (p < pv ? p : p - pv) * 8, s_cnt);
             uint32_t* t = ki; ki = ko; ko = t; t = vi; vi = vo; vo = t;
         }
-        if (ki != key_b + start) {          // an even number of passes left the result in (a)
+        if (ki != key_b + start) {          // an odd number of passes left the result in the scratch half
             for (uint32_t i = lane; i < n; i += 64u) { key_b[start + i] = ld_coherent(ki + i); val_b[start + i] = ld_coherent(vi + i); }
             __threadfence();
             __builtin_amdgcn_wave_barrier();
@@ -474,44 +628,45 @@ k_depth_bucket_sort(int N, const uint32_t* __restrict__ btot, const uint32_t* __
         }
         total = carry;
     }
-    if (tid == 0) bsum[b] = total;          // the bucket's tile sum; k_depth_prefix scans them
-}
-
-// exclusive scan of the buckets' tile sums (one workgroup; <= 8 193 values)
-__global__ void __launch_bounds__(1024)
-k_depth_prefix(int nb1, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ bpre) {
-    __shared__ uint32_t s_w[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (nb1 + 1023) / 1024;            // <= 9
-    uint32_t v[9], sum = 0u;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { const int q = tid * per + k; v[k] = (k < per && q < nb1) ? bsum[q] : 0u; sum += v[k]; }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-    if (lane == 63) s_w[wv] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wv; ++w) run += s_w[w];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { const int q = tid * per + k; if (k < per && q < nb1) bpre[q] = run; run += v[k]; }
+    if (tid == 0) bsum[b] = total;          // the group's tile sum; K3 scans them
 }
 
 // K3: one thread per depth rank; emits that Gaussian's instances, element = (tile << 32) | rank, at offs_rank[rank]...
-// offs_rank[rank] arrives as the prefix INSIDE the rank's depth bucket (k_depth_bucket_sort); the bucket's own prefix is added here
+// offs_rank[rank] arrives as the prefix INSIDE the rank's sort group (k_depth_group_sort); the group's own prefix (scan of bsum) is added here
 // and the sum written back (geom->offsets = exclusive scan of tiles_touched in rank order is an output of the contract).
 // Also zero-fills `ranges` (empty tiles keep (0, 0); k_ranges runs later on the same stream).
 __global__ void __launch_bounds__(TG_BLOCK)
 k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ key_rank,
-            uint32_t* __restrict__ offs_rank, const uint32_t* __restrict__ drange, const uint32_t* __restrict__ bpre,
+            uint32_t* __restrict__ offs_rank, const uint32_t* __restrict__ drange, const uint32_t* __restrict__ gmap, const uint32_t* __restrict__ bsum,
             const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, uint64_t* __restrict__ elems,
             uint2* __restrict__ ranges, uint32_t* __restrict__ zero_words, int num_zero_words) {
+    __shared__ uint32_t s_pre[DS_NB_MAX + 1];
+    __shared__ uint32_t s_w[TG_BLOCK / 64];
     const int r = blockIdx.x * TG_BLOCK + threadIdx.x;
     for (int k = r; k < T; k += (int)gridDim.x * TG_BLOCK) ranges[k] = make_uint2(0u, 0u);
     for (int k = r; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // group count tables of the tile sort
+    const uint32_t d_lo = drange[DR_LO], d_scale = drange[DR_SCALE], d_nb = drange[DR_NB];
+    uint32_t my_group = 0u, my_off = 0u;                // issued ahead of the scan below: key -> bin -> group is two dependent loads
+    if (r < N) { my_group = gmap[depth_bin(key_rank[r], d_lo, d_scale, d_nb)]; my_off = offs_rank[r]; }
+    {   // exclusive scan of the groups' tile sums (every block, redundantly: <= 32 KB of L2 reads; a kernel of its own costs more)
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nb1 = (int)drange[DR_GROUPS] + 1;
+        for (int q = tid; q < nb1; q += TG_BLOCK) s_pre[q] = bsum[q];
+        __syncthreads();
+        const int per = (nb1 + TG_BLOCK - 1) / TG_BLOCK;
+        uint32_t sum = 0u;
+        for (int k = 0; k < per; ++k) { const int q = tid * per + k; sum += (q < nb1) ? s_pre[q] : 0u; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < wv; ++w) run += s_w[w];
+        for (int k = 0; k < per; ++k) { const int q = tid * per + k; if (q < nb1) { const uint32_t c = s_pre[q]; s_pre[q] = run; run += c; } }
+        __syncthreads();
+    }
     if (r >= N) return;
-    DepthRange dr; dr.lo = drange[0]; dr.shift = drange[1]; dr.nb = drange[2];
-    uint32_t off = offs_rank[r] + bpre[depth_bucket(key_rank[r], dr)];
+    uint32_t off = my_off + s_pre[my_group];
     offs_rank[r] = off;
     const uint32_t id = id_rank[r];
     if (tiles_touched[id] == 0u) return;
@@ -582,17 +737,18 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- scratch layouts ------------------------------------------------------------------------------------------------
 // scan_temp (Gaussian level, sized by scan_temp_bytes(N)):
-//   [0]        header zero-filled by K1: btot[DS_NB_MAX + 1] bucket totals, bcur[DS_NB_MAX + 1] bucket fill counters, done[2]
-//   then       gbase[DS_NB_MAX + 2], bsum / bpre[DS_NB_MAX + 1], drange[4], key_a, key_b, val_a, val_b (u32[N] each),
-//              block_D (u32[ceil(N / 256)][5])
+//   [0]        header zero-filled by K1: btot[DS_NB_MAX + 1] bin totals, bcur[DS_NB_MAX + 1] bin fill counters
+//   then       gpos[DS_NB_MAX + 2], gmap / bsum[DS_NB_MAX + 1], drange[8], pair_a (u64[N]), key_b, val_b (u32[N] each),
+//              block_D (u32[5][ceil(N / 256)])
 // sort_temp (instance level, sized by sort_temp_bytes(capacity, T)):
 //   [0]        header zero-filled by K3: 3 x gtable of the tile passes
 //   then       3 x table, elem_tmp (u64[capacity])
 struct GaussScratch {
-    uint32_t *btot, *bcur;  // header (K1 zero-fills it; the `done` ticket word follows bcur)
-    uint32_t *gbase, *bsum, *bpre, *drange;
-    uint32_t* block_D;      // [ceil(N / 256)][5] K1's per-workgroup {sum of tiles_touched, fingerprint lo, hi, min / max valid depth key}
-    uint32_t *key_a, *key_b, *val_a, *val_b;
+    uint32_t *btot, *bcur;  // header (K1 zero-fills it)
+    uint32_t *gpos, *gmap, *bsum, *drange;
+    uint32_t* block_D;      // [5][ceil(N / 256)] K1's per-workgroup sums of tiles_touched, fingerprint lo, hi, min / max valid depth key
+    unsigned long long* pair_a;     // [N] (key << 32 | index) partitioned into depth bins
+    uint32_t *key_b, *val_b;       // [N] depth bits / Gaussian index in rank order
     size_t header_bytes;
 };
 inline size_t zero_header_bytes(int passes, size_t extra) { return align256((size_t)passes * RS_ZERO_WORDS * 4 + extra); }
@@ -603,14 +759,13 @@ inline GaussScratch gauss_scratch(void* base, int N) {
     g.header_bytes = depth_header_bytes();
     g.btot = (uint32_t*)p; g.bcur = g.btot + (DS_NB_MAX + 1);
     p += g.header_bytes;
-    g.gbase = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 2) * 4);
+    g.gpos = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 2) * 4);
+    g.gmap = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 1) * 4);
     g.bsum = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 1) * 4);
-    g.bpre = (uint32_t*)p; p += align256((size_t)(DS_NB_MAX + 1) * 4);
     g.drange = (uint32_t*)p; p += 256;
     const size_t nb = align256((size_t)(N > 0 ? N : 1) * 4);
-    g.key_a = (uint32_t*)p; p += nb;
+    g.pair_a = (unsigned long long*)p; p += 2 * nb;
     g.key_b = (uint32_t*)p; p += nb;
-    g.val_a = (uint32_t*)p; p += nb;
     g.val_b = (uint32_t*)p; p += nb;
     g.block_D = (uint32_t*)p;
     return g;
@@ -647,30 +802,30 @@ size_t sort_temp_bytes(uint32_t D, uint32_t T) {
 }
 
 uint32_t* bin_block_sums_ptr(const TexGSGeom* g, int N) { return gauss_scratch(g->scan_temp, N).block_D; }
-uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // bucket totals / fill counters of the depth sort: K1 zero-fills them
+uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // bin totals / fill counters of the depth sort: K1 zero-fills them
     const GaussScratch gs = gauss_scratch(g->scan_temp, N);
     *words = (int)(gs.header_bytes / 4);
     return gs.btot;
 }
 
-// Gaussian level: depth sort + exclusive scan of tiles_touched in rank order (four launches, see above).  Needs K1's depth keys
+// Gaussian level: depth sort + exclusive scan of tiles_touched in rank order (three launches, see above).  Needs K1's depth keys
 // (bits of view z; 0xFFFFFFFF for culled) in g->depth and its per-workgroup (min, max).  Independent of D: runs while the host
 // waits for the D readback.  Result: (key_b, val_b) = depth bits / Gaussian index in rank order; g->offsets = the prefix inside
-// each rank's bucket, completed by K3 with bpre.
+// each rank's sort group, completed by K3 with the scan of the groups' tile sums.
 int launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s) {
     if (N <= 0) return 0;
     const GaussScratch gs = gauss_scratch(g->scan_temp, N);
     const int nblk = (N + TG_BLOCK - 1) / TG_BLOCK;
     const int blocks = (N + DS_PER - 1) / DS_PER;
-    const int lb = depth_log2_buckets(N), nb = 1 << lb;
+    const int lb = depth_log2_bins(N);
+    const int gmax = depth_max_groups(N, 1 << lb);
     const uint32_t* keys = reinterpret_cast<const uint32_t*>(g->depth);
     hipLaunchKernelGGL(k_depth_count, dim3(blocks), dim3(DS_THREADS), 0, s, keys, N, (const uint32_t*)gs.block_D, nblk, lb, gs.btot);
     hipLaunchKernelGGL(k_depth_scatter, dim3(blocks), dim3(DS_THREADS), 0, s, keys, N, (const uint32_t*)gs.block_D, nblk, lb,
-                       (const uint32_t*)gs.btot, gs.bcur, gs.gbase, gs.drange, gs.key_a, gs.val_a);
-    hipLaunchKernelGGL(k_depth_bucket_sort, dim3(nb + (N + (int)DS_COPY - 1) / (int)DS_COPY), dim3(DS_THREADS), 0, s, N, (const uint32_t*)gs.btot, (const uint32_t*)gs.gbase,
-                       (const uint32_t*)gs.drange, gs.key_a, gs.val_a, gs.key_b, gs.val_b, (const uint32_t*)g->tiles_touched,
-                       g->offsets, gs.bsum, nb);
-    hipLaunchKernelGGL(k_depth_prefix, dim3(1), dim3(1024), 0, s, nb + 1, (const uint32_t*)gs.bsum, gs.bpre);
+                       (const uint32_t*)gs.btot, gs.bcur, gs.gpos, gs.gmap, gs.drange, gs.pair_a);
+    hipLaunchKernelGGL(k_depth_group_sort, dim3(gmax + (N + (int)DS_COPY - 1) / (int)DS_COPY), dim3(DS_THREADS), 0, s, N,
+                       (const uint32_t*)gs.gpos, (const uint32_t*)gs.drange, gs.pair_a, gs.key_b, gs.val_b,
+                       (const uint32_t*)g->tiles_touched, g->offsets, gs.bsum, gmax);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -680,7 +835,7 @@ void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hi
     const GaussScratch gs = gauss_scratch(g->scan_temp, c.N);
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
     hipLaunchKernelGGL(k_duplicate, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, (const uint32_t*)gs.val_b,
-                       (const uint32_t*)gs.key_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.bpre,
+                       (const uint32_t*)gs.key_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.gmap, (const uint32_t*)gs.bsum,
                        (const uint32_t*)g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges),
                        reinterpret_cast<uint32_t*>(b->sort_temp), (int)(zero_header_bytes(TILE_PASSES_MAX, 0) / 4));
 }

@@ -451,7 +451,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
             const uint32_t v = s_tt[threadIdx.x * NW + w];
             r = (threadIdx.x < 3) ? r + v : ((threadIdx.x == 3) ? min(r, v) : max(r, v));
         }
-        block_D[5 * blockIdx.x + threadIdx.x] = r;          // {tiles_touched, fingerprint lo, fingerprint hi, min depth key, max depth key}
+        block_D[threadIdx.x * gridDim.x + blockIdx.x] = r;  // five arrays of gridDim.x: tiles_touched, fingerprint lo, hi, min / max valid depth key
     }
 }
 
