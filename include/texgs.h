@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 10
+#define TEXGS_ABI_VERSION 11
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
 #define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
@@ -174,7 +174,8 @@ typedef struct TexGSGrads {
                                   backward: no initialisation) + two status words: [count] receives max(records a call needed)
                                   -- zero it once; never cleared by the library: the caller sizes tex_rec_cap from it --,
                                   [count+1] = bits of max |dL/dpixel colour| of the call in flight (reset by every backward).  */
-    uint32_t* tex_bin_base;    /* u32[texgs_tex_bin_count(R) + 1]: scratch, list offsets of this call (no initialisation)    */
+    uint32_t* tex_bin_base;    /* u32[2 * texgs_tex_bin_count(R) + 1]: scratch of this call (no initialisation): the list
+                                  offsets [count + 1], then the reduce kernel's launch order [count] (v11)                  */
     uint32_t  tex_rec_cap;     /* records tex_bins holds.  Too small is not an error: footprints that do not fit fall back
                                   to atomics.                                                                            */
     int32_t accumulate;        /* bit mask (TEXGS_ACC_*): K8 ADDS into the per-Gaussian outputs whose bit is set (fused gradient

@@ -30,5 +30,5 @@ cat gpurun_out/variants.jsonl | cut -c1-400
 bash scripts/prof.sh > gpurun_out/prof.log 2>&1
 python scripts/prof_summary.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1
 python scripts/make_traffic.py gpurun_out/prof gpurun_out/traffic.json > /dev/null 2>&1
-grep -E "k_render|k_texgrad|k_preprocess|k_bin_off|k_radix|k_scan|k_dup|k_ranges|k_tile" gpurun_out/prof_summary.txt | grep calls | head -40
+grep -E "k_render|k_texgrad|k_preprocess|k_bin_off|k_radix|k_depth|k_dup|k_ranges|k_tile" gpurun_out/prof_summary.txt | grep calls | head -40
 cat gpurun_out/traffic.json | head -50

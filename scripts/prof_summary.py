@@ -6,7 +6,7 @@ def short(n):
         if k in n: return k
     if "k_radix_count" in n: return "k_radix_count"
     if "k_radix_scatter" in n: return "k_radix_scatter:" + n.split("<")[-1][:24]
-    for k in ("k_scan_sums", "k_scan_apply", "k_bin_offsets", "k_tile_order"):
+    for k in ("k_depth_count", "k_depth_scatter", "k_depth_group_sort", "k_bin_offsets", "k_tile_order"):
         if k in n: return k
     return n[:60]
 # stats

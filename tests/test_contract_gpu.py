@@ -306,6 +306,12 @@ def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
                     assert torch.equal(sc_.bins.cursor[:nb], sc_.bins.base[1:nb + 1]), mode
                     wanted = int(sc_.bins.cursor[nb])
                     assert wanted == int(sc_.bins.base[nb]) > 2000          # list sizes of the last call: what K6 counted
+                    # the reduce kernel's launch order (k_bin_offsets): every bin once, longest list first (up to the 1/32-octave
+                    # length classes of the counting sort)
+                    order = sc_.bins.base[nb + 1:2 * nb + 1].long().cpu()
+                    assert torch.equal(torch.sort(order).values, torch.arange(nb)), mode
+                    lens = (sc_.bins.base[1:nb + 1] - sc_.bins.base[:nb]).long().cpu()[order]
+                    assert bool((lens[1:].float() <= lens[:-1].float() * (1 + 1 / 32) + 1).all()), mode
             finally:
                 RZ.USE_TEX_BINS, RZ.TEX_REC_CAP = saved
                 RZ.release_scratch()

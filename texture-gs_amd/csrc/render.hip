@@ -499,6 +499,7 @@ struct TexBinArgs {
     float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
     uint32_t* cursor;      // [nbins] next free record of each list, ABSOLUTE (k_bin_offsets sets it to base[b] before every K7)
     const uint32_t* base;  // [nbins + 1] exclusive scan of K6's per-bin counts
+    const uint32_t* order; // [nbins] the reduce kernel's launch order: bins by falling list length (k_bin_offsets)
     uint32_t* stats;       // [0] max records a call wanted (for the host), [1] bits of max |dL/dpixel colour| of this call
     uint32_t  cap;         // records the buffer holds; what does not fit goes to dL_dtexture directly
     int       nb;          // bins per face row = ceil(R / 32)
@@ -943,7 +944,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 // cursor IS the record's position) (one workgroup; nbins = 6144 at R = 1024).
 __global__ void __launch_bounds__(1024)
 k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ cursor,
-              uint32_t* __restrict__ stats) {
+              uint32_t* __restrict__ order, uint32_t* __restrict__ stats) {
     // one pass: thread t owns the `per` consecutive counts [t * per, (t + 1) * per) -- serial inside the thread, one wave scan,
     // one cross-wave step (6 144 bins at R = 1024: 6 per thread).  Chunks of 1 024 x BO_MAX bins if there are more.
     constexpr int BO_MAX = 32;
@@ -978,6 +979,33 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
         if (s_carry > stats[0]) stats[0] = s_carry;      // what the lists of this view need: the host sizes the buffer from it
         stats[1] = 0u;                                   // max |dL/dpixel colour| of THIS call: K7 raises it, the reduce reads it
     }
+    // Launch order of the reduce kernel: longest list first (a C3 view: 6 144 lists, mean 3 000 records, the longest 33 000 --
+    // in index order the launch ends on whichever long list started late), as a counting sort on a 1024-level log-ish length
+    // class (speed only: any order is correct; ties keep no particular order).
+    __shared__ uint32_t s_cnt[1024];
+    auto length_class = [](uint32_t len) -> uint32_t {     // monotone decreasing in len: 1023 = empty, 0 = longest
+        if (len == 0u) return 1023u;
+        const uint32_t e = 31u - (uint32_t)__clz((int)len);
+        const uint32_t frac = (e >= 5u) ? ((len >> (e - 5u)) & 31u) : ((len << (5u - e)) & 31u);
+        return 1022u - min(e * 32u + frac, 1022u);
+    };
+    s_cnt[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nbins; i += 1024) atomicAdd(&s_cnt[length_class(count[i])], 1u);
+    __syncthreads();
+    {
+        const uint32_t c = s_cnt[tid];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - c;
+        for (int w = 0; w < wv; ++w) run += s_w[w];
+        s_cnt[tid] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < nbins; i += 1024) order[atomicAdd(&s_cnt[length_class(count[i])], 1u)] = (uint32_t)i;
 }
 
 // One workgroup per 32x32-texel bin: sum the bin's records into a 33x33-texel LDS tile (footprints anchored in the bin
@@ -994,10 +1022,11 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
 #define TB_EDGE 33
 #define TB_ROW 37       // texels per tile row in LDS: the pad puts rows y and y + 1 (taps 00 / 10 of one record) 30 banks apart; measured 180 -> 162 us
 #define TB_SEG (1u << 20)
-__global__ void __launch_bounds__(256)
+#define TB_THREADS 512  // 256: the same; 1024: 185 us (two workgroups per CU)
+__global__ void __launch_bounds__(TB_THREADS)
 k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __shared__ long long s_tile[TB_EDGE * TB_ROW * 3];           // [row][col (padded)][channel], 2^42-scaled fixed point
-    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int b = (int)tb.order[blockIdx.x], tid = (int)threadIdx.x;
     const uint32_t b0 = tb.base[b], b1 = tb.base[b + 1];
     const uint32_t filled = tb.cursor[b] - b0;                   // (the cursor is absolute; K7 bumped it once per record it wanted to append)
     if (filled == 0u) return;                                  // uniform per workgroup
@@ -1008,7 +1037,7 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     const uint32_t bbits = tb.stats[1];
     if (bbits >= 0x7F800000u) {                                // inf / NaN upstream gradient: float atomics, record by record
-        for (uint32_t i = (uint32_t)tid; i < cnt; i += 256u) {
+        for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)TB_THREADS) {
             const uint32_t fxw = __float_as_uint(rp[i]), fyw = __float_as_uint(rp[cap + i]);
             const float fx = __uint_as_float(fxw & ~31u), fy = __uint_as_float(fyw & ~31u);
             const uint32_t y = (uint32_t)by * 32u + (fyw & 31u), x = (uint32_t)bx * 32u + (fxw & 31u);
@@ -1041,12 +1070,13 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     };
     for (uint32_t s0 = 0u; s0 < cnt; s0 += TB_SEG) {             // one trip unless the list is longer than 2^20 records
         const uint32_t s1 = min(cnt, s0 + TB_SEG);
-        for (int k = tid; k < TB_EDGE * TB_ROW * 3; k += 256) s_tile[k] = 0ll;
+        for (int k = tid; k < TB_EDGE * TB_ROW * 3; k += TB_THREADS) s_tile[k] = 0ll;
         __syncthreads();
-        // two records per thread in flight (10 loads)
+        // two records per thread in flight (10 loads).  (More in flight, the next trip's loads issued ahead of the LDS atomics, lanes
+        // spread over distinct cells: no change -- 0.37 GB in 124 us is what dword streaming loads reach on this part, 3 TB/s.)
         uint32_t i = s0 + (uint32_t)tid;
-        for (; i + 256u < s1; i += 512u) {
-            const uint32_t i2 = i + 256u;
+        for (; i + (uint32_t)TB_THREADS < s1; i += 2u * (uint32_t)TB_THREADS) {
+            const uint32_t i2 = i + (uint32_t)TB_THREADS;
             const uint32_t fxa = __float_as_uint(rp[i]), fya = __float_as_uint(rp[cap + i]);
             const float xa0 = rp[2 * cap + i], xa1 = rp[3 * cap + i], xa2 = rp[4 * cap + i];
             const uint32_t fxb = __float_as_uint(rp[i2]), fyb = __float_as_uint(rp[cap + i2]);
@@ -1056,7 +1086,7 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         }
         if (i < s1) add_record(__float_as_uint(rp[i]), __float_as_uint(rp[cap + i]), rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
         __syncthreads();
-        for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += 256) {
+        for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += TB_THREADS) {
             const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
             const long long q = s_tile[row * (TB_ROW * 3) + c];
             if (q == 0ll) continue;
@@ -1095,6 +1125,7 @@ inline TexBinArgs make_bins(const CamConst& c, const TexGSImage* img, const TexG
     tb.rec = on ? gr->tex_bins : nullptr;
     tb.cursor = on ? gr->tex_bin_cursor : nullptr;
     tb.base = on ? gr->tex_bin_base : nullptr;
+    tb.order = on ? gr->tex_bin_base + tex_bin_count(c.R) + 1 : nullptr;
     tb.stats = on ? gr->tex_bin_cursor + tex_bin_count(c.R) : nullptr;
     tb.cap = on ? gr->tex_rec_cap : 0u;
     return tb;
@@ -1131,7 +1162,7 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     if (!tex && !geo) return;
     if (tex && tb.rec)      // list offsets + cursors from the counts the forward left (one small workgroup)
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
-                           gr->tex_bin_base, gr->tex_bin_cursor, tb.stats);
+                           gr->tex_bin_base, gr->tex_bin_cursor, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
     const dim3 grid(blend_grid(a.num_tiles)), blk(64);
 #define K7_LAUNCH(TEX, GEO, UVG, TAPS) hipLaunchKernelGGL((k_render_bwd<TEX, GEO, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
         img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
@@ -1149,5 +1180,5 @@ bool tex_bins_enabled(const CamConst& c, const TexGSInputs* in, const TexGSImage
 void launch_texgrad_reduce(const CamConst& c, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
     const TexBinArgs tb = make_bins(c, img, gr);
     if (!tb.rec) return;
-    hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(256), 0, s, c.R, tb, gr->dL_dtexture);
+    hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(TB_THREADS), 0, s, c.R, tb, gr->dL_dtexture);
 }

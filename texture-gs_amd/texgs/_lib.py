@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8

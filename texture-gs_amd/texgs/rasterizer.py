@@ -145,7 +145,7 @@ class _TexBins:
         self.device, self.R = device, R
         self.nbins = int(lib.texgs_tex_bin_count(R))
         self.cursor = torch.zeros(self.nbins + 2, dtype=torch.int32, device=device)
-        self.base = torch.empty(self.nbins + 1, dtype=torch.int32, device=device)
+        self.base = torch.empty(2 * self.nbins + 1, dtype=torch.int32, device=device)      # list offsets, then the reduce launch order
         self.cap = 0
         self.rec = None
         self.host_stat = torch.zeros(1, dtype=torch.int32).pin_memory()
