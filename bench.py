@@ -63,9 +63,9 @@ def algorithmic_bytes(N, K, D, D_eff, P, T, R, n_vis, n_touched, texels_touched)
     tex = 12 * texels_touched
     return {
         "preprocess_fwd": N * (92 + 12 * K) + n_vis * 96 + N * 20,
-        # K2: 4 stable radix passes over the N (depth key, index) pairs (count: 4N read; scatter: 8N read + 8N write) +
-        # exclusive scan of tiles_touched in rank order (2 x (8N read) + 4N write)
-        "scan": 4 * N * (4 + 8 + 8) + N * 20,
+        # K2: partition of the N depth keys into bins (count: 4N read; scatter: 4N read + 8N of (key, index) pairs written) + one
+        # sort per group of bins (8N read, 8N of rank-ordered key / index written, tiles_touched gathered 4N, offsets written 4N)
+        "scan": N * 4 + N * 12 + N * 24,
         "duplicate": N * 20 + D * 8 + T * 8,
         # K4: 2 stable passes over the D 8-byte (tile | rank) elements; the last writes 12 B / element and gathers 8 B
         "sort": 2 * D * (8 + 8) + D * 8 + D * (12 + 8),

@@ -84,7 +84,7 @@ typedef struct TexGSGeom {
     uint32_t* tiles_touched;   /* u32[N]                                                               */
     uint32_t* offsets;         /* u32[N] EXCLUSIVE prefix sum of tiles_touched in depth-rank order: offsets[r] = first
                                   instance slot of the r-th Gaussian of the (depth bits, index) order (K2)              */
-    void*     scan_temp;       /* >= texgs_scan_temp_bytes(N): count tables, D total, depth-sorted (key, index) pairs */
+    void*     scan_temp;       /* >= texgs_scan_temp_bytes(N): K1's per-workgroup words, depth bins, depth-sorted (key, index) */
     size_t    scan_temp_bytes;
 } TexGSGeom;
 
@@ -196,7 +196,7 @@ size_t texgs_tex_bin_count(int32_t tex_res);
 int texgs_preprocess_forward(const TexGSFrame* frame, const TexGSInputs* in, TexGSGeom* geom, void* stream);
 
 /* The one device->host sync of the forward (the lineage has the same one): starts the asynchronous readback of D,
- * launches K2 -- the stable 4-pass radix sort of the N Gaussians by depth bits and the exclusive scan of tiles_touched in
+ * launches K2 -- the sort of the N Gaussians by (depth bits, index) and the exclusive scan of tiles_touched in
  * that order, neither of which depends on D -- and only then waits for D, so the device is busy during the sync. */
 int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream);
 

@@ -6,6 +6,11 @@ mkdir -p gpurun_out
 rm -f gpurun_out/parity_report.jsonl
 timeout 1500 python -m pytest tests -m gpu -q -rA 2>&1 | grep -E "passed|failed|PASSED|FAILED|ERROR|rror" | tail -120 > gpurun_out/gpu_tests.log
 tail -3 gpurun_out/gpu_tests.log
+# the PMC traffic pass first: the bench lines below then carry roofline.traffic of THESE kernel sources
+bash scripts/prof.sh > gpurun_out/prof.log 2>&1
+python scripts/prof_summary.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1
+python scripts/make_traffic.py gpurun_out/prof gpurun_out/traffic.json > /dev/null 2>&1
+cp gpurun_out/traffic.json profiles/r04_traffic.json
 timeout 600 python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > gpurun_out/bench_c3_serial.json 2> gpurun_out/bench_c3_serial.err
 timeout 300 python bench.py --workload c2 --no-cpu-baseline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err
@@ -27,8 +32,5 @@ for n in ("c3", "c3_serial", "c2", "c5", "c3_diff_gauss", "c3_rccl1"):
         print(n, "ERR", e, open(f"gpurun_out/bench_{n}.err").read()[-800:])
 PY
 cat gpurun_out/variants.jsonl | cut -c1-400
-bash scripts/prof.sh > gpurun_out/prof.log 2>&1
-python scripts/prof_summary.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1
-python scripts/make_traffic.py gpurun_out/prof gpurun_out/traffic.json > /dev/null 2>&1
 grep -E "k_render|k_texgrad|k_preprocess|k_bin_off|k_radix|k_depth|k_dup|k_ranges|k_tile" gpurun_out/prof_summary.txt | grep calls | head -40
 cat gpurun_out/traffic.json | head -50
