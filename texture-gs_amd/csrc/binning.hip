@@ -224,6 +224,7 @@ constexpr int DS_THREADS = 256;
 constexpr int DS_PER = 2048;           // elements per block of the count / scatter kernels
 constexpr int DS_CAP = 2048;           // pairs a group may hold to be sorted in LDS
 constexpr uint32_t DS_GROUP = 160u;    // a group closes at the first bin boundary past a multiple of this many Gaussians
+constexpr int DS_FUSED_GROUPS = 2048;  // up to this many groups K3 scans the group sums itself; beyond: k_depth_prefix
 constexpr uint32_t DS_COPY = 4096u;    // culled pairs one workgroup of the group-sort kernel copies
 constexpr int DS_BLK_WORDS = 5;        // K1's per-workgroup words: tiles_touched, fingerprint lo / hi, min / max valid depth key
 // drange words (written by block 0 of k_depth_scatter)
@@ -631,16 +632,41 @@ k_depth_group_sort(int N, const uint32_t* __restrict__ gpos, const uint32_t* __r
     if (tid == 0) bsum[b] = total;          // the group's tile sum; K3 scans them
 }
 
+// exclusive scan, in place, of the groups' tile sums (one workgroup; <= DS_NB_MAX + 1 values): only for N beyond DS_FUSED_GROUPS
+// groups, see k_duplicate
+__global__ void __launch_bounds__(1024)
+k_depth_prefix(const uint32_t* __restrict__ drange, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb1 = (int)drange[DR_GROUPS] + 1;
+    const int per = (nb1 + 1023) / 1024;            // <= 9
+    uint32_t v[9], sum = 0u;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int q = tid * per + k; v[k] = (k < per && q < nb1) ? bsum[q] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wv; ++w) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int q = tid * per + k; if (k < per && q < nb1) bsum[q] = run; run += v[k]; }
+}
+
 // K3: one thread per depth rank; emits that Gaussian's instances, element = (tile << 32) | rank, at offs_rank[rank]...
 // offs_rank[rank] arrives as the prefix INSIDE the rank's sort group (k_depth_group_sort); the group's own prefix (scan of bsum) is added here
 // and the sum written back (geom->offsets = exclusive scan of tiles_touched in rank order is an output of the contract).
 // Also zero-fills `ranges` (empty tiles keep (0, 0); k_ranges runs later on the same stream).
+// PRE: `bsum` already holds the exclusive scan of the groups' tile sums (k_depth_prefix: large N, where every workgroup redoing
+// the scan is N^2 / 40 960 loads) -- otherwise the workgroup scans the <= 2 049 sums itself (cheaper than a launch).
+template <bool PRE>
 __global__ void __launch_bounds__(TG_BLOCK)
 k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ key_rank,
             uint32_t* __restrict__ offs_rank, const uint32_t* __restrict__ drange, const uint32_t* __restrict__ gmap, const uint32_t* __restrict__ bsum,
             const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, uint64_t* __restrict__ elems,
             uint2* __restrict__ ranges, uint32_t* __restrict__ zero_words, int num_zero_words) {
-    __shared__ uint32_t s_pre[DS_NB_MAX + 1];
+    __shared__ uint32_t s_pre[PRE ? 1 : DS_FUSED_GROUPS + 1];
     __shared__ uint32_t s_w[TG_BLOCK / 64];
     const int r = blockIdx.x * TG_BLOCK + threadIdx.x;
     for (int k = r; k < T; k += (int)gridDim.x * TG_BLOCK) ranges[k] = make_uint2(0u, 0u);
@@ -648,7 +674,10 @@ k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, con
     const uint32_t d_lo = drange[DR_LO], d_scale = drange[DR_SCALE], d_nb = drange[DR_NB];
     uint32_t my_group = 0u, my_off = 0u;                // issued ahead of the scan below: key -> bin -> group is two dependent loads
     if (r < N) { my_group = gmap[depth_bin(key_rank[r], d_lo, d_scale, d_nb)]; my_off = offs_rank[r]; }
-    {   // exclusive scan of the groups' tile sums (every block, redundantly: <= 32 KB of L2 reads; a kernel of its own costs more)
+    uint32_t my_pre = 0u;
+    if constexpr (PRE) {
+        if (r < N) my_pre = bsum[my_group];
+    } else {   // exclusive scan of the groups' tile sums (every block, redundantly: <= 8 KB of L2 reads; a kernel of its own costs more)
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nb1 = (int)drange[DR_GROUPS] + 1;
         for (int q = tid; q < nb1; q += TG_BLOCK) s_pre[q] = bsum[q];
         __syncthreads();
@@ -664,9 +693,10 @@ k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, con
         for (int w = 0; w < wv; ++w) run += s_w[w];
         for (int k = 0; k < per; ++k) { const int q = tid * per + k; if (q < nb1) { const uint32_t c = s_pre[q]; s_pre[q] = run; run += c; } }
         __syncthreads();
+        my_pre = s_pre[my_group];
     }
     if (r >= N) return;
-    uint32_t off = my_off + s_pre[my_group];
+    uint32_t off = my_off + my_pre;
     offs_rank[r] = off;
     const uint32_t id = id_rank[r];
     if (tiles_touched[id] == 0u) return;
@@ -826,6 +856,7 @@ int launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s) {
     hipLaunchKernelGGL(k_depth_group_sort, dim3(gmax + (N + (int)DS_COPY - 1) / (int)DS_COPY), dim3(DS_THREADS), 0, s, N,
                        (const uint32_t*)gs.gpos, (const uint32_t*)gs.drange, gs.pair_a, gs.key_b, gs.val_b,
                        (const uint32_t*)g->tiles_touched, g->offsets, gs.bsum, gmax);
+    if (gmax > DS_FUSED_GROUPS) hipLaunchKernelGGL(k_depth_prefix, dim3(1), dim3(1024), 0, s, (const uint32_t*)gs.drange, gs.bsum);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -834,10 +865,13 @@ void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hi
     if (c.N <= 0 || b->num_rendered == 0) return;
     const GaussScratch gs = gauss_scratch(g->scan_temp, c.N);
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
-    hipLaunchKernelGGL(k_duplicate, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, (const uint32_t*)gs.val_b,
-                       (const uint32_t*)gs.key_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.gmap, (const uint32_t*)gs.bsum,
-                       (const uint32_t*)g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges),
-                       reinterpret_cast<uint32_t*>(b->sort_temp), (int)(zero_header_bytes(TILE_PASSES_MAX, 0) / 4));
+    const bool pre = depth_max_groups(c.N, 1 << depth_log2_bins(c.N)) > DS_FUSED_GROUPS;       // (launch_depth_sort_scan ran k_depth_prefix)
+#define K3_LAUNCH(PRE) hipLaunchKernelGGL(k_duplicate<PRE>, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, (const uint32_t*)gs.val_b, \
+                       (const uint32_t*)gs.key_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.gmap, (const uint32_t*)gs.bsum, \
+                       (const uint32_t*)g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges), \
+                       reinterpret_cast<uint32_t*>(b->sort_temp), (int)(zero_header_bytes(TILE_PASSES_MAX, 0) / 4))
+    if (pre) K3_LAUNCH(true); else K3_LAUNCH(false);
+#undef K3_LAUNCH
 }
 
 // Instance level: stable LSD sort by tile id in 1-3 digits of at most 8 bits (two for up to 65 536 tiles); the last pass
