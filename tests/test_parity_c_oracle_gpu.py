@@ -275,3 +275,37 @@ def test_depth_sort_with_crowded_depth_bins(lib_built, kind):
     got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
     err = (got - torch.tensor(ref.out)).abs()
     assert float(err[[0, 1, 2, 4, 5, 6, 7]].max()) < 2e-4 and float(err[3].max()) < 2e-3
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 200, 257, 1025, 2049, 4097])
+def test_depth_sort_at_the_size_boundaries(lib_built, N):
+    """K2 / K3 at the sizes where their paths change hands: one wave (<= 64 pairs per group), 256 / 512 / 1 024 pairs in registers,
+    one and several blocks of the partition kernels (2 048 keys each), one and several K3 workgroups.  A third of the Gaussians sit
+    behind the camera (culled: key 0xFFFFFFFF, their own bin).  Offsets in rank order, instance keys, point list and ranges are the
+    C oracle's, bit for bit."""
+    g = torch.Generator().manual_seed(100 + N)
+    cam = synth.look_at_camera((0.0, 0.0, -3.2), 160, 128, fovx=0.9)
+    scene = synth.make_scene(N, 16, seed=9, scale_mean=0.05)
+    xy = (torch.rand(N, 2, generator=g) - 0.5) * 1.6
+    z = torch.rand(N, generator=g) * 2.0 - 1.0
+    z[torch.arange(N) % 3 == 2] = -5.0                  # behind the camera
+    scene = scene._replace(means3D=torch.cat([xy, z[:, None]], 1).float().contiguous())
+    bg = torch.zeros(3)
+    ref = CR.RefRun(scene, Hh.settings_for(cam, 1, bg))
+    ref.forward()
+    outs, s = Hh.hip_debug_state(scene, cam, 1, bg)
+    t, D = s.tensors, ref.D
+    assert s.D == D
+    vis = ref.radii[:N] > 0
+    assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
+    if D == 0:
+        return
+    keys = np.where(vis, ref.depth[:N].view(np.uint32), np.uint32(0xFFFFFFFF))
+    order = np.argsort(keys.astype(np.uint64), kind="stable")
+    tt_rank = ref.tiles[:N][order].astype(np.int64)
+    offs = t["offsets"][:N].cpu().numpy().astype(np.uint32).astype(np.int64)
+    nv = int(vis.sum())
+    assert np.array_equal(offs[:nv], (np.cumsum(tt_rank) - tt_rank)[:nv]) and np.all(offs[nv:] == D)
+    assert np.array_equal(t["keys_sorted"][:D].cpu().numpy().view(np.uint64), ref.keys_sorted[:D])
+    assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
+    assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
