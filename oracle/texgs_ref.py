@@ -119,6 +119,37 @@ class RefRun:
         self.acc = acc
         return g
 
+    def _preprocess_bwd(self, acc):
+        N, K = self.N, self.K
+        g = dict(means3D=np.zeros((N, 3), np.float32), means2D=np.zeros((N, 3), np.float32),
+                 shs=np.zeros((N, K, 3), np.float32) if K else None, opacities=np.zeros((N, 1), np.float32),
+                 scales=np.zeros((N, 3), np.float32), rotations=np.zeros((N, 4), np.float32), uvs=np.zeros((N, 3), np.float32))
+        self.lib.texgs_ref_preprocess_bwd(C.byref(self.inp), _p(self.radii), _p(acc), _p(g["means3D"]), _p(g["means2D"]),
+                                          _p(g["shs"]), _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["uvs"]))
+        return g
+
+    def accumulation_sensitive(self, delta=1e-6, trials=8, frac=0.1, row_rtol=1e-3, row_atol_frac=1e-4, seed=0):
+        """After backward(): bool[N] -- Gaussians whose input gradients are ill-conditioned functions of their per-Gaussian sums:
+        re-running the last stage (texgs_ref_preprocess_bwd, fp32 arithmetic) on the sums perturbed by `delta` relative (what an
+        fp32 accumulation in another order does to them; this oracle accumulates in fp64) moves some entry by more than `frac` of the
+        row tolerance the parity tests use (row_rtol * |row| + row_atol_frac * largest entry).  These are needle-shaped splats
+        (a scale of 1e-9 beside one of 1e-2): the conic -> covariance -> scale chain cancels to 1e-4 of its terms and any
+        implementation's rounding re-rolls the result.  ~110 of 10^6 Gaussians at C5, only dL/dscales; a handful at C3."""
+        rng = np.random.default_rng(seed)
+        base = self._preprocess_bwd(self.acc)
+        names = [n for n in ("means3D", "means2D", "opacities", "scales", "rotations", "uvs") if base[n] is not None]
+        tol = {}
+        for n in names:
+            e = np.abs(base[n].reshape(self.N, -1).astype(np.float64))
+            tol[n] = row_rtol * e.max(1) + row_atol_frac * max(float(e.max()), 1e-300)
+        worst = np.zeros(self.N)
+        for _ in range(trials):
+            g = self._preprocess_bwd(self.acc * (1.0 + delta * rng.standard_normal(self.acc.shape)))
+            for n in names:
+                d = np.abs(g[n].reshape(self.N, -1).astype(np.float64) - base[n].reshape(self.N, -1).astype(np.float64)).max(1)
+                worst = np.maximum(worst, d / tol[n])
+        return worst > frac
+
     def variant_render(self, dout=None):
         """The blend loops of the differently-rounded build on THIS run's records / lists: (out[8,H,W], grads or None)."""
         lib = load_variant()

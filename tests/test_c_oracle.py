@@ -84,3 +84,6 @@ def test_ambiguity_attribution_explains_a_differently_rounded_build():
                            tflag if name == "texture" else gflag)
     # flags are not a blanket: most rows are unflagged
     assert gflag.mean() < 0.25 and tflag.mean() < 0.05
+    # accumulation-sensitive rows (needle-shaped splats): few, and found deterministically
+    sens = run.accumulation_sensitive()
+    assert sens.mean() < 1e-3 and np.array_equal(sens, run.accumulation_sensitive())
