@@ -403,3 +403,38 @@ def test_texture_ready_hook_fires_once_between_the_last_render_and_its_accumulat
     done_ids = [log[k + 1][2] for k, e in enumerate(log) if e[0] == "bwd_render"]       # the record right after every render
     assert set(ready[0]) == {done_ids[2], done_ids[3], done_ids[4]}
     assert snk.before_accumulate is None
+
+
+def test_depth_bin_and_group_arithmetic_of_k2():
+    """The integer arithmetic K2's kernels rely on (csrc/binning.hip depth_range / depth_bin / the group cut of k_depth_scatter's
+    block 0), restated in numpy: bin = mulhi(key - lo, floor(2^32 NB / (range + 1))) is monotone in the key and < NB for every key
+    in [lo, lo + range]; a range narrower than NB maps key - lo itself; groups opened where the running total crosses a multiple
+    of 160 are balanced (every group < 160 + its last bin) and never more than N / 160 + 2."""
+    rng = np.random.default_rng(0)
+    DS_GROUP = 160
+    for trial in range(200):
+        nb = 1 << int(rng.integers(8, 14))
+        lo = int(rng.integers(0, 2 ** 31))
+        span = int(rng.choice([0, 1, nb - 1, nb, nb + 1, 12345, 2 ** 23, 2 ** 30, 2 ** 32 - 1 - lo]))
+        span = min(span, 2 ** 32 - 1 - lo)
+        n = int(rng.integers(1, 5000))
+        keys = np.sort(lo + (rng.random(n) ** 3 * span).astype(np.uint64))        # skewed towards lo
+        keys[0], keys[-1] = lo, lo + span
+        keys = np.sort(keys)
+        d = (keys - np.uint64(lo)).astype(np.uint64)
+        if span < nb:
+            bins = d
+        else:
+            scale = (nb << 32) // (span + 1)
+            assert scale < 2 ** 32
+            bins = (d * np.uint64(scale)) >> np.uint64(32)
+        assert int(bins.max()) < nb and np.all(np.diff(bins.astype(np.int64)) >= 0)
+        cnt = np.bincount(bins.astype(np.int64), minlength=nb)
+        pre = np.concatenate([[0], np.cumsum(cnt)])[:nb]                         # first slot of every bin
+        opens = np.ones(nb, bool)
+        opens[1:] = (pre[1:] // DS_GROUP) != (pre[:-1] // DS_GROUP)
+        starts = pre[opens]
+        sizes = np.diff(np.concatenate([starts, [n]]))
+        last_bin = cnt[np.concatenate([np.nonzero(opens)[0][1:] - 1, [nb - 1]])]
+        assert np.all(sizes < DS_GROUP + np.maximum(last_bin, 1)) and sizes.sum() == n
+        assert opens.sum() <= min(n // DS_GROUP + 2, nb)
