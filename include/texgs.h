@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 11
+#define TEXGS_ABI_VERSION 12
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
 #define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
@@ -119,7 +119,14 @@ typedef struct TexGSImage {
                                   element count keys_sorted / point_list were sized for                                     */
     uint16_t* surv_qmask;      /* u16[4 * capacity] bit q: the survivor reaches 4x4 quadrant q of its block                  */
     uint32_t* surv_count;      /* u32[4 * T] survivors written per block                                                     */
+    uint32_t* tex_bin_resv;    /* u32[4 * T * TEXGS_RESV_WORDS] or NULL (v12; non-NULL together with tex_bin_count).  Per 8x8 pixel
+                                  block, K6's RESERVATIONS in the texture-gradient record lists: up to 16 entries {texture bin,
+                                  first record of the block inside that bin's list, records} as three planes of 16 words.  K6
+                                  takes them with one returning atomic per (block, bin) on tex_bin_count (which thereby becomes
+                                  the per-bin totals); K7 hands the slots out block-locally -- no global cursor, no grouping.
+                                  No initialisation; written for every block.                                              */
 } TexGSImage;
+#define TEXGS_RESV_WORDS 48
 
 #define TEXGS_ACC_MEANS3D 1
 #define TEXGS_ACC_MEANS2D 2
@@ -170,10 +177,11 @@ typedef struct TexGSGrads {
                                   NULL (or no counts, or cap 0) = fp32 atomics straight into dL_dtexture (~20 G requests/s
                                   memory-side: 0.7 ms per C3 view).  Contents need no initialisation.  The 5 low mantissa
                                   bits of fx / fy carry the cell (fx, fy keep 18 bits, rounded).                         */
-    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: the lists' fill cursors (scratch, set at the start of every
-                                  backward: no initialisation) + two status words: [count] receives max(records a call needed)
-                                  -- zero it once; never cleared by the library: the caller sizes tex_rec_cap from it --,
-                                  [count+1] = bits of max |dL/dpixel colour| of the call in flight (reset by every backward).  */
+    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: two status words behind a per-bin part that is unused since v12
+                                  (v11 kept the lists' fill cursors there; the layout is unchanged): [count] receives
+                                  max(records a call needed) -- zero it once; never cleared by the library: the caller sizes
+                                  tex_rec_cap from it --, [count+1] = bits of max |dL/dpixel colour| of the call in flight
+                                  (reset by every backward).                                                              */
     uint32_t* tex_bin_base;    /* u32[2 * texgs_tex_bin_count(R) + 1]: scratch of this call (no initialisation): the list
                                   offsets [count + 1], then the reduce kernel's launch order [count] (v11)                  */
     uint32_t  tex_rec_cap;     /* records tex_bins holds.  Too small is not an error: footprints that do not fit fall back

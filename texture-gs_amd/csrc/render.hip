@@ -19,12 +19,14 @@
 //
 // Texture gradient (K7): every fp32 global atomic on this part executes memory-side at ~20 G requests/s and the ~19 M
 // bilinear footprints of a C3 view cost 0.69 ms that way (profiles/r02_ablation.md).  Instead K7 APPENDS a 20-byte
-// record {fx | cell x, fy | cell y, dL/dtexel-colour (3)} per footprint with plain coalesced stores to the list of the
-// 32x32-texel texture block ("bin") the footprint is anchored in -- one returning atomic per (wave round, distinct bin) on
-// the bin's cursor -- and k_texgrad_reduce then sums each bin's list in LDS and adds every texel of the block to dL_dtexture
-// once.  The lists are EXACTLY sized: K6 counts the footprints per bin while it renders (one non-returning atomic per
-// (round, distinct bin)), a one-workgroup scan turns the counts into offsets, and the records of a view are one
-// contiguous array (~0.37 GB at C3) -- no per-bin capacity, no chunk tables, nothing to wait for.
+// record {fx | cell x, fy | cell y, dL/dtexel-colour (3)} per footprint with plain stores to the list of the 32x32-texel
+// texture block ("bin") the footprint is anchored in, and k_texgrad_reduce then sums each bin's list in LDS and adds every
+// texel of the block to dL_dtexture once.  The lists are EXACTLY sized and every slot has an owner before K7 starts: K6
+// counts the footprints per (8x8 pixel block, bin) in a 16-entry LDS table while it renders and, at block end, RESERVES the
+// block's range of each list with one returning atomic per entry on the bin's total; a one-workgroup scan turns the totals
+// into list offsets; K7 reads its block's table back and hands out slots with an LDS atomic (round 5; until then: a grouping
+// loop and one returning GLOBAL atomic per (wave round, distinct bin) on a cursor -- 100 of K7's 700 us).  The records of a
+// view are one contiguous array (~0.37 GB at C3) -- no per-bin capacity, no chunk tables, nothing to wait for.
 // No MFMA: there is no dense contraction on this path.
 #include "common.h"
 #include "wave_ops.h"
@@ -129,6 +131,7 @@ struct PixArgs {
     uint2*    surv;          // {Gaussian id, list position}
     uint16_t* surv_qm;       // bit q: the survivor can reach quadrant q
     uint32_t* surv_cnt;      // [4 * tiles] survivors written per block
+    uint32_t* resv;          // [4 * tiles][3][TG_RESV] per-block reservation table {bin | offset inside the bin's list | count} (NULL: no binned texture gradient)
 };
 
 // workgroup (= one wave) -> (tile, 8x8 block).  Tiles are launched longest-list-first (tile_order).  The four blocks of a
@@ -155,6 +158,31 @@ __device__ __forceinline__ int mbcnt64(ull m) {
 // border: such footprints go straight to dL_dtexture).  K6 counts with this, K7 appends with this: same inputs, same answer.
 __device__ __forceinline__ uint32_t tap_bin(const CubeTap& ct, int nb) { return (uint32_t)((ct.face * nb + (ct.y0 >> 5)) * nb + (ct.x0 >> 5)); }
 __device__ __forceinline__ bool tap_binned(const CubeTap& ct) { return ct.dox != 0u && ct.doy != 0u; }
+// Per-block RESERVATION table (K6 -> K7): the texture bins an 8x8 block's footprints fall into (a surface patch seen through 64
+// pixels covers a handful of 32x32-texel bins), open addressing with linear probing, never flushed.  The home slot keeps the 4x4
+// neighbourhood of bins of one face apart.  K6 counts per entry and, at block end, takes the block's range of every bin's record
+// list with ONE returning atomic per entry; K7 reads the table back and hands out slots with an LDS atomic -- no grouping, no
+// global cursor.  A bin that does not fit the table is neither counted nor reserved: K7 sends those footprints to dL_dtexture
+// directly (still correct).
+#define TG_RESV 16
+#define TG_RESV_EMPTY 0xFFFFFFFFu
+__device__ __forceinline__ int tap_home(const CubeTap& ct) { return ((ct.x0 >> 5) & 3) | (((ct.y0 >> 5) & 3) << 2); }
+// lane-parallel lookup of `bin` from its home slot `h`: the entry that holds it, or -1 (walk ended on an empty slot / table full).
+// Almost always decided by the first read; the walk runs only while some lane of the wave sits on a foreign entry.
+__device__ __forceinline__ int resv_find(const uint32_t* tbin, bool want, uint32_t bin, int h) {
+    uint32_t e = tbin[h];
+    int found = (want && e == bin) ? h : -1;
+    bool walk = want && e != bin && e != TG_RESV_EMPTY;
+    for (int p = 1; p < TG_RESV && __builtin_amdgcn_ballot_w64(walk) != 0ull; ++p) {
+        if (walk) {
+            h = (h + 1) & (TG_RESV - 1);
+            e = tbin[h];
+            if (e == bin) { found = h; walk = false; }
+            else if (e == TG_RESV_EMPTY) walk = false;
+        }
+    }
+    return found;
+}
 
 // ---- per-wave LDS layout shared by K6 and K7 ----
 #define TG_RING 128          // survivor queue (raw list positions), power of two >= 127
@@ -217,8 +245,8 @@ struct __attribute__((aligned(16))) FwdLds {
     ull col[64 * 3];                    // 1536: Q32.32 colour sums of the wave's pixels
     uint32_t ring[TG_RING];             //  512
     uint8_t list[4][64];                //  256: per-quadrant survivor lists, padded with TG_DUMMY
-    uint32_t cbin[8], ccnt[8];          //   64: footprint-count cache (a block's footprints fall into a handful of texture bins)
-};                                      // 10160 B -> 16 waves per CU
+    uint32_t cbin[TG_RESV], ccnt[TG_RESV];   // 128: the block's reservation table: texture bin, footprints counted
+};                                      // 10224 B -> 16 waves per CU
 
 // TAPS = false: the untextured surface (TexGSInputs.texture == NULL; render/render.py:75-84 through `diff_gauss`): the colour of a
 // pair is max(0, viewdep + 0.5), no UV step, no cubemap address, no taps.
@@ -247,7 +275,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     const int nbins_row = (a.R + 31) >> 5;
 
     L.col[lane * 3 + 0] = 0ull; L.col[lane * 3 + 1] = 0ull; L.col[lane * 3 + 2] = 0ull;   // own pixel; only this wave touches it
-    if (lane < 8) { L.cbin[lane] = 0xFFFFFFFFu; L.ccnt[lane] = 0u; }
+    if (lane < TG_RESV) { L.cbin[lane] = TG_RESV_EMPTY; L.ccnt[lane] = 0u; }
     init_dummy(L.p, lane);
     __builtin_amdgcn_wave_barrier();
 
@@ -308,30 +336,29 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             p10 = load_texel(tex, ct.o00 + ct.doy); p11 = load_texel(tex, ct.o00 + ct.doy + ct.dox);
             p_fx = ct.fx; p_fy = ct.fy;
             if (bin_count != nullptr) {
-                // a backward will follow: count this round's footprints per texture bin (sizes of K7's record lists) in a small
-                // per-wave LDS cache (8 entries, hashed by bin; a block's footprints fall into a handful of bins), flushed with one
-                // global atomic per entry on a conflict and at the end: global atomics execute memory-side (one per (round, bin) =
-                // 700 k per view cost 80 us).  Hit: ONE integer LDS atomic per lane, no grouping.  Miss (first touch of a bin, or
-                // a hash conflict): the lanes are grouped by bin with ballots and the group leader replaces the entry.
+                // a backward will follow: count this round's footprints per texture bin in the block's reservation table (sizes of
+                // K7's record lists).  Hit: ONE integer LDS atomic per lane.  First touch of a bin: the lanes are grouped by bin
+                // with ballots and the group leader claims the first free entry on the bin's probe path (a few times per block).
                 const bool binned = (lane < n_) && tap_binned(ct);
                 const uint32_t bin = tap_bin(ct, nbins_row);
-                const uint32_t ce = (bin ^ (bin >> 5)) & 7u;
-                const bool hit = binned && L.cbin[ce] == bin;
-                if (hit) atomicAdd(&L.ccnt[ce], 1u);
-                ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
+                const int home = tap_home(ct);
+                const int ce = resv_find(L.cbin, binned, bin, home);
+                if (ce >= 0) atomicAdd(&L.ccnt[ce], 1u);
+                ull pend = TG_BALLOT(binned) & ~TG_BALLOT(ce >= 0);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
+                    const int h0 = __builtin_amdgcn_readlane(home, l0);
                     const ull m = pend & TG_BALLOT(bin == b0);
-                    if (lane == l0) {
-                        const uint32_t n = (uint32_t)__popcll(m), ob = L.cbin[ce];
-                        if (ob == b0) L.ccnt[ce] += n;            // (installed by an earlier group of this round? cannot be: one group per bin)
-                        else {
-                            if (ob != 0xFFFFFFFFu) atomicAdd(bin_count + ob, L.ccnt[ce]);
-                            L.cbin[ce] = b0; L.ccnt[ce] = n;
-                        }
+                    int f = -1;                             // wave-uniform walk (broadcast reads)
+                    for (int p = 0; p < TG_RESV; ++p) {
+                        const int hh = (h0 + p) & (TG_RESV - 1);
+                        const uint32_t ee = L.cbin[hh];
+                        if (ee == b0 || ee == TG_RESV_EMPTY) { f = hh; break; }
                     }
-                    pend &= ~m;
+                    if (f >= 0 && lane == l0) { L.cbin[f] = b0; L.ccnt[f] += (uint32_t)__popcll(m); }
+                    __builtin_amdgcn_wave_barrier();        // (the next group's walk must see this entry)
+                    pend &= ~m;                             // table full: these footprints stay uncounted, K7 scatters them itself
                 }
             }
         }
@@ -461,7 +488,15 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     }
     finish();
     __builtin_amdgcn_wave_barrier();
-    if (TAPS && bin_count != nullptr && lane < 8 && L.cbin[lane] != 0xFFFFFFFFu) atomicAdd(bin_count + L.cbin[lane], L.ccnt[lane]);
+    if (TAPS && bin_count != nullptr && lane < TG_RESV) {
+        // reserve: this block's footprints of bin b occupy [off, off + n) of b's record list (offsets inside the list: the lists'
+        // bases are known only after k_bin_offsets has scanned the totals this very atomic builds)
+        const uint32_t b = L.cbin[lane], n = L.ccnt[lane];
+        uint32_t off = 0u;
+        if (b != TG_RESV_EMPTY) off = atomicAdd(bin_count + b, n);
+        uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
+        rv[lane] = b; rv[TG_RESV + lane] = off; rv[2 * TG_RESV + lane] = n;
+    }
     if (a.surv_cnt != nullptr && lane == 0) a.surv_cnt[4 * tile + wave] = (uint32_t)nsurv;
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
@@ -494,10 +529,22 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 #ifndef BQ_CAP
 #define BQ_CAP 128
 #endif
+// K7_GATHER: stage B takes the shading record of an item's Gaussian (56 + 16 bytes) from global memory (L2 hits: every lane of a
+// task reads the same record) instead of from LDS planes -- the planes D..G and C (4.7 KB per wave) go, the occupancy goes up.
+#ifndef K7_GATHER
+#define K7_GATHER 0
+#endif
+#ifndef K7_WAVES_PER_SIMD
+#define K7_WAVES_PER_SIMD 2
+#endif
+// K7_SLOT_BALLOT (experiment): record slots by grouping the lanes per table entry with ballots instead of a returning LDS atomic
+#ifndef K7_SLOT_BALLOT
+#define K7_SLOT_BALLOT 0
+#endif
 #define BWD_MAX_IT 16
 struct TexBinArgs {
     float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
-    uint32_t* cursor;      // [nbins] next free record of each list, ABSOLUTE (k_bin_offsets sets it to base[b] before every K7)
+    uint32_t* cursor;      // [nbins + 2]: only the two status words behind the (since v12 unused) per-bin part are live
     const uint32_t* base;  // [nbins + 1] exclusive scan of K6's per-bin counts
     const uint32_t* order; // [nbins] the reduce kernel's launch order: bins by falling list length (k_bin_offsets)
     uint32_t* stats;       // [0] max records a call wanted (for the host), [1] bits of max |dL/dpixel colour| of this call
@@ -505,15 +552,21 @@ struct TexBinArgs {
     int       nb;          // bins per face row = ceil(R / 32)
 };
 
+#if K7_GATHER
+struct PlanesT { float4 A[65]; float4 B[65]; };      // test planes only (stage A, and the splat centre for stages B / C2)
+#else
+typedef Planes PlanesT;
+#endif
 struct __attribute__((aligned(16))) BwdLds {
     float4 items[BQ_CAP * 3 + 3];       // 6192: 3 float4 per item {T -> w, s -> dL/dpower, alpha_raw, key} {dc, du0} {du1, du2, inv, dden}; + one all-zero item
     float4 abuf[BQ_CAP];                // 2048: {T, -, alpha_raw, key} of the NEXT segment's items (stage A runs one segment ahead of B / C)
-    Planes p;                           // 6768
+    PlanesT p;                          // 6768 (2080 with K7_GATHER)
     float4 dpix[64];                    // 1024: dL/d(r, g, b, alpha) of the wave's pixels
     float4 dgeo[64];                    // 1024: dL/d(depth, normal)
     uint32_t task[64];                  //  256
     uint8_t list[4][64];                //  256
-};                                      // 17568 B -> 9 waves per CU
+    uint32_t tbin[TG_RESV], tpos[TG_RESV], tend[TG_RESV];   // 192: the block's reservations: bin, next free record (absolute), end of the range
+};                                      // 17760 B -> 9 waves per CU
 
 // footprints that cannot be binned (clamped at a face border, beyond the buffer): straight into dL_dtexture.  Offsets in BYTES.
 __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_t o00, uint32_t dox, uint32_t doy, float fx, float fy,
@@ -539,7 +592,7 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 //   UVG   the UV chain (dL/duv, dL/dden -> M_DEN, M_DN, M_PHI).   false: nothing upstream of uv wants a gradient, or no texture
 //   TAPS  the texture is sampled at all.                          false: untextured surface (texture == NULL)
 template <bool TEX, bool GEO, bool UVG, bool TAPS>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, K7_WAVES_PER_SIMD)
 k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
              const float* __restrict__ dL_dnorm, const float* __restrict__ dL_dalpha,
@@ -578,7 +631,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     if (lane < 3) L.items[BQ_CAP * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     L.dpix[lane] = make_float4(dpix[0], dpix[1], dpix[2], dpix[7]);
     L.dgeo[lane] = make_float4(dpix[3], dpix[4], dpix[5], dpix[6]);
+#if K7_GATHER
+    if (lane == 0) { L.p.A[TG_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f); L.p.B[TG_DUMMY] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f); }
+#else
     init_dummy(L.p, lane);
+#endif
     if (TEX && tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale of THIS
         // call (k_bin_offsets, launched just before this kernel, cleared the word).  Non-negative floats order like their bit
@@ -588,6 +645,18 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         const int mbits = wave_max_i(max(max(__float_as_int(fabsf(dpix[0])), __float_as_int(fabsf(dpix[1]))), __float_as_int(fabsf(dpix[2]))));
         if (lane == 0 && (uint32_t)mbits > __hip_atomic_load(tb.stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(tb.stats + 1, (uint32_t)mbits);
+    }
+    if constexpr (TEX) {
+        // the block's reservations (K6 left {bin, offset inside the bin's list, count}; k_bin_offsets has since scanned the totals)
+        if (lane < TG_RESV) {
+            uint32_t b = TG_RESV_EMPTY, p0 = 0u, n = 0u;
+            if (tb.rec != nullptr) {
+                const uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
+                b = rv[lane];
+                if (b != TG_RESV_EMPTY) { p0 = tb.base[b] + rv[TG_RESV + lane]; n = rv[2 * TG_RESV + lane]; }
+            }
+            L.tbin[lane] = b; L.tpos[lane] = p0; L.tend[lane] = p0 + n;
+        }
     }
     // last contributor of each quadrant (row maximum) and of the block
     int rl = last;
@@ -614,16 +683,25 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     // both backs.  (Starting round 0's front inside stage A, as soon as 64 items exist, was measured: K7 732 -> 771 us.)
     struct Seg { int n_items, n_it; uint32_t it_lo, it_hi, it_first; };      // it_*: lane k = ballot / first item of the k-th productive iteration
     struct Round {                                        // what the back half needs, as few registers as possible
-        bool have, binned;
-        int e, pl, jj, my_leader, my_rank, axis;
-        uint32_t slot0, b1;                               // absolute slot of the group's first record; end of the bin's list
+        bool have;
+        int e, pl, jj, axis;
+        uint32_t key;
+        uint32_t slot;                                    // the item's record slot (absolute), 0xFFFFFFFF: none (not binned / no room)
         uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
         uint32_t o00, dox, doy;                           // tap byte offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
         float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
         float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
         Texel3 t00, t01, t10, t11;
+#if K7_GATHER
+        float4 sd, se, sf;                                // g, G (8 floats), phi + vd0: between the two parts of the front half only
+        float4 c5;                                        // depth, normal of the item's Gaussian
+#endif
     };
-    auto front = [&](int rbase, Round& R, int n_items) {
+    uint32_t cid = 0u;                                    // lane = survivor of the current chunk: its Gaussian id
+    (void)cid;
+    // front half, part A: the item, and (K7_GATHER) the loads of its Gaussian's shading record.  Part A of EVERY round of the segment
+    // runs before any part B: vmcnt retires in order, a record load issued behind another round's taps would wait for those taps.
+    auto front_a = [&](int rbase, Round& R, int n_items) {
         R.e = rbase + lane;
         R.have = R.e < n_items;
         float4 it = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -631,19 +709,40 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             it = L.abuf[R.e];
             if constexpr (GEO) L.items[R.e * 3] = it;         // (the previous segment's stage C has read its items by now)
         }
-        const uint32_t key = __float_as_uint(it.w);
-        R.pl = KEY_PL(key);
-        const int jj = KEY_J(key);
-        R.jj = jj;
+        R.key = __float_as_uint(it.w);
+        R.pl = KEY_PL(R.key);
+        R.jj = KEY_J(R.key);
+        R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
+#if K7_GATHER
+        // the shading record of the item's Gaussian from global memory (an L2 hit; lanes of one task read the same 80 bytes)
+        const float4* __restrict__ sp = a.rec_shade + 5 * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(R.jj << 2, (int)cid);
+        if constexpr (TAPS) { R.sd = sp[0]; R.se = sp[1]; }
+        R.sf = sp[2];
+        const float4 s3 = sp[3];
+        const float2 s4 = *reinterpret_cast<const float2*>(sp + 4);
+        R.vd1 = s3.x; R.vd2 = s3.y;
+        R.c5 = make_float4(s3.z, s3.w, s4.x, s4.y);
+#endif
+    };
+    auto front_b = [&](Round& R) {
+        const uint32_t key = R.key;
+        const int jj = R.jj;
+#if K7_GATHER
+        const float4 f_ = R.sf;
+        R.vd0 = f_.w;
+#else
         const float4 f_ = L.p.F[jj];
         const float2 g2 = L.p.G[jj];
-        R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
         R.vd0 = f_.w; R.vd1 = g2.x; R.vd2 = g2.y;
-        R.binned = false;
+#endif
         if constexpr (TAPS) {
             // UV Taylor step, cubemap address, tap loads
             const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj]);
+#if K7_GATHER
+            const float4 d_ = R.sd, e4 = R.se;
+#else
             const float4 d_ = L.p.D[jj], e4 = L.p.E[jj];
+#endif
             const float dpx = (float)(wave_px + KEY_OX(key)) - xy.x, dpy = (float)(wave_py + KEY_OY(key)) - xy.y;
             const float den = 1.0f + d_.x * dpx + d_.y * dpy;
             R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
@@ -664,28 +763,30 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
                 R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
                 R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
-                // slot in the texture bin's record list: one returning atomic per distinct bin of the round.  Group the
-                // lanes by bin (ballots only), then every group leader bumps its bin's cursor in ONE instruction.
-                R.binned = R.have && tb.rec != nullptr && tap_binned(ct);
-                const uint32_t bin = tap_bin(ct, tb.nb);
-                bool leader = false;
-                R.my_leader = lane; R.my_rank = 0;
-                int my_n = 0;
-                ull pend = TG_BALLOT(R.binned);
+                // slot in the texture bin's record list: the block's reservation of that bin (K6 counted exactly these footprints),
+                // taken with one returning LDS atomic per lane
+                const bool binned = R.have && tb.rec != nullptr && tap_binned(ct);
+                const int te = resv_find(L.tbin, binned, tap_bin(ct, tb.nb), tap_home(ct));
+                R.slot = 0xFFFFFFFFu;
+#if K7_SLOT_BALLOT
+                ull pend = TG_BALLOT(te >= 0);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;
-                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
-                    const ull m = TG_BALLOT(R.binned && bin == b0);
-                    if ((m >> lane) & 1ull) {
-                        R.my_leader = l0;
-                        R.my_rank = mbcnt64(m);
-                        if (lane == l0) { leader = true; my_n = __popcll(m); }
-                    }
+                    const int t0 = __builtin_amdgcn_readlane(te, l0);
+                    const ull m = pend & TG_BALLOT(te == t0);
+                    const uint32_t p0 = L.tpos[t0], p1 = L.tend[t0];
+                    if ((m >> lane) & 1ull) { const uint32_t pos = p0 + (uint32_t)mbcnt64(m); if (pos < p1) R.slot = pos; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == l0) L.tpos[t0] = p0 + (uint32_t)__popcll(m);
+                    __builtin_amdgcn_wave_barrier();
                     pend &= ~m;
                 }
-                R.slot0 = 0u; R.b1 = 0u;
-                if (leader) R.slot0 = atomicAdd(tb.cursor + bin, (uint32_t)my_n);
-                if (R.binned) R.b1 = tb.base[bin + 1u];
+#else
+                if (te >= 0) {
+                    const uint32_t pos = atomicAdd(&L.tpos[te], 1u);
+                    if (pos < L.tend[te]) R.slot = pos;
+                }
+#endif
             }
         }
     };
@@ -719,7 +820,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const float qv = fmaxf(0.f, pre0) * d0 + fmaxf(0.f, pre1) * d1 + fmaxf(0.f, pre2) * d2;
                 // s = colour . dL/dcolour + (depth, normal) . dL/d(depth, normal) + dL/dalpha: everything stage C1's
                 // recurrence needs from this pair, formed here where all 64 lanes work
+#if K7_GATHER
+                const float4 c5 = R.c5;
+#else
                 const float4 c5 = L.p.C[R.jj];
+#endif
                 const float4 dg = L.dgeo[R.pl];
                 L.items[R.e * 3].y = qv + c5.x * dg.x + c5.y * dg.y + c5.z * dg.z + c5.w * dg.w + dp.w;
                 float du0 = 0.f;
@@ -741,9 +846,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         if constexpr (TEX) {
             // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
             // a face border / does not fit the buffer (still correct, just slow)
-            const uint32_t pos = (uint32_t)__builtin_amdgcn_ds_bpermute(R.my_leader << 2, (int)R.slot0) + (uint32_t)R.my_rank;
-            if (R.binned && pos < R.b1 && pos < tb.cap) {
-                float* __restrict__ rp = tb.rec + pos;
+            if (R.slot < tb.cap) {
+                float* __restrict__ rp = tb.rec + R.slot;
                 rp[0] = __uint_as_float(R.fxw); rp[tb.cap] = __uint_as_float(R.fyw);
                 rp[2 * (size_t)tb.cap] = x0; rp[3 * (size_t)tb.cap] = x1; rp[4 * (size_t)tb.cap] = x2;
             } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
@@ -760,8 +864,18 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         const int take = min(64, hi);
         if ((int)__builtin_amdgcn_readlane((int)pos, take - 1) >= wave_last) continue;
         __builtin_amdgcn_wave_barrier();
+        cid = id;
+#if K7_GATHER
+        {   // lane = survivor: only the test record goes to LDS (a dead lane: alpha 0, position beyond every list)
+            float4 T0 = make_float4(0.f, 0.f, 0.f, 0.f), T1 = make_float4(0.f, 0.f, -1.f, 1.f);
+            if (live) { const float4* __restrict__ tp = a.rec_test + 2 * (size_t)id; T0 = tp[0]; T1 = tp[1]; }
+            L.p.A[lane] = T0;
+            L.p.B[lane] = make_float4(T1.x, T1.y, __uint_as_float(pos), 0.f);
+        }
+#else
         float4 T0, T1;
         load_chunk(a, L.p, lane, live, id, pos, T0, T1);
+#endif
         reinterpret_cast<uint32_t*>(&L.list[0][0])[lane] = 0x40404040u;
         __builtin_amdgcn_wave_barrier();
         int len[4];
@@ -920,9 +1034,19 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             __builtin_amdgcn_wave_barrier();
             // ================================================================ stage B, front halves
             Round R[NR];
+#if K7_GATHER
 #pragma unroll
             for (int r = 0; r < NR; ++r)
-                if (r == 0 || r * 64 < cur.n_items) front(r * 64, R[r], cur.n_items);
+                if (r == 0 || r * 64 < cur.n_items) front_a(r * 64, R[r], cur.n_items);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (r == 0 || r * 64 < cur.n_items) front_b(R[r]);
+#else
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (r == 0 || r * 64 < cur.n_items) { front_a(r * 64, R[r], cur.n_items); front_b(R[r]); }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             nxt.n_items = 0; nxt.n_it = 0;
             if (t < tmax) stage_a(nxt);
@@ -937,13 +1061,25 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (TEX) {
+        // A reservation this block did not use up -- impossible while K6 and K7 agree on every footprint (same decisions, same uv
+        // arithmetic); should they ever not, the reduce must not sum whatever an earlier call left in the unused slots.
+        __builtin_amdgcn_wave_barrier();
+        if (lane < TG_RESV) {
+            const uint32_t q1 = min(L.tend[lane], tb.cap);
+            for (uint32_t q = L.tpos[lane]; q < q1; ++q) {
+                float* __restrict__ rp = tb.rec + q;
+                rp[0] = 0.f; rp[tb.cap] = 0.f; rp[2 * (size_t)tb.cap] = 0.f; rp[3 * (size_t)tb.cap] = 0.f; rp[4 * (size_t)tb.cap] = 0.f;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ texture-gradient lists
-// Exclusive scan of K6's per-bin footprint counts -> list offsets and the lists' fill cursors (absolute: K7's returning atomic on a
-// cursor IS the record's position) (one workgroup; nbins = 6144 at R = 1024).
+// Exclusive scan of K6's per-bin footprint counts -> list offsets (K7 adds them to its blocks' reservations, which K6 made
+// relative to the start of each list) (one workgroup; nbins = 6144 at R = 1024).
 __global__ void __launch_bounds__(1024)
-k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ cursor,
+k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base,
               uint32_t* __restrict__ order, uint32_t* __restrict__ stats) {
     // one pass: thread t owns the `per` consecutive counts [t * per, (t + 1) * per) -- serial inside the thread, one wave scan,
     // one cross-wave step (6 144 bins at R = 1024: 6 per thread).  Chunks of 1 024 x BO_MAX bins if there are more.
@@ -969,7 +1105,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
         uint32_t run = s_carry + incl - sum;
         for (int w = 0; w < wv; ++w) run += s_w[w];
 #pragma unroll
-        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) { base[i0 + k] = run; cursor[i0 + k] = run; } run += v[k]; }
+        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) base[i0 + k] = run; run += v[k]; }
         __syncthreads();
         if (tid == 1023) s_carry = run;
         __syncthreads();
@@ -1028,7 +1164,7 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __shared__ long long s_tile[TB_EDGE * TB_ROW * 3];           // [row][col (padded)][channel], 2^42-scaled fixed point
     const int b = (int)tb.order[blockIdx.x], tid = (int)threadIdx.x;
     const uint32_t b0 = tb.base[b], b1 = tb.base[b + 1];
-    const uint32_t filled = tb.cursor[b] - b0;                   // (the cursor is absolute; K7 bumped it once per record it wanted to append)
+    const uint32_t filled = b1 - b0;                             // every slot of a list is reserved by exactly one block of K7, which fills it
     if (filled == 0u) return;                                  // uniform per workgroup
     const uint32_t room = (b0 < tb.cap) ? min(b1, tb.cap) - b0 : 0u;      // records of this list that exist (K7's own test)
     const uint32_t cnt = min(filled, room);
@@ -1114,13 +1250,14 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
     a.surv = hand ? reinterpret_cast<uint2*>(img->survivors) : nullptr;
     a.surv_qm = hand ? img->surv_qmask : nullptr;
     a.surv_cnt = hand ? img->surv_count : nullptr;
+    a.resv = img->tex_bin_resv;
     return a;
 }
 
 inline TexBinArgs make_bins(const CamConst& c, const TexGSImage* img, const TexGSGrads* gr) {
     TexBinArgs tb;
     tb.nb = (c.R + 31) >> 5;
-    const bool on = (gr->want & TEXGS_WANT_TEXTURE) && img->tex_bin_count != nullptr && gr->tex_bins != nullptr &&
+    const bool on = (gr->want & TEXGS_WANT_TEXTURE) && img->tex_bin_count != nullptr && img->tex_bin_resv != nullptr && gr->tex_bins != nullptr &&
                     gr->tex_bin_cursor != nullptr && gr->tex_bin_base != nullptr && gr->tex_rec_cap > 0;
     tb.rec = on ? gr->tex_bins : nullptr;
     tb.cursor = on ? gr->tex_bin_cursor : nullptr;
@@ -1143,7 +1280,7 @@ void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     const PixArgs a = make_pix(c, f, in, g, b, img);
     if (in->texture)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
-                           img->out_norm, img->out_alpha, img->final_T, img->n_contrib, img->tex_bin_count);
+                           img->out_norm, img->out_alpha, img->final_T, img->n_contrib, img->tex_bin_resv ? img->tex_bin_count : (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(blend_grid(a.num_tiles)), dim3(64), 0, s, a, img->out_color, img->out_depth,
                            img->out_norm, img->out_alpha, img->final_T, img->n_contrib, (uint32_t*)nullptr);
@@ -1162,7 +1299,7 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     if (!tex && !geo) return;
     if (tex && tb.rec)      // list offsets + cursors from the counts the forward left (one small workgroup)
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
-                           gr->tex_bin_base, gr->tex_bin_cursor, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
+                           gr->tex_bin_base, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
     const dim3 grid(blend_grid(a.num_tiles)), blk(64);
 #define K7_LAUNCH(TEX, GEO, UVG, TAPS) hipLaunchKernelGGL((k_render_bwd<TEX, GEO, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
         img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)

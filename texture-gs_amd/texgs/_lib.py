@@ -6,12 +6,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8
 REC_SHADE_FLOATS = 20
 TEXBIN_RECORD_FLOATS = 5
+RESV_WORDS = 48          # per 8x8 pixel block: 16 reservation entries x {bin, offset, count} (TexGSImage.tex_bin_resv)
 ACC_FLOATS = 32
 WANT_TEXTURE, WANT_GAUSSIANS, WANT_ALL = 1, 2, 3
 
@@ -43,7 +44,7 @@ class Binning(C.Structure):
 class Image(C.Structure):
     _fields_ = [("out_color", _fp), ("out_depth", _fp), ("out_norm", _fp), ("out_alpha", _fp),
                 ("final_T", _fp), ("n_contrib", _fp), ("tex_bin_count", _fp),
-                ("survivors", _fp), ("surv_qmask", _fp), ("surv_count", _fp)]
+                ("survivors", _fp), ("surv_qmask", _fp), ("surv_count", _fp), ("tex_bin_resv", _fp)]
 
 
 class Grads(C.Structure):
@@ -133,7 +134,7 @@ def load():
                  "texgs_backward_preprocess", "texgs_rgb_alpha_loss", "texgs_mark_visible"):
         getattr(lib, name).restype = C.c_int
     v = lib.texgs_abi_version()
-    if v != ABI_VERSION:
+    if v != ABI_VERSION and not (os.environ.get("TEXGS_LIB") and os.environ.get("TEXGS_ABI_ANY") == "1"):     # (A/B runs of an older experiment build)
         raise RuntimeError(f"libtexgs.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
     _lib = lib
     return lib

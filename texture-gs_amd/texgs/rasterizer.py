@@ -318,6 +318,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             ar.add("tile_order", (tiles,), i32)
             if want_counts and handoff:
                 ar.add("tex_bin_count", (int(lib.texgs_tex_bin_count(R)),), i32)
+                ar.add("tex_bin_resv", (4 * tiles, _lib.RESV_WORDS), i32)      # K6's per-block reservations in the record lists
             if handoff:
                 ar.add("surv_count", (4 * tiles,), i32)
         if not candidate:
@@ -333,7 +334,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         out_norm = torch.empty(3, H, W, dtype=f32, device=device)
         out_alpha = torch.empty(1, H, W, dtype=f32, device=device)
         img = _lib.Image(_ptr(out_color), _ptr(out_depth), _ptr(out_norm), _ptr(out_alpha), fix.ptr("final_T"),
-                         fix.ptr("n_contrib"), None, None, None, None)
+                         fix.ptr("n_contrib"), None, None, None, None, None)
 
         def alloc_bin(cap, lists_ar):
             c1 = max(cap, 1)
@@ -353,6 +354,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             b = _lib.Binning(0, ar.ptr("keys_unsorted"), ar.ptr("keys_sorted"), ar.ptr("point_list"), la.ptr("ranges"),
                              la.ptr("tile_order"), ar.ptr("sort_temp"), sort_bytes)
             img.tex_bin_count, img.surv_count = la.ptr("tex_bin_count"), la.ptr("surv_count")
+            img.tex_bin_resv = la.ptr("tex_bin_resv")
             img.survivors, img.surv_qmask = ar.ptr("survivors"), ar.ptr("surv_qmask")
             return b, ar
         hint_key = (device.index, N, H, W)
@@ -375,7 +377,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
                                                 stream), "texgs_render_forward")
             if for_backward and entry.handoff and (entry.counts or not want_counts):
                 img.survivors, img.surv_qmask, img.surv_count = entry.handoff
-                img.tex_bin_count = entry.counts if want_counts else None
+                img.tex_bin_count, img.tex_bin_resv = entry.counts if want_counts else (None, None)
             cap = entry.cap
         else:
             _GEOM_STATS["misses"] += 1
@@ -397,7 +399,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
                          binning.sort_temp, binning.sort_temp_bytes)
                 e.arenas = (fix, bin_ar)
                 e.handoff = (img.survivors, img.surv_qmask, img.surv_count) if handoff else None
-                e.counts = img.tex_bin_count if handoff else None
+                e.counts = (img.tex_bin_count, img.tex_bin_resv) if (handoff and img.tex_bin_count) else None
                 _GEOM[gkey] = e
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
@@ -432,6 +434,7 @@ def _late_handoff(s: _State):
     ar.add("surv_count", (4 * s.tiles,), i32)
     if s.want_counts:
         ar.add("tex_bin_count", (int(lib.texgs_tex_bin_count(s.R)),), i32)
+        ar.add("tex_bin_resv", (4 * s.tiles, _lib.RESV_WORDS), i32)
     ar.add("scratch_out", (8, s.H, s.W), f32)
     ar.add("final_T", (s.H, s.W), f32)
     ar.add("n_contrib", (s.H, s.W), i32)
@@ -439,13 +442,13 @@ def _late_handoff(s: _State):
     so = ar.ptr("scratch_out")
     hw = 4 * s.H * s.W
     img = _lib.Image(so, so + 3 * hw, so + 4 * hw, so + 7 * hw, ar.ptr("final_T"), ar.ptr("n_contrib"), ar.ptr("tex_bin_count"),
-                     ar.ptr("survivors"), ar.ptr("surv_qmask"), ar.ptr("surv_count"))
+                     ar.ptr("survivors"), ar.ptr("surv_qmask"), ar.ptr("surv_count"), ar.ptr("tex_bin_resv"))
     _lib.check(lib.texgs_render_forward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin), C.byref(img), stream),
                "texgs_render_forward (late hand-off)")
     s.img.survivors, s.img.surv_qmask, s.img.surv_count = img.survivors, img.surv_qmask, img.surv_count
-    s.img.tex_bin_count = img.tex_bin_count
+    s.img.tex_bin_count, s.img.tex_bin_resv = img.tex_bin_count, img.tex_bin_resv
     s.tensors._arenas = tuple(s.tensors._arenas) + (ar,)
-    for n in ("survivors", "surv_qmask", "surv_count", "tex_bin_count"):
+    for n in ("survivors", "surv_qmask", "surv_count", "tex_bin_count", "tex_bin_resv"):
         s.tensors.pop(n, None)
     if not s.want_counts:
         s.tensors["tex_bin_count"] = None
