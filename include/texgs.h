@@ -83,7 +83,10 @@ typedef struct TexGSGeom {
     uint32_t* rect;            /* u32[N,2]: (minx | miny<<16), (maxx | maxy<<16) tile rectangle        */
     uint32_t* tiles_touched;   /* u32[N]                                                               */
     uint32_t* offsets;         /* u32[N] EXCLUSIVE prefix sum of tiles_touched in depth-rank order: offsets[r] = first
-                                  instance slot of the r-th Gaussian of the (depth bits, index) order (K2)              */
+                                  instance slot of the r-th Gaussian of the (depth bits, index) order.  Written by K3
+                                  (texgs_bin_sort_render_forward) from what K2 left in scan_temp; undefined before that.  K3
+                                  only reads K2's result, so texgs_bin_sort_render_forward may be called again on it (a retry
+                                  with larger buffers, a timing loop)                                                   */
     void*     scan_temp;       /* >= texgs_scan_temp_bytes(N): K1's per-workgroup words, depth bins, depth-sorted (key, index) */
     size_t    scan_temp_bytes;
 } TexGSGeom;
@@ -108,10 +111,12 @@ typedef struct TexGSImage {
     float*    out_alpha;       /* f32[1,H,W]                                                           */
     float*    final_T;         /* f32[H,W]                                                             */
     uint32_t* n_contrib;       /* u32[H,W] 1-based position of the last contributor in the tile list   */
-    uint32_t* tex_bin_count;   /* u32[texgs_tex_bin_count(R)] or NULL.  Non-NULL = "a backward will follow": K6 (which zero-fills it
+    uint32_t* tex_bin_count;   /* u32[2 * texgs_tex_bin_count(R)] or NULL.  Non-NULL = "a backward will follow": K6 (which zero-fills it
                                   first) counts the bilinear footprints per 32x32-texel texture bin, the exact sizes of the
-                                  record lists texgs_backward_render builds.  NULL: forward-only call, or a backward that
-                                  sends every texture-gradient footprint through atomics.                              */
+                                  record lists texgs_backward_render builds: [b] = records the 8x8 pixel blocks RESERVED in bin
+                                  b's list (tex_bin_resv), [count + b] = overflow footprints, appended behind them (v12).
+                                  NULL: forward-only call, or a backward that sends every texture-gradient footprint through
+                                  atomics.                                                                              */
     /* K6 -> K7 hand-off, all three non-NULL when a backward will follow (else all NULL): K6 culls every tile list against each
        of the tile's four 8x8 pixel blocks anyway; it leaves the survivors so that K7 replays them instead of culling again. */
     uint32_t* survivors;       /* u32[2 * 4 * capacity] {Gaussian id, list position} pairs; block (tile, w) owns entries
@@ -120,13 +125,16 @@ typedef struct TexGSImage {
     uint16_t* surv_qmask;      /* u16[4 * capacity] bit q: the survivor reaches 4x4 quadrant q of its block                  */
     uint32_t* surv_count;      /* u32[4 * T] survivors written per block                                                     */
     uint32_t* tex_bin_resv;    /* u32[4 * T * TEXGS_RESV_WORDS] or NULL (v12; non-NULL together with tex_bin_count).  Per 8x8 pixel
-                                  block, K6's RESERVATIONS in the texture-gradient record lists: up to 16 entries {texture bin,
-                                  first record of the block inside that bin's list, records} as three planes of 16 words.  K6
-                                  takes them with one returning atomic per (block, bin) on tex_bin_count (which thereby becomes
-                                  the per-bin totals); K7 hands the slots out block-locally -- no global cursor, no grouping.
-                                  No initialisation; written for every block.                                              */
+                                  block, K6's RESERVATIONS in the texture-gradient record lists: a direct-mapped table of 64
+                                  entries {texture bin (0xFFFFFFFF: free), first record of the block inside that bin's list,
+                                  records} as three planes of 64 words, entry = low 3 bits of the bin's x | y inside its face.
+                                  K6 takes each range with one returning atomic per (block, bin) on tex_bin_count[bin]; K7
+                                  hands the slots out block-locally (an LDS atomic per footprint: no global cursor, no
+                                  grouping).  Footprints whose entry belongs to another bin (~2 %) are counted in the second half
+                                  of tex_bin_count and appended through TexGSGrads.tex_bin_cursor.  No initialisation; written
+                                  for every block.                                                                       */
 } TexGSImage;
-#define TEXGS_RESV_WORDS 48
+#define TEXGS_RESV_WORDS 192
 
 #define TEXGS_ACC_MEANS3D 1
 #define TEXGS_ACC_MEANS2D 2
@@ -177,8 +185,8 @@ typedef struct TexGSGrads {
                                   NULL (or no counts, or cap 0) = fp32 atomics straight into dL_dtexture (~20 G requests/s
                                   memory-side: 0.7 ms per C3 view).  Contents need no initialisation.  The 5 low mantissa
                                   bits of fx / fy carry the cell (fx, fy keep 18 bits, rounded).                         */
-    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: two status words behind a per-bin part that is unused since v12
-                                  (v11 kept the lists' fill cursors there; the layout is unchanged): [count] receives
+    uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: the fill cursors of the lists' OVERFLOW parts (scratch, set at the
+                                  start of every backward: no initialisation) + two status words: [count] receives
                                   max(records a call needed) -- zero it once; never cleared by the library: the caller sizes
                                   tex_rec_cap from it --, [count+1] = bits of max |dL/dpixel colour| of the call in flight
                                   (reset by every backward).                                                              */

@@ -57,6 +57,11 @@ typedef struct {
     float tanfovx, tanfovy, scale_modifier;
     const float *bg, *V, *P, *cam;               /* host pointers: bg[3], viewmatrix[16], projmatrix[16], campos[3] */
     const float *means, *shs, *opac, *scales, *rots, *uvs, *juv, *tex;
+    /* the untextured surface `diff_gauss` (reference render/render.py:75-84): tex == NULL (uvs / juv may then be NULL too) --
+       colour = max(0, viewdep + coff + 0.5) with coff = C0 * SH_DC or colors_precomp - 0.5 (render/render.py:66-68);
+       cov3d (render/render.py:52-53, layout of utils/general.py:73-82: xx xy xz yy yz zz) replaces scales / rots, the scale
+       modifier is then not applied (lineage) */
+    const float *coff, *cov3d;
 } RefIn;
 
 typedef struct {           /* per-Gaussian forward intermediates (same fields as the HIP kernel's) */
@@ -117,6 +122,41 @@ static void sh_basis_grad(int deg, float x, float y, float z, float *bx, float *
     }
 }
 
+/* Unit eigenvector of the smallest eigenvalue of the symmetric matrix (xx,xy,xz,yy,yz,zz): cyclic Jacobi, six sweeps in the fixed
+ * order (0,1), (0,2), (1,2), on the matrix scaled by 1 / trace.  "The shortest axis" of a splat given by its covariance
+ * (decision 8): a selection -- no gradient flows through it.  Same operations as the HIP kernel's. */
+static void jacobi_rot(float *app, float *aqq, float *apq, float *arp, float *arq, float *v0p, float *v0q, float *v1p, float *v1q,
+                       float *v2p, float *v2q) {
+    if (fabsf(*apq) < 1e-30f) return;
+    const float theta = (*aqq - *app) / (2.0f * *apq);
+    const float t = ((theta >= 0.f) ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+    const float c = 1.0f / sqrtf(t * t + 1.0f), sn = t * c;
+    *app -= t * *apq; *aqq += t * *apq; *apq = 0.f;
+    const float rp = *arp, rq = *arq;
+    *arp = c * rp - sn * rq; *arq = sn * rp + c * rq;
+    float x;
+    x = *v0p; *v0p = c * x - sn * *v0q; *v0q = sn * x + c * *v0q;
+    x = *v1p; *v1p = c * x - sn * *v1q; *v1q = sn * x + c * *v1q;
+    x = *v2p; *v2p = c * x - sn * *v2q; *v2q = sn * x + c * *v2q;
+}
+static void smallest_eigvec(const float *S6, float *n) {
+    const float tr = S6[0] + S6[3] + S6[5];
+    const float sc = (tr > 0.f) ? 1.0f / tr : 1.0f;
+    float a00 = S6[0] * sc, a01 = S6[1] * sc, a02 = S6[2] * sc, a11 = S6[3] * sc, a12 = S6[4] * sc, a22 = S6[5] * sc;
+    float v00 = 1.f, v01 = 0.f, v02 = 0.f, v10 = 0.f, v11 = 1.f, v12 = 0.f, v20 = 0.f, v21 = 0.f, v22 = 1.f;
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        jacobi_rot(&a00, &a11, &a01, &a02, &a12, &v00, &v01, &v10, &v11, &v20, &v21);
+        jacobi_rot(&a00, &a22, &a02, &a01, &a12, &v00, &v02, &v10, &v12, &v20, &v22);
+        jacobi_rot(&a11, &a22, &a12, &a01, &a02, &v01, &v02, &v11, &v12, &v21, &v22);
+    }
+    int k = 0; float m = a00;
+    if (a11 < m) { m = a11; k = 1; }
+    if (a22 < m) { m = a22; k = 2; }
+    n[0] = (k == 0) ? v00 : ((k == 1) ? v01 : v02);
+    n[1] = (k == 0) ? v10 : ((k == 1) ? v11 : v12);
+    n[2] = (k == 0) ? v20 : ((k == 1) ? v21 : v22);
+}
+
 /* Same fp32 operation order as geo_forward() in the HIP preprocess kernel (bit-exact contract). */
 static void geo_forward(Geo *g, const RefIn *in, int i) {
     const float *V = in->V, *P = in->P;
@@ -138,12 +178,18 @@ static void geo_forward(Geo *g, const RefIn *in, int i) {
     const float ndcx = g->hx * g->pw, ndcy = g->hy * g->pw;
     g->xy[0] = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
     g->xy[1] = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (in->cov3d) {        /* the world covariance is an input (render/render.py:52-53): used as it is */
+        for (int k = 0; k < 6; ++k) g->S[k] = in->cov3d[6 * i + k];
+        for (int k = 0; k < 9; ++k) { g->R[k] = 0.f; g->M[k] = 0.f; }
+        g->q[0] = g->q[1] = g->q[2] = g->q[3] = 0.f; g->s[0] = g->s[1] = g->s[2] = 0.f;
+    } else {
     for (int k = 0; k < 4; ++k) g->q[k] = in->rots[4 * i + k];
     const float r = g->q[0], x = g->q[1], y = g->q[2], z = g->q[3];
     g->R[0] = 1.0f - 2.0f * (y * y + z * z); g->R[1] = 2.0f * (x * y - r * z); g->R[2] = 2.0f * (x * z + r * y);
     g->R[3] = 2.0f * (x * y + r * z); g->R[4] = 1.0f - 2.0f * (x * x + z * z); g->R[5] = 2.0f * (y * z - r * x);
     g->R[6] = 2.0f * (x * z - r * y); g->R[7] = 2.0f * (y * z + r * x); g->R[8] = 1.0f - 2.0f * (x * x + y * y);
-    const float s0 = in->scales[3 * i], s1 = in->scales[3 * i + 1], s2 = in->scales[3 * i + 2];
+    s0 = in->scales[3 * i]; s1 = in->scales[3 * i + 1]; s2 = in->scales[3 * i + 2];
     g->s[0] = in->scale_modifier * s0; g->s[1] = in->scale_modifier * s1; g->s[2] = in->scale_modifier * s2;
     for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) g->M[rr * 3 + cc] = g->R[rr * 3 + cc] * g->s[cc];
     const float *M = g->M;
@@ -153,6 +199,7 @@ static void geo_forward(Geo *g, const RefIn *in, int i) {
     g->S[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
     g->S[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
     g->S[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    }
     const float limx = FRUSTUM_CLAMP * in->tanfovx, limy = FRUSTUM_CLAMP * in->tanfovy;
     const float txtz = tx / tz, tytz = ty / tz;
     g->clx = (txtz < -limx) || (txtz > limx);
@@ -185,11 +232,19 @@ static void geo_forward(Geo *g, const RefIn *in, int i) {
     const float mid = 0.5f * (g->a + g->c);
     const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - g->det));
     g->radius = (int)ceilf(3.0f * sqrtf(lam));
-    g->kmin = 0; float smin = s0;
-    if (s1 < smin) { smin = s1; g->kmin = 1; }
-    if (s2 < smin) { smin = s2; g->kmin = 2; }
     g->dir[0] = mx - in->cam[0]; g->dir[1] = my - in->cam[1]; g->dir[2] = mz - in->cam[2];
-    float n0 = g->R[0 + g->kmin], n1 = g->R[3 + g->kmin], n2 = g->R[6 + g->kmin];
+    float n0, n1, n2;
+    if (in->cov3d) {
+        float ev[3];
+        smallest_eigvec(g->S, ev);
+        n0 = ev[0]; n1 = ev[1]; n2 = ev[2];
+        g->kmin = -1;       /* no rotation-matrix column: the normal's gradient goes nowhere */
+    } else {
+        g->kmin = 0; float smin = s0;
+        if (s1 < smin) { smin = s1; g->kmin = 1; }
+        if (s2 < smin) { smin = s2; g->kmin = 2; }
+        n0 = g->R[0 + g->kmin]; n1 = g->R[3 + g->kmin]; n2 = g->R[6 + g->kmin];
+    }
     g->sign = ((n0 * g->dir[0] + n1 * g->dir[1] + n2 * g->dir[2]) > 0.0f) ? -1.0f : 1.0f;
     g->n[0] = g->sign * n0; g->n[1] = g->sign * n1; g->n[2] = g->sign * n2;
     g->dlen = sqrtf(g->dir[0] * g->dir[0] + g->dir[1] * g->dir[1] + g->dir[2] * g->dir[2]);
@@ -197,10 +252,11 @@ static void geo_forward(Geo *g, const RefIn *in, int i) {
     for (int k = 0; k < 3; ++k) g->nv[k] = WR(V, k, 0) * g->n[0] + WR(V, k, 1) * g->n[1] + WR(V, k, 2) * g->n[2];
     g->sdot = g->nv[0] * tx + g->nv[1] * ty + g->nv[2] * tz;
     const float tn = sqrtf(tx * tx + ty * ty + tz * tz);
-    g->degen = fabsf(g->sdot) <= PLANE_EPS * tn;
-    const float *juv = in->juv;
+    const float *juv = in->tex ? in->juv : NULL;       /* untextured surface: no UV plane at all */
+    g->degen = (juv == NULL) || fabsf(g->sdot) <= PLANE_EPS * tn;
     for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc)
-        g->Km[rr * 3 + cc] = juv[9 * i + rr * 3 + 0] * WR(V, cc, 0) + juv[9 * i + rr * 3 + 1] * WR(V, cc, 1)
+        g->Km[rr * 3 + cc] = (juv == NULL) ? 0.0f
+                           : juv[9 * i + rr * 3 + 0] * WR(V, cc, 0) + juv[9 * i + rr * 3 + 1] * WR(V, cc, 1)
                            + juv[9 * i + rr * 3 + 2] * WR(V, cc, 2);
     if (g->degen) {
         g->gx = 0; g->gy = 0; for (int k = 0; k < 6; ++k) g->G[k] = 0;
@@ -252,11 +308,13 @@ uint32_t texgs_ref_preprocess(const RefIn *in, float *rec, float *depth, int32_t
             const float *sp = in->shs + (size_t)i * in->K * 3;
             for (int k = 0; k < na; ++k) { vd[0] += b[k] * sp[3 * k]; vd[1] += b[k] * sp[3 * k + 1]; vd[2] += b[k] * sp[3 * k + 2]; }
         }
+        if (in->coff) { vd[0] += in->coff[3 * i]; vd[1] += in->coff[3 * i + 1]; vd[2] += in->coff[3 * i + 2]; }
         radii[i] = g.radius; tiles[i] = (uint32_t)((x1 - x0) * (y1 - y0)); depth[i] = g.t[2];
         rect[4 * i] = x0; rect[4 * i + 1] = y0; rect[4 * i + 2] = x1; rect[4 * i + 3] = y1;
         r[0] = g.xy[0]; r[1] = g.xy[1]; r[2] = g.conic[0]; r[3] = g.conic[1]; r[4] = g.conic[2]; r[5] = in->opac[i];
         r[6] = g.gx; r[7] = g.gy; for (int k = 0; k < 6; ++k) r[8 + k] = g.G[k];
-        r[14] = in->uvs[3 * i]; r[15] = in->uvs[3 * i + 1]; r[16] = in->uvs[3 * i + 2];
+        if (in->tex && in->uvs) { r[14] = in->uvs[3 * i]; r[15] = in->uvs[3 * i + 1]; r[16] = in->uvs[3 * i + 2]; }
+        else { r[14] = 0.f; r[15] = 0.f; r[16] = 1.f; }
         r[17] = vd[0]; r[18] = vd[1]; r[19] = vd[2]; r[20] = g.t[2]; r[21] = g.n[0]; r[22] = g.n[1]; r[23] = g.n[2];
     }
     uint32_t run = 0;
@@ -355,20 +413,24 @@ void texgs_ref_render_fwd(const RefIn *in, const float *rec, const uint32_t *poi
                 if (alpha < ALPHA_MIN) continue;
                 const float Tn = T * (1.0f - alpha);
                 if (Tn < T_EPS) break;
-                const float dpx = -dx, dpy = -dy;
-                const float den = 1.0f + r[6] * dpx + r[7] * dpy;
-                const float inv = (den >= DEN_MIN) ? RCPF(den) : 0.0f;
-                const float u0 = r[14] + (r[8] * dpx + r[9] * dpy) * inv;
-                const float u1 = r[15] + (r[10] * dpx + r[11] * dpy) * inv;
-                const float u2 = r[16] + (r[12] * dpx + r[13] * dpy) * inv;
-                const Tap ct = cube_address(u0, u1, u2, in->R);
-                const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
-                const float w10 = (1.f - ct.fx) * ct.fy, w11 = ct.fx * ct.fy;
                 const float w = alpha * T;
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float tv = w00 * in->tex[ct.o00 + ch] + w01 * in->tex[ct.o01 + ch] + w10 * in->tex[ct.o10 + ch]
-                                   + w11 * in->tex[ct.o11 + ch];
-                    A[ch] += w * fmaxf(0.f, SH_C0 * tv + r[17 + ch] + 0.5f);
+                if (in->tex) {
+                    const float dpx = -dx, dpy = -dy;
+                    const float den = 1.0f + r[6] * dpx + r[7] * dpy;
+                    const float inv = (den >= DEN_MIN) ? RCPF(den) : 0.0f;
+                    const float u0 = r[14] + (r[8] * dpx + r[9] * dpy) * inv;
+                    const float u1 = r[15] + (r[10] * dpx + r[11] * dpy) * inv;
+                    const float u2 = r[16] + (r[12] * dpx + r[13] * dpy) * inv;
+                    const Tap ct = cube_address(u0, u1, u2, in->R);
+                    const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
+                    const float w10 = (1.f - ct.fx) * ct.fy, w11 = ct.fx * ct.fy;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float tv = w00 * in->tex[ct.o00 + ch] + w01 * in->tex[ct.o01 + ch] + w10 * in->tex[ct.o10 + ch]
+                                       + w11 * in->tex[ct.o11 + ch];
+                        A[ch] += w * fmaxf(0.f, SH_C0 * tv + r[17 + ch] + 0.5f);
+                    }
+                } else {        /* untextured surface: the colour is the (offset) view-dependent term alone */
+                    for (int ch = 0; ch < 3; ++ch) A[ch] += w * fmaxf(0.f, r[17 + ch] + 0.5f);
                 }
                 A[3] += w * r[20]; A[4] += w * r[21]; A[5] += w * r[22]; A[6] += w * r[23]; A[7] += w;
                 T = Tn; last = k - r0 + 1;
@@ -435,7 +497,7 @@ void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *poin
                         }
                     }
                     if (pass == 0) {
-                        if (contributes) {
+                        if (contributes && in->tex) {
                             const float dpx = -dx, dpy = -dy;
                             const float den = 1.0f + r[6] * dpx + r[7] * dpy;
                             const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
@@ -450,7 +512,11 @@ void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *poin
                         mpix = fminf(mpix, m);
                     } else {
                         const int marginal = pix_amb && (m < tau_fwd || past_marginal_stop);      /* may contribute on the other side */
-                        if (contributes || marginal) {
+                        if ((contributes || marginal) && !in->tex) {
+                            float m_relu = INFINITY;
+                            for (int ch = 0; ch < 3; ++ch) m_relu = fminf(m_relu, fabsf(r[17 + ch] + 0.5f));
+                            if (pix_amb || m_relu < tau_relu) gflag[id] = 1;
+                        } else if (contributes || marginal) {
                             const float dpx = -dx, dpy = -dy;
                             const float den = 1.0f + r[6] * dpx + r[7] * dpy;
                             const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
@@ -490,9 +556,25 @@ static void atomic_addd(double *p, double v) {
     *p += v;
 }
 
-/* K7: dout[8,H,W] upstream grads; acc[N,24] (double, zero-filled by caller), dtex (float, zero-filled) */
+/* K7: dout[8,H,W] upstream grads; acc[N,24] (double, zero-filled by caller), dtex (float, zero-filled).
+ * TEST ATTRIBUTION (optional, fmass != NULL; caller zero-fills fmass[N,24]): the part of every Gaussian's sums that hangs on a
+ * bilinear CELL choice within tau_cell texels of flipping -- for each such (pixel, Gaussian) pair, cell_weight x |term| of the
+ * terms that carry the texture's uv-derivative (slots 6..16 and the uv share of slots 0, 1).  Across a cell edge the sample is
+ * continuous and so are the texture gradient and everything else; only dL/duv of the pair changes -- by O(1) of itself on a
+ * white-noise texture (cell_weight 1), by a few per cent on a band-limited one.  Pushed through texgs_ref_preprocess_bwd (which is
+ * linear in the sums) this bounds, row by row, how far two fp32 implementations may be apart (tests/helpers.py grad_mass_attributed):
+ * the tolerance of EVERY row is widened by what its own near-edge pairs can contribute, instead of excusing a row altogether for
+ * having one such pair among its hundreds. */
+void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                             const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
+                             float tau_cell, float cell_weight, double *fmass);
 void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                           const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex) {
+    texgs_ref_render_bwd_ex(in, rec, point_list, ranges, final_T, n_contrib, dout, acc, dtex, 0.0f, 0.0f, NULL);
+}
+void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                             const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
+                             float tau_cell, float cell_weight, double *fmass) {
     const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE, HW = W * H;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gxn * gyn; ++tile) {
@@ -520,19 +602,23 @@ void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *poi
                 T = T / (1.0f - alpha);
                 const float w = alpha * T;
                 const float dpx = -dx, dpy = -dy;
+                const int textured = in->tex != NULL;
                 const float den = 1.0f + r[6] * dpx + r[7] * dpy;
-                const int good = den >= DEN_MIN;
+                const int good = textured && den >= DEN_MIN;
                 const float inv = good ? RCPF(den) : 0.0f;
                 const float nu0 = r[8] * dpx + r[9] * dpy, nu1 = r[10] * dpx + r[11] * dpy, nu2 = r[12] * dpx + r[13] * dpy;
                 const float u0 = r[14] + nu0 * inv, u1 = r[15] + nu1 * inv, u2 = r[16] + nu2 * inv;
-                const Tap ct = cube_address(u0, u1, u2, in->R);
+                Tap ct; memset(&ct, 0, sizeof(ct));
+                if (textured) ct = cube_address(u0, u1, u2, in->R);
                 const float w00 = (1.f - ct.fx) * (1.f - ct.fy), w01 = ct.fx * (1.f - ct.fy);
                 const float w10 = (1.f - ct.fx) * ct.fy, w11 = ct.fx * ct.fy;
-                float f[8], pre[3], t00[3], t01[3], t10[3], t11[3];
+                float f[8], pre[3], t00[3] = {0, 0, 0}, t01[3] = {0, 0, 0}, t10[3] = {0, 0, 0}, t11[3] = {0, 0, 0};
                 for (int ch = 0; ch < 3; ++ch) {
-                    t00[ch] = in->tex[ct.o00 + ch]; t01[ch] = in->tex[ct.o01 + ch];
-                    t10[ch] = in->tex[ct.o10 + ch]; t11[ch] = in->tex[ct.o11 + ch];
-                    pre[ch] = SH_C0 * (w00 * t00[ch] + w01 * t01[ch] + w10 * t10[ch] + w11 * t11[ch]) + r[17 + ch] + 0.5f;
+                    if (textured) {
+                        t00[ch] = in->tex[ct.o00 + ch]; t01[ch] = in->tex[ct.o01 + ch];
+                        t10[ch] = in->tex[ct.o10 + ch]; t11[ch] = in->tex[ct.o11 + ch];
+                        pre[ch] = SH_C0 * (w00 * t00[ch] + w01 * t01[ch] + w10 * t10[ch] + w11 * t11[ch]) + r[17 + ch] + 0.5f;
+                    } else pre[ch] = r[17 + ch] + 0.5f;       /* untextured surface (render/render.py:68) */
                     f[ch] = fmaxf(0.f, pre[ch]);
                 }
                 f[3] = r[20]; f[4] = r[21]; f[5] = r[22]; f[6] = r[23]; f[7] = 1.0f;
@@ -556,7 +642,7 @@ void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *poi
                 float dtexv[3], dLdcol = 0.f, dLdrow = 0.f;
                 for (int ch = 0; ch < 3; ++ch) {
                     const float dc = (pre[ch] > 0.f) ? w * dpix[ch] : 0.f;
-                    part[17 + ch] = dc; dtexv[ch] = SH_C0 * dc;
+                    part[17 + ch] = dc; dtexv[ch] = textured ? SH_C0 * dc : 0.f;
                     if (dtexv[ch] != 0.f) {
                         atomic_addf(dtex + ct.o00 + ch, w00 * dtexv[ch]); atomic_addf(dtex + ct.o01 + ch, w01 * dtexv[ch]);
                         atomic_addf(dtex + ct.o10 + ch, w10 * dtexv[ch]); atomic_addf(dtex + ct.o11 + ch, w11 * dtexv[ch]);
@@ -571,31 +657,47 @@ void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *poi
                 else if (ct.axis == 1) { du1 = dum; du0 = dua; du2 = dub; }
                 else { du2 = dum; du0 = dua; du1 = dub; }
                 part[14] = du0; part[15] = du1; part[16] = du2;
+                float uv0 = 0.f, uv1 = 0.f;        /* the uv share of the xy slots */
                 if (good) {
                     const float dn0 = du0 * inv, dn1 = du1 * inv, dn2 = du2 * inv;
                     const float dden = -(du0 * nu0 + du1 * nu1 + du2 * nu2) * inv * inv;
                     part[8] = dn0 * dpx; part[9] = dn0 * dpy; part[10] = dn1 * dpx; part[11] = dn1 * dpy;
                     part[12] = dn2 * dpx; part[13] = dn2 * dpy; part[6] = dden * dpx; part[7] = dden * dpy;
-                    part[0] -= (r[8] * dn0 + r[10] * dn1 + r[12] * dn2) + r[6] * dden;
-                    part[1] -= (r[9] * dn0 + r[11] * dn1 + r[13] * dn2) + r[7] * dden;
+                    uv0 = (r[8] * dn0 + r[10] * dn1 + r[12] * dn2) + r[6] * dden;
+                    uv1 = (r[9] * dn0 + r[11] * dn1 + r[13] * dn2) + r[7] * dden;
+                    part[0] -= uv0;
+                    part[1] -= uv1;
                 }
                 double *ap = acc + (size_t)id * REC;
                 for (int k = 0; k < REC; ++k) if (part[k] != 0.f) atomic_addd(ap + k, (double)part[k]);
+                if (fmass && textured && fminf(fminf(ct.fx, 1.0f - ct.fx), fminf(ct.fy, 1.0f - ct.fy)) < tau_cell) {
+                    double *fp = fmass + (size_t)id * REC;
+                    for (int k = 6; k < 17; ++k) if (part[k] != 0.f) atomic_addd(fp + k, (double)(cell_weight * fabsf(part[k])));
+                    if (uv0 != 0.f) atomic_addd(fp + 0, (double)(cell_weight * fabsf(uv0)));
+                    if (uv1 != 0.f) atomic_addd(fp + 1, (double)(cell_weight * fabsf(uv1)));
+                }
             }
         }
     }
 }
 
-/* K8: acc[N,24] -> input gradients */
+/* K8: acc[N,24] -> input gradients.  d_coff [N,3] (dL/dcolor_offset) and d_cov [N,6] (dL/dcov3D, off-diagonal entries carrying
+ * both symmetric halves: the lineage's layout) may be NULL; with in->cov3d, d_scales / d_rots may be NULL and receive nothing. */
 void texgs_ref_preprocess_bwd(const RefIn *in, const int32_t *radii, const double *acc, float *d_means, float *d_means2D,
-                              float *d_shs, float *d_op, float *d_scales, float *d_rots, float *d_uvs) {
+                              float *d_shs, float *d_op, float *d_scales, float *d_rots, float *d_uvs, float *d_coff, float *d_cov) {
     const int N = in->N, K = in->K;
     const float fx = (float)in->W / (2.0f * in->tanfovx), fy = (float)in->H / (2.0f * in->tanfovy);
     const float *V = in->V, *P = in->P;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
-        for (int k = 0; k < 3; ++k) { d_means[3 * i + k] = 0; d_means2D[3 * i + k] = 0; d_scales[3 * i + k] = 0; d_uvs[3 * i + k] = 0; }
-        for (int k = 0; k < 4; ++k) d_rots[4 * i + k] = 0;
+        for (int k = 0; k < 3; ++k) {
+            d_means[3 * i + k] = 0; d_means2D[3 * i + k] = 0;
+            if (d_scales) d_scales[3 * i + k] = 0;
+            if (d_uvs) d_uvs[3 * i + k] = 0;
+            if (d_coff) d_coff[3 * i + k] = 0;
+        }
+        if (d_rots) for (int k = 0; k < 4; ++k) d_rots[4 * i + k] = 0;
+        if (d_cov) for (int k = 0; k < 6; ++k) d_cov[6 * i + k] = 0;
         d_op[i] = 0;
         if (d_shs) for (int k = 0; k < 3 * K; ++k) d_shs[(size_t)i * 3 * K + k] = 0;
         if (radii[i] <= 0) continue;
@@ -603,7 +705,9 @@ void texgs_ref_preprocess_bwd(const RefIn *in, const int32_t *radii, const doubl
         float A[REC]; for (int k = 0; k < REC; ++k) A[k] = (float)acc[(size_t)i * REC + k];
         const float tx = g.t[0], ty = g.t[1], tz = g.t[2];
         float dt[3] = {0, 0, 0}, dm[3] = {0, 0, 0}, dR[9]; for (int k = 0; k < 9; ++k) dR[k] = 0;
-        d_op[i] = A[5]; d_uvs[3 * i] = A[14]; d_uvs[3 * i + 1] = A[15]; d_uvs[3 * i + 2] = A[16];
+        d_op[i] = A[5];
+        if (d_uvs) { d_uvs[3 * i] = A[14]; d_uvs[3 * i + 1] = A[15]; d_uvs[3 * i + 2] = A[16]; }
+        if (d_coff) { d_coff[3 * i] = A[17]; d_coff[3 * i + 1] = A[18]; d_coff[3 * i + 2] = A[19]; }
         const float dA = A[2], dB = A[3], dC = A[4], inv = g.inv, inv2 = inv * inv;
         const float da = dA * (-g.c * g.c * inv2) + dB * (g.b * g.c * inv2) + dC * (inv - g.a * g.c * inv2);
         const float db = dA * (2.0f * g.b * g.c * inv2) + dB * (-inv - 2.0f * g.b * g.b * inv2) + dC * (2.0f * g.a * g.b * inv2);
@@ -618,6 +722,10 @@ void texgs_ref_preprocess_bwd(const RefIn *in, const int32_t *radii, const doubl
         float dS[9], dM[9], dscale[3];
         for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l)
             dS[k * 3 + l] = g.T0[k] * g.T0[l] * da + (g.T0[k] * g.T1[l] + g.T1[k] * g.T0[l]) * hb + g.T1[k] * g.T1[l] * dc;
+        if (in->cov3d && d_cov) {
+            d_cov[6 * i] = dS[0]; d_cov[6 * i + 1] = dS[1] + dS[3]; d_cov[6 * i + 2] = dS[2] + dS[6];
+            d_cov[6 * i + 3] = dS[4]; d_cov[6 * i + 4] = dS[5] + dS[7]; d_cov[6 * i + 5] = dS[8];
+        }
         for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc)
             dM[rr * 3 + cc] = 2.0f * (dS[rr * 3] * g.M[cc] + dS[rr * 3 + 1] * g.M[3 + cc] + dS[rr * 3 + 2] * g.M[6 + cc]);
         for (int cc = 0; cc < 3; ++cc) {
@@ -655,7 +763,7 @@ void texgs_ref_preprocess_bwd(const RefIn *in, const int32_t *radii, const doubl
             dt[0] += ds * g.nv[0]; dt[1] += ds * g.nv[1]; dt[2] += ds * g.nv[2] + dtz;
             for (int k = 0; k < 3; ++k) dn[k] += dnv[0] * WR(V, 0, k) + dnv[1] * WR(V, 1, k) + dnv[2] * WR(V, 2, k);
         }
-        dR[g.kmin] += g.sign * dn[0]; dR[3 + g.kmin] += g.sign * dn[1]; dR[6 + g.kmin] += g.sign * dn[2];
+        if (g.kmin >= 0) { dR[g.kmin] += g.sign * dn[0]; dR[3 + g.kmin] += g.sign * dn[1]; dR[6 + g.kmin] += g.sign * dn[2]; }
         const int na = (in->shs && in->sh_degree > 0) ? sh_active(in->sh_degree, K) : 0;
         if (d_shs && na > 0) {
             float b[15], bx[15], by[15], bz[15];
@@ -673,7 +781,9 @@ void texgs_ref_preprocess_bwd(const RefIn *in, const int32_t *radii, const doubl
             dm[0] += (ddx - g.dir[0] * dd) / g.dlen; dm[1] += (ddy - g.dir[1] * dd) / g.dlen; dm[2] += (ddz - g.dir[2] * dd) / g.dlen;
         }
         for (int k = 0; k < 3; ++k) dm[k] += dt[0] * V[k * 4] + dt[1] * V[k * 4 + 1] + dt[2] * V[k * 4 + 2];
-        for (int k = 0; k < 3; ++k) { d_means[3 * i + k] = dm[k]; d_scales[3 * i + k] = dscale[k]; }
+        for (int k = 0; k < 3; ++k) d_means[3 * i + k] = dm[k];
+        if (in->cov3d || !d_scales || !d_rots) continue;
+        for (int k = 0; k < 3; ++k) d_scales[3 * i + k] = dscale[k];
         const float r = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
         d_rots[4 * i] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
         d_rots[4 * i + 1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
@@ -695,4 +805,62 @@ void texgs_ref_set_threads(int n) {
 #else
     (void)n;
 #endif
+}
+
+/* DIAGNOSTIC (tests / sizing only): per 8x8 pixel block, how many distinct 32x32-texel texture bins do the bilinear footprints of
+ * its contributing (pixel, Gaussian) pairs fall into, and how many of the footprints would miss a DIRECT-MAPPED table of
+ * `slots` (16 / 32 / 64) entries (first bin to arrive owns its slot; hash 0: low bits of the bin's (x, y) inside the face,
+ * hash 1: the same xor-folded with the face)?  The product's K6 keeps such a table per block (csrc/render.hip); this is the sizing
+ * evidence for it.  out_blocks[4 * T][3] = {distinct bins (capped at 1024), footprints, footprints that miss}. */
+void texgs_ref_block_bin_stats(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                               int slots, int hash, uint32_t *out_blocks) {
+    const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE;
+    const int nb = (in->R + 31) >> 5;
+    const int lx2 = (slots >= 64) ? 3 : 2, ly2 = (slots >= 32) ? 3 : 2;        /* 16: 2+2 bits, 32: 2+3, 64: 3+3 */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gxn * gyn; ++tile) {
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const int tx0 = (tile % gxn) * TILE, ty0 = (tile / gxn) * TILE;
+        for (int blk = 0; blk < 4; ++blk) {
+            uint32_t seen[1024]; int nseen = 0;
+            uint32_t slot[64]; for (int k = 0; k < 64; ++k) slot[k] = 0xFFFFFFFFu;
+            uint32_t nfoot = 0, nmiss = 0;
+            /* K6 walks the list in depth order for the whole block; here pixel by pixel -- the OWNER of a slot may differ from
+               the kernel's (first to arrive in list order), the counts are representative, not identical */
+            for (int ly = 0; ly < 8; ++ly) for (int lx = 0; lx < 8; ++lx) {
+                const int px = tx0 + ((blk & 1) << 3) + lx, py = ty0 + ((blk >> 1) << 3) + ly;
+                if (px >= W || py >= H) continue;
+                const float pxf = (float)px, pyf = (float)py;
+                float T = 1.0f;
+                for (uint32_t k = r0; k < r1; ++k) {
+                    const float *r = rec + (size_t)point_list[k] * REC;
+                    const float dx = r[0] - pxf, dy = r[1] - pyf;
+                    const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float alpha = fminf(ALPHA_MAX, r[5] * expf(power));
+                    if (alpha < ALPHA_MIN) continue;
+                    const float Tn = T * (1.0f - alpha);
+                    if (Tn < T_EPS) break;
+                    const float dpx = -dx, dpy = -dy;
+                    const float den = 1.0f + r[6] * dpx + r[7] * dpy;
+                    const float inv = (den >= DEN_MIN) ? 1.0f / den : 0.0f;
+                    const Tap ct = cube_address(r[14] + (r[8] * dpx + r[9] * dpy) * inv, r[15] + (r[10] * dpx + r[11] * dpy) * inv,
+                                                r[16] + (r[12] * dpx + r[13] * dpy) * inv, in->R);
+                    T = Tn;
+                    if (ct.o01 == ct.o00 || ct.o10 == ct.o00) continue;            /* clamped at a face border: never binned */
+                    const int texel = ct.o00 / 3, x0 = texel % in->R, y0 = (texel / in->R) % in->R, face = texel / (in->R * in->R);
+                    const uint32_t bin = (uint32_t)((face * nb + (y0 >> 5)) * nb + (x0 >> 5));
+                    ++nfoot;
+                    int f = 0; for (; f < nseen; ++f) if (seen[f] == bin) break;
+                    if (f == nseen && nseen < 1024) seen[nseen++] = bin;
+                    int h = ((x0 >> 5) & ((1 << lx2) - 1)) | (((y0 >> 5) & ((1 << ly2) - 1)) << lx2);
+                    if (hash == 1) h = (h ^ (face * 11)) & (slots - 1);
+                    if (slot[h] == 0xFFFFFFFFu) slot[h] = bin;
+                    if (slot[h] != bin) ++nmiss;
+                }
+            }
+            uint32_t *o = out_blocks + 3 * (size_t)(4 * tile + blk);
+            o[0] = (uint32_t)nseen; o[1] = nfoot; o[2] = nmiss;
+        }
+    }
 }

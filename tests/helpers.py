@@ -159,6 +159,11 @@ def tau_relu(R):
 
 
 
+# share of a pair's dL/duv that a different bilinear cell changes on synth.band_limited_texture(period=64): the first derivative is
+# continuous, its step across a texel edge is ~ f'' x 1 texel ~ (2-3) / period of f'
+BAND_LIMITED_CELL_WEIGHT = 0.05
+
+
 def tau_cell(R):
     """Distance (texels) of a bilinear sample from a cell edge below which the cell may be chosen differently: 2 ulp of the
     fp32 texel coordinate (col, row < R; (sc rma + 1) R/2 - 0.5 is fused / uses v_rcp on one side and not on the other)."""
@@ -173,7 +178,7 @@ def image_tol(R, tol=1e-4):
     return tol * max(1.0, float(R) / 1024.0)
 
 
-def forward_attributed(label, got8, ref, margin, tol=1e-4, depth_tol=4e-4, n_contrib=None, amb_frac_max=1e-3):
+def forward_attributed(label, got8, ref, margin, tol=1e-4, depth_tol=4e-4, n_contrib=None, amb_frac_max=1e-3, rgb_tol=None):
     """north_star's 'per-pixel RGB / alpha within 1e-4' LITERALLY on every pixel whose discrete decisions are not within TAU_FWD
     of a threshold (RGB: image_tol(R) -- 1e-4 up to R = 1024); the rest (ambiguous) must be < 0.1 % of the image.  Returns the
     measured figures (also reported)."""
@@ -181,7 +186,8 @@ def forward_attributed(label, got8, ref, margin, tol=1e-4, depth_tol=4e-4, n_con
     exp = torch.as_tensor(ref.out)
     err = (got8.cpu() - exp).abs()
     scale = torch.full((8, 1, 1), tol); scale[3] = depth_tol
-    scale[0:3] = image_tol(ref.R, tol)
+    rgb_tol = image_tol(ref.R, tol) if rgb_tol is None else rgb_tol      # (a band-limited texture: the literal tolerance at any R)
+    scale[0:3] = rgb_tol
     over = (err > scale).any(dim=0)
     amb = torch.as_tensor(margin < TAU_FWD)
     unexplained = over & ~amb
@@ -189,7 +195,7 @@ def forward_attributed(label, got8, ref, margin, tol=1e-4, depth_tol=4e-4, n_con
     res = dict(ambiguous_pixel_frac=float(amb.float().mean()), pixels_over_tol=int(over.sum()),
                pixels_over_tol_ambiguous=int((over & amb).sum()), pixels_over_tol_UNEXPLAINED=int(unexplained.sum()),
                max_err_unambiguous_in_tol_units=clean_max, worst_pixel_any=float((err / scale * tol).max()), tau_fwd=TAU_FWD,
-               rgb_tol=image_tol(ref.R, tol), alpha_normal_tol=tol, depth_tol=depth_tol)
+               rgb_tol=rgb_tol, alpha_normal_tol=tol, depth_tol=depth_tol)
     if n_contrib is not None:
         agree = torch.as_tensor(np.asarray(n_contrib) == ref.n_contrib)
         res["n_contrib_mismatch_unambiguous"] = int((~agree & ~amb).sum())
@@ -240,3 +246,188 @@ def grad_attributed(label, got, exp, flagged, row_rtol=1e-3, row_atol_frac=1e-4,
     assert res["outlier_rows_flagged"] <= flagged_outlier_frac_max * max(res["rows_with_gradient"], 1) + 20, res
     assert res["max_row_err_over_gmax_flagged"] < flagged_err_max, res
     return res
+
+
+def grad_mass_attributed(label, got, exp, hard_flag, dev, kappa=4.0, row_rtol=1e-3, row_atol_frac=1e-4, hard_frac_max=0.05,
+                         clean_rel=2e-3):
+    """Pair-level attribution (VERDICT r4 #3b).  EVERY per-Gaussian gradient row is checked: its tolerance is the plain one
+    (1e-3 relative + 1e-4 of the largest entry) plus kappa x `dev`, the amount by which the row can move when the uv-derivative of
+    each of ITS OWN near-cell-edge (pixel, Gaussian) pairs is swapped for another of its size (oracle/texgs_ref.py
+    cell_edge_deviation) -- a row with one such pair among 300 gets a tolerance a fraction of a per cent wider, not a pardon.
+    Only rows behind a 1/255, T-stop or colour-clamp decision within rounding of flipping (`hard_flag`: a contributor may appear
+    or vanish) may differ freely; they must stay under hard_frac_max of the rows that carry a gradient.  Zero unexplained rows."""
+    g = got.double().reshape(got.shape[0], -1)
+    e = exp.double().reshape(g.shape)
+    hard = torch.as_tensor(hard_flag).reshape(-1)
+    dv = torch.as_tensor(dev).double().reshape(-1)
+    gmax = float(e.abs().max())
+    err = (g - e).abs().max(dim=1).values
+    base = row_rtol * e.abs().max(dim=1).values + row_atol_frac * gmax
+    tol = base + kappa * dv
+    touched = e.abs().max(dim=1).values > 0
+    bad = err > tol
+    unexplained = bad & ~hard
+    widened = (kappa * dv > base) & touched
+    ok_rows = ~hard
+    rel = float((g[ok_rows] - e[ok_rows]).norm() / e[ok_rows].norm().clamp_min(1e-300))
+    res = dict(rows=int(g.shape[0]), rows_with_gradient=int(touched.sum()), hard_flagged_rows=int((hard & touched).sum()),
+               hard_flagged_frac=float((hard & touched).sum()) / max(int(touched.sum()), 1),
+               rows_with_tolerance_more_than_doubled_frac=float(widened.sum()) / max(int(touched.sum()), 1),
+               rows_over_plain_tolerance=int((err > base).sum()), rows_over_widened_tolerance=int(bad.sum()),
+               outlier_rows_UNEXPLAINED=int(unexplained.sum()), rel_l2_all_but_hard=rel,
+               median_widening_over_plain=float((kappa * dv[touched] / base[touched]).median()) if bool(touched.any()) else 0.0)
+    if int(unexplained.sum()):
+        idx = torch.nonzero(unexplained).reshape(-1)[:8]
+        res["unexplained_rows"] = [int(i) for i in idx]
+        res["unexplained_err_over_tol"] = [float(err[i] / tol[i]) for i in idx]
+    report(label, **res)
+    assert res["outlier_rows_UNEXPLAINED"] == 0, res
+    assert res["hard_flagged_frac"] < hard_frac_max, res
+    assert rel < clean_rel * 5, res
+    return res
+
+
+def band_limited_parity(label, scene, cam, bg, seed=9, flagged_frac_max=0.05):
+    """VERDICT r4 #3a: the same geometry with a BAND-LIMITED texture (synth.band_limited_texture) against the C oracle.  A bilinear
+    cell chosen differently then changes a pair's dL/duv by ~1 %, so NO gradient row is excused for sitting near a cell edge
+    (tau_cell = 0): what stays flagged are the 1/255, T-stop and colour-clamp decisions -- under 5 % of the rows -- and RGB is held
+    to the literal 1e-4 at any texture resolution."""
+    import numpy as np
+    from oracle import texgs_ref as CR
+    from texgs.rasterizer import backward_raw
+    R = scene.texture.shape[1]
+    scene2 = scene._replace(texture=synth.band_limited_texture(R, seed=seed, period=64, amplitude=0.5))
+    ref = CR.RefRun(scene2, settings_for(cam, 3, bg))
+    ref.forward()
+    margin, gflag, tflag = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=0.0, tau_relu=1e-5)
+    outs, s = hip_debug_state(scene2, cam, 3, bg)
+    got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0)
+    nc = s.tensors["n_contrib"].cpu().numpy().astype(np.uint32)
+    forward_attributed(f"{label}/fwd", got, ref, margin, n_contrib=nc, rgb_tol=1e-4)
+    H, W = cam.image_height, cam.image_width
+    g = torch.Generator().manual_seed(79)
+    dout = torch.randn(8, H, W, generator=g) / (H * W)
+    dev = outs[0].device
+    res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(), dout[4:7].to(dev).contiguous(),
+                       dout[7:8].to(dev).contiguous())
+    gref = ref.backward(dout.numpy(), tau_cell=tau_cell(R), cell_weight=BAND_LIMITED_CELL_WEIGHT)
+    cdev = ref.cell_edge_deviation()
+    sens = ref.accumulation_sensitive()
+    report(f"{label}/bwd/accumulation_sensitive_rows", rows=int(sens.sum()), frac=float(sens.mean()))
+    gflag = gflag | sens
+    for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
+        if name_ == "texture":
+            grad_attributed(f"{label}/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]), tflag, flagged_frac_max=flagged_frac_max)
+        else:
+            r = grad_mass_attributed(f"{label}/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]), gflag, cdev[name_],
+                                     hard_frac_max=flagged_frac_max)
+            assert r["rows_with_tolerance_more_than_doubled_frac"] < flagged_frac_max, (name_, r)
+
+
+def pair_level_gradient_check(label, ref, res, dout, R, sens):
+    """The white-noise runs, per-Gaussian gradients at PAIR level (grad_mass_attributed): `ref` a C-oracle run after forward(),
+    `res` the HIP backward's 8 gradients for upstream `dout`."""
+    gref = ref.backward(dout.numpy(), tau_cell=tau_cell(R), cell_weight=1.0)
+    cdev = ref.cell_edge_deviation()
+    _, hard, _ = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=0.0, tau_relu=tau_relu(R))
+    hard = hard | sens
+    for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs"], res[:7]):
+        grad_mass_attributed(f"{label}/{name_}", got_g.cpu(), torch.tensor(gref[name_]), hard, cdev[name_])
+    return gref
+
+
+# ---- the untextured surface (diff_gauss, render/render.py:75-84) ------------------------------------------------------------------
+class UntexturedScene:
+    """Inputs of the untextured surface as the kernels / oracles see them: view-dependent SH rows 1..K (`shs`, may be None), a
+    colour offset [N,3] (C0 * SH_DC for `shs=`, colors_precomp - 0.5 for `colors_precomp=`, render/render.py:66-68) and either
+    (scales, rotations) or cov3D_precomp [N,6] (render/render.py:52-53, layout utils/general.py:73-82).  texture is None."""
+    texture = None
+    uvs = None
+    gradient_uvs = None
+
+    def __init__(self, means3D, opacities, shs, color_offset, scales=None, rotations=None, cov3D_precomp=None):
+        self.means3D, self.opacities, self.shs, self.color_offset = means3D, opacities, shs, color_offset
+        self.scales, self.rotations, self.cov3D_precomp = scales, rotations, cov3D_precomp
+
+
+def untextured_from(scene, mode, seed=8, thin=None):
+    """mode 'shs': SH rows of the scene + a random DC row (offset = C0 * DC); 'precomp': random colours, no SH;
+    'cov': precomputed covariances of ellipsoids with three distinct axes (third axis `thin` x the smaller of the other two,
+    so that the smallest-eigenvector normal is well defined) + random colours."""
+    g = torch.Generator().manual_seed(seed)
+    N = scene.means3D.shape[0]
+    if mode == "shs":
+        dc = torch.randn(N, 3, generator=g)
+        return UntexturedScene(scene.means3D, scene.opacities, scene.shs, (O.SH_C0 * dc).float(), scene.scales, scene.rotations), dc
+    col = torch.rand(N, 3, generator=g)
+    if mode == "precomp":
+        return UntexturedScene(scene.means3D, scene.opacities, None, col - 0.5, scene.scales, scene.rotations), col
+    d = torch.float64
+    sc = scene.scales.to(d).clone()
+    lo, hi = thin or (0.2, 0.5)
+    sc[:, 2] = sc[:, :2].min(dim=1).values * (lo + (hi - lo) * torch.rand(N, generator=g, dtype=d))
+    Rm = O.build_rotation(scene.rotations.to(d))
+    M = Rm * sc[:, None, :]
+    Sig = M @ M.transpose(1, 2)
+    cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], 1).float()
+    return UntexturedScene(scene.means3D, scene.opacities, None, col - 0.5, cov3D_precomp=cov6), col
+
+
+def oracle_run_untextured(us, cam, sh_degree, bg, with_grad=False, target=None, nhat=None, depth_weight=0.0, dtype=torch.float64):
+    """The float64 torch oracle on an UntexturedScene (1x1 zero cubemap, zero Jacobian: the texture term vanishes identically).
+    -> (res, dbg, grads by name: means3D, opacities, shs, color_offset, scales, rotations | cov3D)."""
+    st = settings_for(cam, sh_degree, bg)
+    N = us.means3D.shape[0]
+    names = [n for n in ("means3D", "opacities", "shs", "color_offset", "scales", "rotations", "cov3D_precomp") if getattr(us, n) is not None]
+    leaves = {n: getattr(us, n).clone().to(dtype).requires_grad_(with_grad) for n in names}
+    uvs = torch.zeros(N, 3, dtype=dtype); uvs[:, 2] = 1.0
+    m2 = torch.zeros(N, 3, dtype=dtype, requires_grad=with_grad)
+    res, dbg = O.rasterize(leaves["means3D"], m2, leaves.get("shs"), leaves["opacities"], leaves.get("scales"), leaves.get("rotations"),
+                           uvs, torch.zeros(N, 9, dtype=dtype), torch.zeros(6, 1, 1, 3, dtype=dtype), st, dtype=dtype, debug=True,
+                           color_offset=leaves["color_offset"], cov3D_precomp=leaves.get("cov3D_precomp"))
+    grads = None
+    if with_grad:
+        L = synth.synthetic_loss(res[0], res[3], res[2], target.to(dtype), nhat.to(dtype))
+        if depth_weight:
+            L = L + depth_weight * res[1].mean()
+        L.backward()
+        grads = {("cov3D" if n == "cov3D_precomp" else n): leaves[n].grad for n in names}
+        grads["means2D"] = m2.grad
+    return res, dbg, grads
+
+
+def assert_integer_stages_bit_exact(ref, outs, s):
+    """HIP forward state `s` (+ outputs `outs`) against a C-oracle run `ref` of the same inputs: radii, tile rects, tiles_touched,
+    depth key bits, the rank-ordered offsets / instance keys (K2 / K3 contract of include/texgs.h), sorted keys, point list and
+    tile ranges -- all IDENTICAL."""
+    import numpy as np
+    N = ref.N
+    t = s.tensors
+    assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
+    assert np.array_equal(t["tiles_touched"][:N].cpu().numpy().astype(np.uint32), ref.tiles[:N])
+    assert s.D == ref.D
+    vis = ref.radii[:N] > 0
+    rect = t["rect"][:N].cpu().numpy().astype(np.uint32)
+    got = np.stack([rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, rect[:, 1] >> 16], 1).astype(np.int32)
+    assert np.array_equal(got[vis], ref.rect[:N][vis])
+    depth = t["depth"][:N].cpu().numpy()
+    assert np.array_equal(depth[vis].view(np.uint32), ref.depth[:N][vis].view(np.uint32))     # sort-key bits
+    assert np.all(depth[~vis].view(np.uint32) == 0xFFFFFFFF)                                  # culled: after every visible one
+    D = ref.D
+    # K2 / K3 contract (include/texgs.h): Gaussians ranked by (depth bits, index) with culled ones last; offsets = exclusive
+    # scan of tiles_touched in rank order; instance k of the r-th ranked Gaussian = (tile << 32) | r at offsets[r] + k
+    key = np.where(vis, ref.depth[:N].view(np.uint32), np.uint32(0xFFFFFFFF)).astype(np.uint64)
+    order = np.argsort(key, kind="stable")
+    tt_rank = ref.tiles[:N][order].astype(np.int64)
+    offs_rank = np.cumsum(tt_rank) - tt_rank
+    assert np.array_equal(t["offsets"][:N].cpu().numpy().astype(np.uint32).astype(np.int64), offs_rank)
+    offs_idx = ref.offsets[:N].astype(np.int64) - ref.tiles[:N].astype(np.int64)               # lineage: exclusive, index order
+    src = np.repeat(offs_idx[order], tt_rank) + (np.arange(D) - np.repeat(offs_rank, tt_rank))
+    exp_unsorted = (ref.keys_unsorted[:D][src] & np.uint64(0xFFFFFFFF00000000)) | np.repeat(np.arange(N, dtype=np.uint64), tt_rank)
+    assert np.array_equal(t["keys_unsorted"][:D].cpu().numpy().view(np.uint64), exp_unsorted)
+    assert np.array_equal(t["keys_sorted"][:D].cpu().numpy().view(np.uint64), ref.keys_sorted[:D])
+    assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
+    assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
+    # the xy / conic part of the record that the tile rect came from is bit-identical too
+    rec = t["rec"][:N, :2].cpu().numpy()
+    assert np.array_equal(rec[vis].view(np.uint32), ref.rec[:N, :2][vis].view(np.uint32))

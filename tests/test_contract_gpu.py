@@ -283,6 +283,16 @@ def test_c5_full_size_vs_c_oracle(lib_built):
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
         Hh.grad_attributed(f"hip_vs_c32/c5/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]),
                            tflag if name_ == "texture" else gflag)
+    # at PAIR level: every row checked (54 % of them are excused above for having one near-edge pair among hundreds)
+    Hh.pair_level_gradient_check("hip_vs_c32/c5/bwd_pair_level", ref, res, dout, 2048, sens)
+
+
+def test_c5_band_limited_texture_literal_tolerance(lib_built):
+    """C5 (1M Gaussians, 2048^2 cubemap, 1600x1200) with a band-limited texture: RGB at the LITERAL 1e-4 (no R / 1024 scaling), no
+    cell-edge flags, flagged gradient rows < 5 %, zero unexplained pixels / rows."""
+    scene = synth.make_scene(1_000_000, 2048, seed=0)
+    cam = synth.fibonacci_cameras(64, 1600, 1200)[7]
+    Hh.band_limited_parity("hip_vs_c32/c5_band_limited", scene, cam, torch.zeros(3))
 
 
 def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
@@ -308,6 +318,8 @@ def test_texture_gradient_bins_full_and_disabled_paths_agree(lib_built):
                     torch.cuda.synchronize()
                     (sc_,) = RZ._SCRATCH.values()
                     nb = sc_.bins.nbins
+                    # every list's overflow part was filled exactly to the end of the list (absolute cursors)
+                    assert torch.equal(sc_.bins.cursor[:nb], sc_.bins.base[1:nb + 1]), mode
                     wanted = int(sc_.bins.cursor[nb])
                     assert wanted == int(sc_.bins.base[nb]) > 2000          # list sizes of the last call: what K6 counted
                     # the reduce kernel's launch order (k_bin_offsets): every bin once, longest list first (up to the 1/32-octave
@@ -366,34 +378,35 @@ def test_texture_gradient_counts_and_no_count_path(lib_built):
 
 
 def _check_reservations(resv, counts):
-    """Invariants of K6's per-block reservation tables (TexGSImage.tex_bin_resv) against the per-bin totals: the ranges the blocks
-    took of every bin's list tile [0, count[bin]) exactly -- no gap, no overlap; a block lists a bin at most once."""
-    resv = resv.cpu().long().view(-1, 3, 16)
-    counts = counts.cpu().long()
+    """Invariants of K6's per-block reservation tables (TexGSImage.tex_bin_resv: 64 direct-mapped entries {bin, offset, count})
+    against the per-bin totals (first half of tex_bin_count): the ranges the blocks took of every bin's list tile [0, total[bin])
+    exactly -- no gap, no overlap; a block lists a bin at most once, at the entry its (x, y) low bits select."""
+    resv = (resv.cpu().long() & 0xFFFFFFFF).view(-1, 3, 64)
+    counts = counts.cpu().long() & 0xFFFFFFFF
+    nb = counts.numel() // 2
     bins, offs, cnts = resv[:, 0], resv[:, 1], resv[:, 2]
     used = bins != 0xFFFFFFFF
     assert bool((cnts[~used] == 0).all())
-    for row in bins:                                   # distinct bins per block
-        r = row[row != 0xFFFFFFFF]
-        assert r.numel() == r.unique().numel()
     b, o, c = bins[used], offs[used], cnts[used]
-    assert bool((c > 0).all())
-    tot = torch.zeros_like(counts).index_add_(0, b, c)
-    assert torch.equal(tot, counts)
+    assert bool((c > 0).all()) and bool((b < nb).all())
+    key = torch.arange(bins.shape[0])[:, None].expand_as(bins)[used] * (1 << 32) + b
+    assert key.unique().numel() == key.numel()                     # a bin at most once per block
+    tot = torch.zeros(nb, dtype=torch.long).index_add_(0, b, c)
+    assert torch.equal(tot, counts[:nb])
     order = torch.argsort(b * (1 << 32) + o)
     b, o, c = b[order], o[order], c[order]
     first = torch.ones_like(b, dtype=torch.bool)
     first[1:] = b[1:] != b[:-1]
     assert bool((o[first] == 0).all())
-    cont = ~first
-    assert bool((o[cont] == (o + c)[:-1][cont[1:]]).all())
-    return int(used.sum()), int(used.sum(1).max())
+    assert bool((o[1:][~first[1:]] == (o + c)[:-1][~first[1:]]).all())
+    return int(used.sum()), int(used.sum(1).max()), int(counts[nb:].sum())
 
 
 def test_block_reservations_tile_the_record_lists(lib_built):
-    """v12: K6 reserves, per 8x8 pixel block and texture bin, the block's range of the bin's record list; K7 fills exactly those
-    ranges (no cursor).  The tables partition every list; the binned gradient equals the one through atomics -- also when a block
-    sees more bins than its table holds (a coarse image of a fine texture: the surplus goes to dL_dtexture directly)."""
+    """v12: K6 reserves, per 8x8 pixel block and texture bin, the block's range of the bin's record list (a 64-entry direct-mapped
+    table per block); K7 fills exactly those ranges, no cursor.  The tables partition the reserved part of every list; the binned
+    gradient equals the one through atomics -- also when most footprints miss the table (a coarse image of a fine texture: a
+    block sees hundreds of bins; the surplus is counted and appended through the overflow cursor)."""
     from texgs import rasterizer as RZ
     from texgs.rasterizer import GaussianRasterizationSettings, forward_raw, backward_raw
     dev = torch.device("cuda:0")
@@ -407,10 +420,16 @@ def test_block_reservations_tile_the_record_lists(lib_built):
         RZ.release_scratch()
         _, s1 = forward_raw(st, *args)
         torch.cuda.synchronize()
-        entries, widest = _check_reservations(s1.tensors["tex_bin_resv"], s1.tensors["tex_bin_count"])
+        entries, widest, overflow = _check_reservations(s1.tensors["tex_bin_resv"], s1.tensors["tex_bin_count"])
+        records = int(s1.tensors["tex_bin_count"].sum())
         g = torch.Generator().manual_seed(2)
         dimg = (torch.randn(3, H, W, generator=g) * 1e-4).to(dev)
         a = backward_raw(s1, dimg, None, None, None)
+        torch.cuda.synchronize()
+        (sc_,) = RZ._SCRATCH.values()
+        nb = sc_.bins.nbins
+        assert int(sc_.bins.base[nb]) == records                          # the lists are exactly the counts ...
+        assert torch.equal(sc_.bins.cursor[:nb], sc_.bins.base[1:nb + 1])  # ... and K7 filled every overflow part to its end
         RZ.release_scratch()
         _, s2 = forward_raw(st, *args)
         s2.tensors["tex_bin_count"] = None                                   # no counts: every footprint through atomics
@@ -418,12 +437,12 @@ def test_block_reservations_tile_the_record_lists(lib_built):
         b = backward_raw(s2, dimg, None, None, None)
         torch.cuda.synchronize()
         r = Hh.rel_err(a[7], b[7])
-        Hh.report(f"texture_bins/reservations/{name}", rel_l2=r, entries=entries, widest_table=widest,
-                  records=int(s1.tensors["tex_bin_count"].sum()))
+        Hh.report(f"texture_bins/reservations/{name}", rel_l2=r, entries=entries, widest_table=widest, records=records,
+                  overflow_records=overflow)
         assert r < 1e-5, (name, r)
         assert Hh.rel_err(a[0], b[0]) < 1e-5 and Hh.rel_err(a[6], b[6]) < 1e-5
         if name == "coarse":
-            assert widest == 16                  # some block's table is full: the overflow path ran
+            assert overflow > records // 10          # the overflow path really ran
     RZ.release_scratch()
 
 

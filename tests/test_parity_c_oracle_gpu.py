@@ -50,36 +50,7 @@ def _run(name):
 @pytest.mark.parametrize("name", ["small", "c2", "c3"])
 def test_integer_stages_bit_exact(lib_built, name):
     scene, cam, bg, ref, outs, s = _run(name)
-    N = ref.N
-    t = s.tensors
-    assert np.array_equal(outs[4].cpu().numpy(), ref.radii[:N])
-    assert np.array_equal(t["tiles_touched"][:N].cpu().numpy().astype(np.uint32), ref.tiles[:N])
-    assert s.D == ref.D
-    vis = ref.radii[:N] > 0
-    rect = t["rect"][:N].cpu().numpy().astype(np.uint32)
-    got = np.stack([rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, rect[:, 1] >> 16], 1).astype(np.int32)
-    assert np.array_equal(got[vis], ref.rect[:N][vis])
-    depth = t["depth"][:N].cpu().numpy()
-    assert np.array_equal(depth[vis].view(np.uint32), ref.depth[:N][vis].view(np.uint32))     # sort-key bits
-    assert np.all(depth[~vis].view(np.uint32) == 0xFFFFFFFF)                                  # culled: after every visible one
-    D = ref.D
-    # K2 / K3 contract (include/texgs.h): Gaussians ranked by (depth bits, index) with culled ones last; offsets = exclusive
-    # scan of tiles_touched in rank order; instance k of the r-th ranked Gaussian = (tile << 32) | r at offsets[r] + k
-    key = np.where(vis, ref.depth[:N].view(np.uint32), np.uint32(0xFFFFFFFF)).astype(np.uint64)
-    order = np.argsort(key, kind="stable")
-    tt_rank = ref.tiles[:N][order].astype(np.int64)
-    offs_rank = np.cumsum(tt_rank) - tt_rank
-    assert np.array_equal(t["offsets"][:N].cpu().numpy().astype(np.uint32).astype(np.int64), offs_rank)
-    offs_idx = ref.offsets[:N].astype(np.int64) - ref.tiles[:N].astype(np.int64)               # lineage: exclusive, index order
-    src = np.repeat(offs_idx[order], tt_rank) + (np.arange(D) - np.repeat(offs_rank, tt_rank))
-    exp_unsorted = (ref.keys_unsorted[:D][src] & np.uint64(0xFFFFFFFF00000000)) | np.repeat(np.arange(N, dtype=np.uint64), tt_rank)
-    assert np.array_equal(t["keys_unsorted"][:D].cpu().numpy().view(np.uint64), exp_unsorted)
-    assert np.array_equal(t["keys_sorted"][:D].cpu().numpy().view(np.uint64), ref.keys_sorted[:D])
-    assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
-    assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
-    # the xy / conic part of the record that the tile rect came from is bit-identical too
-    rec = t["rec"][:N, :2].cpu().numpy()
-    assert np.array_equal(rec[vis].view(np.uint32), ref.rec[:N, :2][vis].view(np.uint32))
+    Hh.assert_integer_stages_bit_exact(ref, outs, s)
 
 
 @pytest.mark.parametrize("name", ["small", "c2", "c3"])
@@ -111,6 +82,14 @@ def test_backward_full_size_vs_c_oracle(lib_built, name):
     for name_, got in zip(names, res[:8]):
         Hh.grad_attributed(f"hip_vs_c32/{name}/bwd/{name_}", got.cpu(), torch.tensor(gref[name_]),
                            tflag if name_ == "texture" else gflag)
+    # the same gradients at PAIR level: every row checked, tolerance widened by what its own near-cell-edge pairs can contribute
+    Hh.pair_level_gradient_check(f"hip_vs_c32/{name}/bwd_pair_level", ref, res, dout, scene.texture.shape[1], sens)
+
+
+def test_band_limited_texture_c3(lib_built):
+    """C3 geometry, band-limited texture: no cell-edge excuses, flagged rows < 5 %, zero unexplained pixels / rows."""
+    scene, cam, bg, ref, outs, s = _run("c3")
+    Hh.band_limited_parity("hip_vs_c32/c3_band_limited", scene, cam, bg)
 
 
 def test_size_independent_properties_full_size(lib_built):
@@ -172,11 +151,14 @@ def test_stress_scene_vs_c_oracle(lib_built):
     assert s.D == D
     assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
     assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
+    # by attribution, like the benchmark scenes (VERDICT r4 #3c; until round 5: "2e-3 of the pixels over 1e-4, worst 2e-2").  Depth
+    # reaches ~8 scene units here (the benchmark sphere: 3.2, tolerance 4e-4): the same 1.25e-4 of the range.
+    R = scene.texture.shape[1]
+    margin, gflag, tflag = ref.ambiguity(tau_fwd=Hh.TAU_FWD, tau_cell=Hh.tau_cell(R), tau_relu=Hh.tau_relu(R))
     got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
-    err = (got - torch.tensor(ref.out)).abs()
-    scale = torch.ones(8, 1, 1); scale[3] = 10.0
-    assert float(((err > 1e-4 * scale).any(dim=0)).float().mean()) < 2e-3
-    assert float((err / scale).max()) < 2e-2
+    zmax = float(ref.out[3].max())
+    Hh.forward_attributed("hip_vs_c32/stress/fwd", got, ref, margin, depth_tol=1.25e-4 * max(zmax, 3.2),
+                          n_contrib=t["n_contrib"].cpu().numpy().astype(np.uint32), amb_frac_max=5e-3)
     H, W = cam.image_height, cam.image_width
     gen = torch.Generator().manual_seed(11)
     dout = torch.randn(8, H, W, generator=gen) / (H * W)
@@ -184,11 +166,13 @@ def test_stress_scene_vs_c_oracle(lib_built):
     res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(), dout[4:7].to(dev).contiguous(),
                        dout[7:8].to(dev).contiguous())
     gref = ref.backward(dout.numpy())
+    sens = ref.accumulation_sensitive()
+    Hh.report("hip_vs_c32/stress/bwd/accumulation_sensitive_rows", rows=int(sens.sum()), frac=float(sens.mean()))
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
         assert bool(torch.isfinite(got_g).all()), name_
-        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.005, global_rel=1e-2,
-                                label=f"hip_vs_c32/stress/bwd/{name_}")
-        assert ok, (name_, msg)
+        Hh.grad_attributed(f"hip_vs_c32/stress/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]),
+                           tflag if name_ == "texture" else (gflag | sens), flagged_frac_max=0.9)
+    Hh.pair_level_gradient_check("hip_vs_c32/stress/bwd_pair_level", ref, res, dout, R, sens)
 
 
 def test_more_than_65536_tiles_three_digit_tile_sort(lib_built):
@@ -211,11 +195,8 @@ def test_more_than_65536_tiles_three_digit_tile_sort(lib_built):
     assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
     assert int((ref.keys_sorted[:D] >> np.uint64(32)).max()) >= 65536          # the third digit is really exercised
     got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
-    err = (got - torch.tensor(ref.out)).abs()
-    scale = torch.ones(8, 1, 1); scale[3] = 4.0
-    Hh.report("hip_vs_c32/tiles66049/fwd", D=D, worst_pixel=float((err / scale).max()),
-              pixels_over_1e4th_frac=float((err > 1e-4 * scale).any(dim=0).float().mean()))
-    assert float((err > 1e-4 * scale).any(dim=0).float().mean()) < 3e-4 and float((err / scale).max()) < 5e-3
+    margin, _, _ = ref.ambiguity(tau_fwd=Hh.TAU_FWD, tau_cell=Hh.tau_cell(32), tau_relu=Hh.tau_relu(32))
+    Hh.forward_attributed("hip_vs_c32/tiles66049/fwd", got, ref, margin, n_contrib=t["n_contrib"].cpu().numpy().astype(np.uint32))
     from texgs import _lib
     import ctypes as C
     lib = _lib.load()
@@ -277,8 +258,10 @@ def test_depth_sort_with_crowded_depth_bins(lib_built, kind):
     assert np.array_equal(t["point_list"][:D].cpu().numpy().astype(np.uint32), ref.point_list[:D])
     assert np.array_equal(t["ranges"].cpu().numpy().astype(np.uint32), ref.ranges)
     got = torch.cat([outs[0], outs[1], outs[2], outs[3]], 0).cpu()
-    err = (got - torch.tensor(ref.out)).abs()
-    assert float(err[[0, 1, 2, 4, 5, 6, 7]].max()) < 2e-4 and float(err[3].max()) < 2e-3
+    margin, _, _ = ref.ambiguity(tau_fwd=Hh.TAU_FWD, tau_cell=Hh.tau_cell(32), tau_relu=Hh.tau_relu(32))
+    zmax = float(ref.out[3].max())                   # (far_outlier / two_clusters: a splat at depth 90)
+    Hh.forward_attributed(f"hip_vs_c32/crowded_{kind}/fwd", got, ref, margin, depth_tol=1.25e-4 * max(zmax, 3.2),
+                          n_contrib=t["n_contrib"].cpu().numpy().astype(np.uint32), amb_frac_max=5e-3)
 
 
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 200, 257, 1025, 2049, 4097])

@@ -287,6 +287,31 @@ def test_untextured_surface_with_cov3Ds_precomp(lib_built):
         assert ok, (name, msg)
 
 
+def test_bin_sort_render_forward_can_run_twice(lib_built):
+    """texgs_bin_sort_render_forward is a public staged entry point taking `const TexGSGeom*`; a second call on the same
+    K2 result (a retry with larger buffers, a K3-K6 timing loop) must give the same lists and image -- K3 reads the group-local
+    prefix from scratch and WRITES geom->offsets, it does not update it in place."""
+    import ctypes as C
+    from texgs import _lib
+    scene, cam, deg, bg = _scene(CASES[1])
+    outs, s = Hh.hip_debug_state(scene, cam, deg, bg)
+    t = s.tensors
+    before = {n: t[n].clone() for n in ("offsets", "keys_unsorted", "keys_sorted", "point_list", "ranges", "tile_order")}
+    img0 = [o.clone() for o in outs[:4]]
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        _lib.check(lib.texgs_bin_sort_render_forward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin),
+                                                     C.byref(s.img), stream), "texgs_bin_sort_render_forward (again)")
+    torch.cuda.synchronize()
+    D = s.D
+    for n, v in before.items():
+        k = D if n in ("keys_unsorted", "keys_sorted", "point_list") else v.shape[0]
+        assert torch.equal(t[n][:k], v[:k]), n
+    for a, b in zip(outs[:4], img0):
+        assert torch.equal(a, b)
+
+
 def test_fused_grad_sink_equals_autograd_accumulation(lib_built):
     """texgs.multiview fused accumulation (kernels add into the bucket) == plain autograd accumulation over 3 views."""
     from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer

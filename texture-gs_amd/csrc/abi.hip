@@ -182,7 +182,7 @@ static int render_forward_impl(const TexGSFrame* frame, const TexGSInputs* in, c
     hipStream_t s = (hipStream_t)stream;
     const CamConst c = make_cam(frame);
     if (img->tex_bin_count && in->texture && !counters_zeroed) {       // K6 counts the texture-gradient footprints per bin into it
-        hipError_t e = hipMemsetAsync(img->tex_bin_count, 0, sizeof(uint32_t) * tex_bin_count(c.R), s);
+        hipError_t e = hipMemsetAsync(img->tex_bin_count, 0, sizeof(uint32_t) * 2 * tex_bin_count(c.R), s);
         if (e != hipSuccess) return fail("tex_bin_count memset", e);
     }
     { ProfScope p(TEXGS_K_RENDER_FWD, s); launch_render_fwd(c, frame, in, geom, bin, img, s); }
@@ -210,7 +210,7 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     }
     // (the one-workgroup tile-order kernel also zero-fills the per-bin footprint counters K6 adds into)
     { ProfScope p(TEXGS_K_RANGES, s);
-      launch_ranges(c, bin, img->tex_bin_count, img->tex_bin_count ? (int)tex_bin_count(c.R) : 0, s); }
+      launch_ranges(c, bin, img->tex_bin_count, img->tex_bin_count ? 2 * (int)tex_bin_count(c.R) : 0, s); }
     if (int r = check(frame, s, "tile_ranges")) return r;
     return render_forward_impl(frame, in, geom, bin, img, stream, true);
 }

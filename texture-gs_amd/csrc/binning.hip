@@ -216,7 +216,7 @@ k_radix_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ va
 //                    Gaussians, i.e. 1/NB of the depth range does; one wave, slow, correct); tiles_touched is gathered in that
 //                    order and scanned inside the group;
 //                    K3 scans the groups' tile sums (every workgroup, redundantly) and adds a rank's group prefix when it reads
-//                    its offset (and writes it back: geom->offsets is an output of the contract).
+//                    its group-local offset from scratch (and writes the sum to geom->offsets, an output of the contract).
 // (Tried and dropped, profiles/r04_ablation.md: equal-width sort units; one wave per unit; the scans done by "the last block to
 //  finish" -- a ticket word takes 13 ns per workgroup, same address.)
 constexpr int DS_NB_MAX = 8192;        // depth bins (+ 1 for culled Gaussians)
@@ -655,15 +655,16 @@ k_depth_prefix(const uint32_t* __restrict__ drange, uint32_t* __restrict__ bsum)
 }
 
 // K3: one thread per depth rank; emits that Gaussian's instances, element = (tile << 32) | rank, at offs_rank[rank]...
-// offs_rank[rank] arrives as the prefix INSIDE the rank's sort group (k_depth_group_sort); the group's own prefix (scan of bsum) is added here
-// and the sum written back (geom->offsets = exclusive scan of tiles_touched in rank order is an output of the contract).
+// loc_rank[rank] is the prefix INSIDE the rank's sort group (k_depth_group_sort, scratch); the group's own prefix (scan of bsum) is
+// added here and the sum written to offs_rank (geom->offsets = exclusive scan of tiles_touched in rank order is an output of the
+// contract).  Reads only what K2 left and writes only outputs: running K3 again on the same K2 result gives the same result.
 // Also zero-fills `ranges` (empty tiles keep (0, 0); k_ranges runs later on the same stream).
 // PRE: `bsum` already holds the exclusive scan of the groups' tile sums (k_depth_prefix: large N, where every workgroup redoing
 // the scan is N^2 / 40 960 loads) -- otherwise the workgroup scans the <= 2 049 sums itself (cheaper than a launch).
 template <bool PRE>
 __global__ void __launch_bounds__(TG_BLOCK)
 k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, const uint32_t* __restrict__ key_rank,
-            uint32_t* __restrict__ offs_rank, const uint32_t* __restrict__ drange, const uint32_t* __restrict__ gmap, const uint32_t* __restrict__ bsum,
+            const uint32_t* __restrict__ loc_rank, uint32_t* __restrict__ offs_rank, const uint32_t* __restrict__ drange, const uint32_t* __restrict__ gmap, const uint32_t* __restrict__ bsum,
             const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, uint64_t* __restrict__ elems,
             uint2* __restrict__ ranges, uint32_t* __restrict__ zero_words, int num_zero_words) {
     __shared__ uint32_t s_pre[PRE ? 1 : DS_FUSED_GROUPS + 1];
@@ -673,7 +674,7 @@ k_duplicate(int N, int tiles_x, int T, const uint32_t* __restrict__ id_rank, con
     for (int k = r; k < num_zero_words; k += (int)gridDim.x * TG_BLOCK) zero_words[k] = 0u;      // group count tables of the tile sort
     const uint32_t d_lo = drange[DR_LO], d_scale = drange[DR_SCALE], d_nb = drange[DR_NB];
     uint32_t my_group = 0u, my_off = 0u;                // issued ahead of the scan below: key -> bin -> group is two dependent loads
-    if (r < N) { my_group = gmap[depth_bin(key_rank[r], d_lo, d_scale, d_nb)]; my_off = offs_rank[r]; }
+    if (r < N) { my_group = gmap[depth_bin(key_rank[r], d_lo, d_scale, d_nb)]; my_off = loc_rank[r]; }
     uint32_t my_pre = 0u;
     if constexpr (PRE) {
         if (r < N) my_pre = bsum[my_group];
@@ -779,6 +780,8 @@ struct GaussScratch {
     uint32_t* block_D;      // [5][ceil(N / 256)] K1's per-workgroup sums of tiles_touched, fingerprint lo, hi, min / max valid depth key
     unsigned long long* pair_a;     // [N] (key << 32 | index) partitioned into depth bins
     uint32_t *key_b, *val_b;       // [N] depth bits / Gaussian index in rank order
+    uint32_t *loc_b;               // [N] exclusive scan of tiles_touched in rank order INSIDE the rank's sort group (K2); K3 adds the
+                                   // group's prefix and writes geom->offsets -- from this read-only source, so K3 can run again
     size_t header_bytes;
 };
 inline size_t zero_header_bytes(int passes, size_t extra) { return align256((size_t)passes * RS_ZERO_WORDS * 4 + extra); }
@@ -797,6 +800,7 @@ inline GaussScratch gauss_scratch(void* base, int N) {
     g.pair_a = (unsigned long long*)p; p += 2 * nb;
     g.key_b = (uint32_t*)p; p += nb;
     g.val_b = (uint32_t*)p; p += nb;
+    g.loc_b = (uint32_t*)p; p += nb;
     g.block_D = (uint32_t*)p;
     return g;
 }
@@ -819,7 +823,7 @@ inline void pass_geometry(uint32_t n, uint32_t& blocks, uint32_t& per) {
 size_t scan_temp_bytes(int N) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     return depth_header_bytes() + align256((size_t)(DS_NB_MAX + 2) * 4) + 2 * align256((size_t)(DS_NB_MAX + 1) * 4) + 256
-         + 4 * align256(n * 4) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * (size_t)DS_BLK_WORDS * 4);
+         + 5 * align256(n * 4) + align256(((n + TG_BLOCK - 1) / TG_BLOCK) * (size_t)DS_BLK_WORDS * 4);
 }
 
 constexpr int TILE_PASSES_MAX = 3;      // tile ids up to 2^24 in digits of at most 8 bits (the count / scatter kernels index 256-entry LDS tables)
@@ -840,8 +844,8 @@ uint32_t* bin_header_ptr(const TexGSGeom* g, int N, int* words) {       // bin t
 
 // Gaussian level: depth sort + exclusive scan of tiles_touched in rank order (three launches, see above).  Needs K1's depth keys
 // (bits of view z; 0xFFFFFFFF for culled) in g->depth and its per-workgroup (min, max).  Independent of D: runs while the host
-// waits for the D readback.  Result: (key_b, val_b) = depth bits / Gaussian index in rank order; g->offsets = the prefix inside
-// each rank's sort group, completed by K3 with the scan of the groups' tile sums.
+// waits for the D readback.  Result (all in scan_temp): (key_b, val_b) = depth bits / Gaussian index in rank order, loc_b = the
+// prefix inside each rank's sort group; K3 completes it with the scan of the groups' tile sums and writes g->offsets.
 int launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s) {
     if (N <= 0) return 0;
     const GaussScratch gs = gauss_scratch(g->scan_temp, N);
@@ -855,7 +859,7 @@ int launch_depth_sort_scan(const TexGSGeom* g, int N, hipStream_t s) {
                        (const uint32_t*)gs.btot, gs.bcur, gs.gpos, gs.gmap, gs.drange, gs.pair_a);
     hipLaunchKernelGGL(k_depth_group_sort, dim3(gmax + (N + (int)DS_COPY - 1) / (int)DS_COPY), dim3(DS_THREADS), 0, s, N,
                        (const uint32_t*)gs.gpos, (const uint32_t*)gs.drange, gs.pair_a, gs.key_b, gs.val_b,
-                       (const uint32_t*)g->tiles_touched, g->offsets, gs.bsum, gmax);
+                       (const uint32_t*)g->tiles_touched, gs.loc_b, gs.bsum, gmax);
     if (gmax > DS_FUSED_GROUPS) hipLaunchKernelGGL(k_depth_prefix, dim3(1), dim3(1024), 0, s, (const uint32_t*)gs.drange, gs.bsum);
     hipError_t e = hipGetLastError();
     return (int)e;
@@ -867,7 +871,7 @@ void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hi
     const int blocks = (c.N + TG_BLOCK - 1) / TG_BLOCK;
     const bool pre = depth_max_groups(c.N, 1 << depth_log2_bins(c.N)) > DS_FUSED_GROUPS;       // (launch_depth_sort_scan ran k_depth_prefix)
 #define K3_LAUNCH(PRE) hipLaunchKernelGGL(k_duplicate<PRE>, dim3(blocks), dim3(TG_BLOCK), 0, s, c.N, c.tiles_x, c.tiles_x * c.tiles_y, (const uint32_t*)gs.val_b, \
-                       (const uint32_t*)gs.key_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.gmap, (const uint32_t*)gs.bsum, \
+                       (const uint32_t*)gs.key_b, (const uint32_t*)gs.loc_b, g->offsets, (const uint32_t*)gs.drange, (const uint32_t*)gs.gmap, (const uint32_t*)gs.bsum, \
                        (const uint32_t*)g->tiles_touched, reinterpret_cast<const uint2*>(g->rect), b->keys_unsorted, reinterpret_cast<uint2*>(b->ranges), \
                        reinterpret_cast<uint32_t*>(b->sort_temp), (int)(zero_header_bytes(TILE_PASSES_MAX, 0) / 4))
     if (pre) K3_LAUNCH(true); else K3_LAUNCH(false);

@@ -131,7 +131,7 @@ struct PixArgs {
     uint2*    surv;          // {Gaussian id, list position}
     uint16_t* surv_qm;       // bit q: the survivor can reach quadrant q
     uint32_t* surv_cnt;      // [4 * tiles] survivors written per block
-    uint32_t* resv;          // [4 * tiles][3][TG_RESV] per-block reservation table {bin | offset inside the bin's list | count} (NULL: no binned texture gradient)
+    uint32_t* resv;          // [4 * tiles][3][64] per-block reservation table {bin | offset inside the bin's list | count} (NULL: no binned texture gradient)
 };
 
 // workgroup (= one wave) -> (tile, 8x8 block).  Tiles are launched longest-list-first (tile_order).  The four blocks of a
@@ -158,38 +158,30 @@ __device__ __forceinline__ int mbcnt64(ull m) {
 // border: such footprints go straight to dL_dtexture).  K6 counts with this, K7 appends with this: same inputs, same answer.
 __device__ __forceinline__ uint32_t tap_bin(const CubeTap& ct, int nb) { return (uint32_t)((ct.face * nb + (ct.y0 >> 5)) * nb + (ct.x0 >> 5)); }
 __device__ __forceinline__ bool tap_binned(const CubeTap& ct) { return ct.dox != 0u && ct.doy != 0u; }
-// Per-block RESERVATION table (K6 -> K7): the texture bins an 8x8 block's footprints fall into (a surface patch seen through 64
-// pixels covers a handful of 32x32-texel bins), open addressing with linear probing, never flushed.  The home slot keeps the 4x4
-// neighbourhood of bins of one face apart.  K6 counts per entry and, at block end, takes the block's range of every bin's record
-// list with ONE returning atomic per entry; K7 reads the table back and hands out slots with an LDS atomic -- no grouping, no
-// global cursor.  A bin that does not fit the table is neither counted nor reserved: K7 sends those footprints to dL_dtexture
-// directly (still correct).
-#define TG_RESV 16
+// Per-block RESERVATION table (K6 -> K7), round 5.  The bilinear footprints of an 8x8 pixel block fall into 11 texture bins at
+// the median and up to ~45 (C3; measured with oracle/texgs_ref.c texgs_ref_block_bin_stats: front and back shell, needle-shaped
+// splats whose Taylor term sweeps the cube face) -- a DIRECT-MAPPED table of 64 entries indexed by the low bits of the bin's (x, y)
+// inside the face holds 97.8 % of the footprints (16 entries: 87 %, 32: 96 %), the first bin to arrive owns a slot.  K6 counts per
+// entry and, at block end, takes the block's range of every owned bin's record list with ONE returning atomic per entry; K7 reads
+// the table back and hands out slots with one LDS atomic per lane -- no grouping loop, no global cursor.  Footprints whose slot
+// belongs to another bin take the round-4 path: counted per (round, bin) by a global atomic in K6, appended behind the reserved
+// part of the list through a global cursor in K7.  The bins live in the spare fourth word of plane B (entries 0..63 of
+// Planes::B[].w: LDS the layout had and did not use), the counts as packed 16-bit pairs: not one byte of LDS more than round 4.
+// (A count beyond 65 535 wraps into its neighbour: the reservation is then too small / too large by that much, K7 sends what does
+// not fit to dL_dtexture directly and zero-fills what stays empty -- slower, still exact.)
+#define TG_RESV 64
 #define TG_RESV_EMPTY 0xFFFFFFFFu
-__device__ __forceinline__ int tap_home(const CubeTap& ct) { return ((ct.x0 >> 5) & 3) | (((ct.y0 >> 5) & 3) << 2); }
-// lane-parallel lookup of `bin` from its home slot `h`: the entry that holds it, or -1 (walk ended on an empty slot / table full).
-// Almost always decided by the first read; the walk runs only while some lane of the wave sits on a foreign entry.
-__device__ __forceinline__ int resv_find(const uint32_t* tbin, bool want, uint32_t bin, int h) {
-    uint32_t e = tbin[h];
-    int found = (want && e == bin) ? h : -1;
-    bool walk = want && e != bin && e != TG_RESV_EMPTY;
-    for (int p = 1; p < TG_RESV && __builtin_amdgcn_ballot_w64(walk) != 0ull; ++p) {
-        if (walk) {
-            h = (h + 1) & (TG_RESV - 1);
-            e = tbin[h];
-            if (e == bin) { found = h; walk = false; }
-            else if (e == TG_RESV_EMPTY) walk = false;
-        }
-    }
-    return found;
-}
+#define TG_SLOT_NONE 0xFFFFFFFFu
+#define TG_SLOT_OVF  0x80000000u          // | leader lane << 8 | rank: an overflow footprint's slot, resolved in the back half
+__device__ __forceinline__ int tap_home(const CubeTap& ct) { return ((ct.x0 >> 5) & 7) | (((ct.y0 >> 5) & 7) << 3); }
+template <class P> __device__ __forceinline__ uint32_t& resv_bin(P& p, int h) { return reinterpret_cast<uint32_t*>(&p.B[h])[3]; }
 
 // ---- per-wave LDS layout shared by K6 and K7 ----
 #define TG_RING 128          // survivor queue (raw list positions), power of two >= 127
 #define TG_DUMMY 64          // plane slot of the all-zero dummy survivor (alpha 0: never contributes); list padding points here
 struct Planes {              // the chunk's 64 survivors, plane-major [field group][survivor]: row-broadcast reads are conflict-free
     float4 A[65];            // xy, ah, bh                      (test)
-    float4 B[65];            // ch, opacity, list position, -    (test)
+    float4 B[65];            // ch, opacity, list position, [.w of entries 0..63: the block's reservation table, resv_bin()]    (test)
     float4 C[65];            // depth, normal                    (K6 blend, K7 stage B)
     float4 D[65];            // g, G0, G1                        (dense phase)
     float4 E[65];            // G2..G5
@@ -221,7 +213,7 @@ __device__ __forceinline__ void load_chunk(const PixArgs& a, Planes& P, int lane
         T0 = tp[0]; T1 = tp[1]; S0 = sp[0]; S1 = sp[1]; S2 = sp[2]; S3 = sp[3]; S4 = sp[4];
     }
     P.A[lane] = T0;
-    P.B[lane] = make_float4(T1.x, T1.y, __uint_as_float(pos), 0.f);
+    { float* pb = reinterpret_cast<float*>(&P.B[lane]); pb[0] = T1.x; pb[1] = T1.y; pb[2] = __uint_as_float(pos); }   // (.w: the reservation table)
     P.C[lane] = make_float4(S3.z, S3.w, S4.x, S4.y);
     P.D[lane] = S0; P.E[lane] = S1; P.F[lane] = S2;
     P.G[lane] = make_float2(S3.x, S3.y);
@@ -245,7 +237,7 @@ struct __attribute__((aligned(16))) FwdLds {
     ull col[64 * 3];                    // 1536: Q32.32 colour sums of the wave's pixels
     uint32_t ring[TG_RING];             //  512
     uint8_t list[4][64];                //  256: per-quadrant survivor lists, padded with TG_DUMMY
-    uint32_t cbin[TG_RESV], ccnt[TG_RESV];   // 128: the block's reservation table: texture bin, footprints counted
+    uint32_t ccnt[TG_RESV / 2];         //  128: footprints counted per reservation entry, two 16-bit counts per word (the bins: p.B[].w)
 };                                      // 10224 B -> 16 waves per CU
 
 // TAPS = false: the untextured surface (TexGSInputs.texture == NULL; render/render.py:75-84 through `diff_gauss`): the colour of a
@@ -275,7 +267,8 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     const int nbins_row = (a.R + 31) >> 5;
 
     L.col[lane * 3 + 0] = 0ull; L.col[lane * 3 + 1] = 0ull; L.col[lane * 3 + 2] = 0ull;   // own pixel; only this wave touches it
-    if (lane < TG_RESV) { L.cbin[lane] = TG_RESV_EMPTY; L.ccnt[lane] = 0u; }
+    resv_bin(L.p, lane) = TG_RESV_EMPTY;
+    if (lane < TG_RESV / 2) L.ccnt[lane] = 0u;
     init_dummy(L.p, lane);
     __builtin_amdgcn_wave_barrier();
 
@@ -337,28 +330,28 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             p_fx = ct.fx; p_fy = ct.fy;
             if (bin_count != nullptr) {
                 // a backward will follow: count this round's footprints per texture bin in the block's reservation table (sizes of
-                // K7's record lists).  Hit: ONE integer LDS atomic per lane.  First touch of a bin: the lanes are grouped by bin
-                // with ballots and the group leader claims the first free entry on the bin's probe path (a few times per block).
+                // K7's record lists).  Hit: ONE integer LDS atomic per lane.  Otherwise the lanes are grouped by bin with ballots:
+                // the first bin to arrive at a free entry claims it (a dozen times per block); a bin whose entry belongs to another
+                // one is counted on the global overflow counter, one atomic per (round, bin) -- 2 % of the footprints.
                 const bool binned = (lane < n_) && tap_binned(ct);
                 const uint32_t bin = tap_bin(ct, nbins_row);
                 const int home = tap_home(ct);
-                const int ce = resv_find(L.cbin, binned, bin, home);
-                if (ce >= 0) atomicAdd(&L.ccnt[ce], 1u);
-                ull pend = TG_BALLOT(binned) & ~TG_BALLOT(ce >= 0);
+                const bool hit = binned && resv_bin(L.p, home) == bin;
+                if (hit) atomicAdd(&L.ccnt[home >> 1], 1u << ((home & 1) << 4));
+                ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
                     const int h0 = __builtin_amdgcn_readlane(home, l0);
                     const ull m = pend & TG_BALLOT(bin == b0);
-                    int f = -1;                             // wave-uniform walk (broadcast reads)
-                    for (int p = 0; p < TG_RESV; ++p) {
-                        const int hh = (h0 + p) & (TG_RESV - 1);
-                        const uint32_t ee = L.cbin[hh];
-                        if (ee == b0 || ee == TG_RESV_EMPTY) { f = hh; break; }
+                    const uint32_t e0 = resv_bin(L.p, h0);          // (wave-uniform address: a broadcast read)
+                    if (lane == l0) {
+                        const uint32_t n = (uint32_t)__popcll(m);
+                        if (e0 == TG_RESV_EMPTY) { resv_bin(L.p, h0) = b0; atomicAdd(&L.ccnt[h0 >> 1], n << ((h0 & 1) << 4)); }
+                        else atomicAdd(bin_count + 6 * nbins_row * nbins_row + b0, n);
                     }
-                    if (f >= 0 && lane == l0) { L.cbin[f] = b0; L.ccnt[f] += (uint32_t)__popcll(m); }
-                    __builtin_amdgcn_wave_barrier();        // (the next group's walk must see this entry)
-                    pend &= ~m;                             // table full: these footprints stay uncounted, K7 scatters them itself
+                    __builtin_amdgcn_wave_barrier();                // (the next group's read must see a claimed entry)
+                    pend &= ~m;
                 }
             }
         }
@@ -488,10 +481,10 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     }
     finish();
     __builtin_amdgcn_wave_barrier();
-    if (TAPS && bin_count != nullptr && lane < TG_RESV) {
+    if (TAPS && bin_count != nullptr) {
         // reserve: this block's footprints of bin b occupy [off, off + n) of b's record list (offsets inside the list: the lists'
-        // bases are known only after k_bin_offsets has scanned the totals this very atomic builds)
-        const uint32_t b = L.cbin[lane], n = L.ccnt[lane];
+        // bases are known only after k_bin_offsets has scanned the totals this very atomic builds); lane = table entry
+        const uint32_t b = resv_bin(L.p, lane), n = (L.ccnt[lane >> 1] >> ((lane & 1) << 4)) & 0xFFFFu;
         uint32_t off = 0u;
         if (b != TG_RESV_EMPTY) off = atomicAdd(bin_count + b, n);
         uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
@@ -537,14 +530,10 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 #ifndef K7_WAVES_PER_SIMD
 #define K7_WAVES_PER_SIMD 2
 #endif
-// K7_SLOT_BALLOT (experiment): record slots by grouping the lanes per table entry with ballots instead of a returning LDS atomic
-#ifndef K7_SLOT_BALLOT
-#define K7_SLOT_BALLOT 0
-#endif
 #define BWD_MAX_IT 16
 struct TexBinArgs {
     float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
-    uint32_t* cursor;      // [nbins + 2]: only the two status words behind the (since v12 unused) per-bin part are live
+    uint32_t* cursor;      // [nbins] next free record of each list's OVERFLOW part, absolute (k_bin_offsets sets it to the end of the reserved part)
     const uint32_t* base;  // [nbins + 1] exclusive scan of K6's per-bin counts
     const uint32_t* order; // [nbins] the reduce kernel's launch order: bins by falling list length (k_bin_offsets)
     uint32_t* stats;       // [0] max records a call wanted (for the host), [1] bits of max |dL/dpixel colour| of this call
@@ -565,8 +554,8 @@ struct __attribute__((aligned(16))) BwdLds {
     float4 dgeo[64];                    // 1024: dL/d(depth, normal)
     uint32_t task[64];                  //  256
     uint8_t list[4][64];                //  256
-    uint32_t tbin[TG_RESV], tpos[TG_RESV], tend[TG_RESV];   // 192: the block's reservations: bin, next free record (absolute), end of the range
-};                                      // 17760 B -> 9 waves per CU
+    uint32_t tpos[TG_RESV], tend[TG_RESV];   // 512: the block's reservations: next free record (absolute), end of the range (the bins: p.B[].w)
+};                                      // 18080 B -> 9 waves per CU
 
 // footprints that cannot be binned (clamped at a face border, beyond the buffer): straight into dL_dtexture.  Offsets in BYTES.
 __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_t o00, uint32_t dox, uint32_t doy, float fx, float fy,
@@ -647,16 +636,15 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             atomicMax(tb.stats + 1, (uint32_t)mbits);
     }
     if constexpr (TEX) {
-        // the block's reservations (K6 left {bin, offset inside the bin's list, count}; k_bin_offsets has since scanned the totals)
-        if (lane < TG_RESV) {
-            uint32_t b = TG_RESV_EMPTY, p0 = 0u, n = 0u;
-            if (tb.rec != nullptr) {
-                const uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
-                b = rv[lane];
-                if (b != TG_RESV_EMPTY) { p0 = tb.base[b] + rv[TG_RESV + lane]; n = rv[2 * TG_RESV + lane]; }
-            }
-            L.tbin[lane] = b; L.tpos[lane] = p0; L.tend[lane] = p0 + n;
+        // the block's reservations (K6 left {bin, offset inside the bin's list, count} per table entry; k_bin_offsets has since
+        // scanned the totals); lane = table entry
+        uint32_t b = TG_RESV_EMPTY, p0 = 0u, n = 0u;
+        if (tb.rec != nullptr) {
+            const uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
+            b = rv[lane];
+            if (b != TG_RESV_EMPTY) { p0 = tb.base[b] + rv[TG_RESV + lane]; n = rv[2 * TG_RESV + lane]; }
         }
+        resv_bin(L.p, lane) = b; L.tpos[lane] = p0; L.tend[lane] = p0 + n;
     }
     // last contributor of each quadrant (row maximum) and of the block
     int rl = last;
@@ -686,7 +674,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         bool have;
         int e, pl, jj, axis;
         uint32_t key;
-        uint32_t slot;                                    // the item's record slot (absolute), 0xFFFFFFFF: none (not binned / no room)
+        uint32_t slot;                                    // the item's record slot (absolute); TG_SLOT_NONE: none (not binned / no room);
+                                                          // TG_SLOT_OVF | leader << 8 | rank: an overflow footprint (see front_b)
+        uint32_t ovf0, ovf1;                              // group leaders of overflow footprints: first slot of the group, end of the list
         uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
         uint32_t o00, dox, doy;                           // tap byte offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
         float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
@@ -763,30 +753,28 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
                 R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
                 R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
-                // slot in the texture bin's record list: the block's reservation of that bin (K6 counted exactly these footprints),
-                // taken with one returning LDS atomic per lane
+                // slot in the texture bin's record list: from the block's reservation of that bin (K6 counted exactly these
+                // footprints), one returning LDS atomic per lane.  A footprint whose table entry belongs to another bin (2 %) goes
+                // behind the reserved part of the list: lanes grouped by bin, one returning GLOBAL atomic per group on the bin's
+                // overflow cursor, resolved in the back half (the round-4 path).
                 const bool binned = R.have && tb.rec != nullptr && tap_binned(ct);
-                const int te = resv_find(L.tbin, binned, tap_bin(ct, tb.nb), tap_home(ct));
-                R.slot = 0xFFFFFFFFu;
-#if K7_SLOT_BALLOT
-                ull pend = TG_BALLOT(te >= 0);
+                const uint32_t bin = tap_bin(ct, tb.nb);
+                const int home = tap_home(ct);
+                const bool hit = binned && resv_bin(L.p, home) == bin;
+                R.slot = TG_SLOT_NONE; R.ovf0 = 0u; R.ovf1 = 0u;
+                if (hit) {
+                    const uint32_t pos = atomicAdd(&L.tpos[home], 1u);
+                    if (pos < L.tend[home]) R.slot = pos;
+                }
+                ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;
-                    const int t0 = __builtin_amdgcn_readlane(te, l0);
-                    const ull m = pend & TG_BALLOT(te == t0);
-                    const uint32_t p0 = L.tpos[t0], p1 = L.tend[t0];
-                    if ((m >> lane) & 1ull) { const uint32_t pos = p0 + (uint32_t)mbcnt64(m); if (pos < p1) R.slot = pos; }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == l0) L.tpos[t0] = p0 + (uint32_t)__popcll(m);
-                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, l0);
+                    const ull m = pend & TG_BALLOT(bin == b0);
+                    if ((m >> lane) & 1ull) R.slot = TG_SLOT_OVF | ((uint32_t)l0 << 8) | (uint32_t)mbcnt64(m);
+                    if (lane == l0) { R.ovf0 = atomicAdd(tb.cursor + b0, (uint32_t)__popcll(m)); R.ovf1 = tb.base[b0 + 1u]; }
                     pend &= ~m;
                 }
-#else
-                if (te >= 0) {
-                    const uint32_t pos = atomicAdd(&L.tpos[te], 1u);
-                    if (pos < L.tend[te]) R.slot = pos;
-                }
-#endif
             }
         }
     };
@@ -846,8 +834,16 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         if constexpr (TEX) {
             // texture gradient of this pair: append the record, or straight to dL_dtexture when the footprint is clamped at
             // a face border / does not fit the buffer (still correct, just slow)
-            if (R.slot < tb.cap) {
-                float* __restrict__ rp = tb.rec + R.slot;
+            uint32_t slot = R.slot;
+            const bool ovf = (slot & TG_SLOT_OVF) != 0u && slot != TG_SLOT_NONE;
+            if (TG_BALLOT(ovf) != 0ull) {                 // (wave-uniform: most rounds have no overflow footprint)
+                const int ldr = (int)((slot >> 8) & 63u) << 2;
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ldr, (int)R.ovf0);
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ldr, (int)R.ovf1);
+                if (ovf) { const uint32_t pos = p0 + (slot & 63u); slot = (pos < p1) ? pos : TG_SLOT_NONE; }
+            }
+            if (slot < tb.cap) {
+                float* __restrict__ rp = tb.rec + slot;
                 rp[0] = __uint_as_float(R.fxw); rp[tb.cap] = __uint_as_float(R.fyw);
                 rp[2 * (size_t)tb.cap] = x0; rp[3 * (size_t)tb.cap] = x1; rp[4 * (size_t)tb.cap] = x2;
             } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
@@ -870,7 +866,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             float4 T0 = make_float4(0.f, 0.f, 0.f, 0.f), T1 = make_float4(0.f, 0.f, -1.f, 1.f);
             if (live) { const float4* __restrict__ tp = a.rec_test + 2 * (size_t)id; T0 = tp[0]; T1 = tp[1]; }
             L.p.A[lane] = T0;
-            L.p.B[lane] = make_float4(T1.x, T1.y, __uint_as_float(pos), 0.f);
+            float* pb = reinterpret_cast<float*>(&L.p.B[lane]); pb[0] = T1.x; pb[1] = T1.y; pb[2] = __uint_as_float(pos);
         }
 #else
         float4 T0, T1;
@@ -1065,21 +1061,21 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         // A reservation this block did not use up -- impossible while K6 and K7 agree on every footprint (same decisions, same uv
         // arithmetic); should they ever not, the reduce must not sum whatever an earlier call left in the unused slots.
         __builtin_amdgcn_wave_barrier();
-        if (lane < TG_RESV) {
-            const uint32_t q1 = min(L.tend[lane], tb.cap);
-            for (uint32_t q = L.tpos[lane]; q < q1; ++q) {
-                float* __restrict__ rp = tb.rec + q;
-                rp[0] = 0.f; rp[tb.cap] = 0.f; rp[2 * (size_t)tb.cap] = 0.f; rp[3 * (size_t)tb.cap] = 0.f; rp[4 * (size_t)tb.cap] = 0.f;
-            }
+        const uint32_t q1 = min(L.tend[lane], tb.cap);
+        for (uint32_t q = L.tpos[lane]; q < q1; ++q) {
+            float* __restrict__ rp = tb.rec + q;
+            rp[0] = 0.f; rp[tb.cap] = 0.f; rp[2 * (size_t)tb.cap] = 0.f; rp[3 * (size_t)tb.cap] = 0.f; rp[4 * (size_t)tb.cap] = 0.f;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ texture-gradient lists
-// Exclusive scan of K6's per-bin footprint counts -> list offsets (K7 adds them to its blocks' reservations, which K6 made
-// relative to the start of each list) (one workgroup; nbins = 6144 at R = 1024).
+// Exclusive scan of K6's per-bin footprint counts -> list offsets (one workgroup; nbins = 6144 at R = 1024).  count[b] = the
+// footprints the blocks RESERVED in bin b's list (K7 adds base[b] to its blocks' reservations, which K6 made relative to the start
+// of the list), count[nbins + b] = the overflow footprints, appended behind them through cursor[b] (absolute, starts at the end of
+// the reserved part).
 __global__ void __launch_bounds__(1024)
-k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base,
+k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restrict__ base, uint32_t* __restrict__ cursor,
               uint32_t* __restrict__ order, uint32_t* __restrict__ stats) {
     // one pass: thread t owns the `per` consecutive counts [t * per, (t + 1) * per) -- serial inside the thread, one wave scan,
     // one cross-wave step (6 144 bins at R = 1024: 6 per thread).  Chunks of 1 024 x BO_MAX bins if there are more.
@@ -1096,7 +1092,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
         uint32_t v[BO_MAX];
         uint32_t sum = 0u;
 #pragma unroll
-        for (int k = 0; k < BO_MAX; ++k) { v[k] = (k < per && i0 + k < c0 + n) ? count[i0 + k] : 0u; sum += v[k]; }
+        for (int k = 0; k < BO_MAX; ++k) { v[k] = (k < per && i0 + k < c0 + n) ? count[i0 + k] + count[nbins + i0 + k] : 0u; sum += v[k]; }
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
@@ -1105,7 +1101,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
         uint32_t run = s_carry + incl - sum;
         for (int w = 0; w < wv; ++w) run += s_w[w];
 #pragma unroll
-        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) base[i0 + k] = run; run += v[k]; }
+        for (int k = 0; k < BO_MAX; ++k) { if (k < per && i0 + k < c0 + n) { base[i0 + k] = run; cursor[i0 + k] = run + count[i0 + k]; } run += v[k]; }
         __syncthreads();
         if (tid == 1023) s_carry = run;
         __syncthreads();
@@ -1127,7 +1123,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
     };
     s_cnt[tid] = 0u;
     __syncthreads();
-    for (int i = tid; i < nbins; i += 1024) atomicAdd(&s_cnt[length_class(count[i])], 1u);
+    for (int i = tid; i < nbins; i += 1024) atomicAdd(&s_cnt[length_class(count[i] + count[nbins + i])], 1u);
     __syncthreads();
     {
         const uint32_t c = s_cnt[tid];
@@ -1141,7 +1137,7 @@ k_bin_offsets(int nbins, const uint32_t* __restrict__ count, uint32_t* __restric
         s_cnt[tid] = run;
     }
     __syncthreads();
-    for (int i = tid; i < nbins; i += 1024) order[atomicAdd(&s_cnt[length_class(count[i])], 1u)] = (uint32_t)i;
+    for (int i = tid; i < nbins; i += 1024) order[atomicAdd(&s_cnt[length_class(count[i] + count[nbins + i])], 1u)] = (uint32_t)i;
 }
 
 // One workgroup per 32x32-texel bin: sum the bin's records into a 33x33-texel LDS tile (footprints anchored in the bin
@@ -1164,7 +1160,8 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     __shared__ long long s_tile[TB_EDGE * TB_ROW * 3];           // [row][col (padded)][channel], 2^42-scaled fixed point
     const int b = (int)tb.order[blockIdx.x], tid = (int)threadIdx.x;
     const uint32_t b0 = tb.base[b], b1 = tb.base[b + 1];
-    const uint32_t filled = b1 - b0;                             // every slot of a list is reserved by exactly one block of K7, which fills it
+    const uint32_t filled = tb.cursor[b] - b0;                   // the reserved part (every slot has an owner block, which fills it) + what K7
+                                                               // appended behind it (the cursor is absolute and started at the end of the reserved part)
     if (filled == 0u) return;                                  // uniform per workgroup
     const uint32_t room = (b0 < tb.cap) ? min(b1, tb.cap) - b0 : 0u;      // records of this list that exist (K7's own test)
     const uint32_t cnt = min(filled, room);
@@ -1299,7 +1296,7 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     if (!tex && !geo) return;
     if (tex && tb.rec)      // list offsets + cursors from the counts the forward left (one small workgroup)
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
-                           gr->tex_bin_base, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
+                           gr->tex_bin_base, gr->tex_bin_cursor, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
     const dim3 grid(blend_grid(a.num_tiles)), blk(64);
 #define K7_LAUNCH(TEX, GEO, UVG, TAPS) hipLaunchKernelGGL((k_render_bwd<TEX, GEO, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
         img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)

@@ -12,7 +12,7 @@ TILE = 16
 REC_TEST_FLOATS = 8
 REC_SHADE_FLOATS = 20
 TEXBIN_RECORD_FLOATS = 5
-RESV_WORDS = 48          # per 8x8 pixel block: 16 reservation entries x {bin, offset, count} (TexGSImage.tex_bin_resv)
+RESV_WORDS = 192         # per 8x8 pixel block: 64 reservation entries x {bin, offset, count} (TexGSImage.tex_bin_resv)
 ACC_FLOATS = 32
 WANT_TEXTURE, WANT_GAUSSIANS, WANT_ALL = 1, 2, 3
 

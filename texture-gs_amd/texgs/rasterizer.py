@@ -317,7 +317,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             ar.add("ranges", (tiles, 2), i32)              # zero-filled by K3
             ar.add("tile_order", (tiles,), i32)
             if want_counts and handoff:
-                ar.add("tex_bin_count", (int(lib.texgs_tex_bin_count(R)),), i32)
+                ar.add("tex_bin_count", (2 * int(lib.texgs_tex_bin_count(R)),), i32)     # reserved | overflow footprints per bin
                 ar.add("tex_bin_resv", (4 * tiles, _lib.RESV_WORDS), i32)      # K6's per-block reservations in the record lists
             if handoff:
                 ar.add("surv_count", (4 * tiles,), i32)
@@ -433,7 +433,7 @@ def _late_handoff(s: _State):
     ar.add("surv_qmask", (4 * max(s.cap, 1),), torch.int16)
     ar.add("surv_count", (4 * s.tiles,), i32)
     if s.want_counts:
-        ar.add("tex_bin_count", (int(lib.texgs_tex_bin_count(s.R)),), i32)
+        ar.add("tex_bin_count", (2 * int(lib.texgs_tex_bin_count(s.R)),), i32)
         ar.add("tex_bin_resv", (4 * s.tiles, _lib.RESV_WORDS), i32)
     ar.add("scratch_out", (8, s.H, s.W), f32)
     ar.add("final_T", (s.H, s.W), f32)

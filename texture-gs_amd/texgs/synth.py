@@ -83,6 +83,21 @@ def make_scene(N, R, seed=0, scale_mean=0.006, sh_coeffs=15, random_jacobian=Fal
     return Scene(f(means), f(scales), f(q), f(opac), f(shs), f(uvs), f(Jm.reshape(N, 9)), tex)
 
 
+def band_limited_texture(R, seed=0, period=32, amplitude=1.0):
+    """A cubemap of LOW-PASSED noise: white noise drawn every `period` texels, bicubically interpolated to [6,R,R,3] -- slope
+    ~ amplitude / period per texel (0.03-0.05 at the default) and a continuous first derivative, against the O(1) texel-to-texel
+    steps of make_scene's white-noise texture.  Parity runs use it beside the white noise: a bilinear cell chosen differently by
+    two fp32 implementations then moves a pair's dL/duv by a few per cent instead of by O(1), so that every gradient row can
+    be compared at the plain tolerance (no cell-edge flags), and the sample itself is insensitive to the last bit of the texel
+    coordinate (RGB within the literal 1e-4 at R = 2048 too)."""
+    g = torch.Generator().manual_seed(seed)
+    n = max(R // period, 1) + 3
+    coarse = amplitude * torch.randn(6 * 3, 1, n, n, generator=g, dtype=torch.float32)
+    fine = torch.nn.functional.interpolate(coarse, size=(R + 2 * period, R + 2 * period), mode="bicubic", align_corners=True)
+    fine = fine[:, 0, period:period + R, period:period + R]            # away from the interpolation's clamped border
+    return fine.reshape(6, 3, R, R).permute(0, 2, 3, 1).contiguous()
+
+
 def world2view(Rm, t):
     """utils/graphics.py:38-49 with translate=0, scale=1 (the inverse-of-inverse is the identity there)."""
     Rt = np.zeros((4, 4))
