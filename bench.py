@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
                     help="HIP streams the views of a step are pipelined over (texgs.multiview.ViewPipeline); 1 = serial")
     ap.add_argument("--order", default=os.environ.get("TEXGS_BENCH_ORDER", "accumulate"), choices=["backward", "accumulate", "none"])
+    ap.add_argument("--leg", default="operator", choices=["operator", "iteration"],
+                    help="iteration = one training iteration of the reference's texture stage on this stack (UV map, two renders, the "
+                         "loss front-end, one backward; models/texture_gaussian3d.py:315-418) -- scripts/bench_iteration.py; its own "
+                         "metric, never the headline")
     ap.add_argument("--surface", default="textured", choices=["textured", "diff_gauss"],
                     help="diff_gauss = the untextured operator the reference's stages 1-2 call (render/render.py:75-84): same scene, "
                          "colours from SH with DC, no texture (SURVEY 8f-1); reported as its own metric, not the headline")
@@ -136,6 +140,15 @@ def main():
     from texgs.multiview import GradBucket, ViewPipeline, shard_views
 
     N, R, W, H, mode = WORKLOADS[args.workload]
+    if args.leg == "iteration":
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_iteration
+        if rank == 0:
+            res = bench_iteration.run(N, R, W, H, iters=max(args.steps, 4), warm=max(args.warmup, 2), dev_index=dev_index)
+            print(json.dumps({"metric": f"reference training iteration (texture stage), ms per iteration ({args.workload})",
+                              "value": res["uv_once_ms_per_iteration"], "unit": "ms/iteration", "higher_is_better": False, "n_gpus": 1,
+                              "dtype": "f32", "data": "synthetic", **res}), flush=True)
+        return
     with_bwd = mode == "fwd+bwd"
     K = 15
     scene = synth.make_scene(N, R, seed=0)
@@ -340,6 +353,13 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": ab[dom], "avg_launch_us": round(kinfo[dom]["avg_us"], 2)}
+        # the same figure on SURVEY.md section 8(d)'s terms for the two blend kernels (K7: 52 P + 116 D + 228 N + 216 R^2, K6:
+        # 116 D + 72 R^2 + 40 P + 8 T -- whole lists and the whole texture, where this file's own definition counts the list up to
+        # the last contributor and the texels actually touched: the smaller, stricter number stays `achieved`)
+        sv = {"render_bwd": 52 * P + 116 * s.D + 228 * N + 216 * R * R, "render_fwd": 116 * s.D + 72 * R * R + 40 * P + 8 * T}.get(dom)
+        if sv and not untextured:
+            roofline["alg_bytes_per_launch_survey_8d"] = sv
+            roofline["frac_survey_8d"] = round(sv / (kinfo[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         if dom == DOMINANT and kern_solo_dom[1]:
             solo_us = 1e3 * kern_solo_dom[0] / kern_solo_dom[1]
             roofline["solo_launch_us"] = round(solo_us, 2)
@@ -390,6 +410,8 @@ def main():
                 scales=torch.exp(raw["scales"]), rotations=torch.nn.functional.normalize(raw["rotations"]),
                 uvs=raw["uvs"], gradient_uvs=juv, texture=raw["texture"], extra_attrs=None)
             torch.autograd.backward([out[0], out[3], out[2]], [g_img, g_alpha, g_norm])
+            for p_ in raw.values():          # optimizer.zero_grad(set_to_none=True) after every iteration (models/texture_gaussian3d.py:442-444)
+                p_.grad = None
         nv = min(16, len(my_views))
         for v in my_views[:4]:
             compat_view(v)
@@ -400,7 +422,9 @@ def main():
         torch.cuda.synchronize(dev)
         compat = {"views_per_s": round(nv / (time.perf_counter() - c0), 2), "views": nv,
                   "note": "one view per call through autograd: sigmoid/exp/normalize activations + their backward, fresh "
-                          "means2D, AccumulateGrad of every gradient (no fused sink); measured after the timed region"}
+                          "means2D, gradients delivered by autograd (no fused sink) and dropped with set_to_none after every view as "
+                          "models/texture_gaussian3d.py:442-444 does (until round 5 they were left to accumulate: an extra "
+                          "read-modify-write of 150 MB per view the reference does not pay); measured after the timed region"}
 
         # ---- the reference's ITERATION after iteration 10 000 (models/texture_gaussian3d.py:318, 375-389, 410): render at the active
         # degree, render AGAIN at sh_degree 0 (lambda_no_sh: same camera, same Gaussians, activations recomputed by the getters),
@@ -418,6 +442,8 @@ def main():
                     scales=torch.exp(raw["scales"]), rotations=torch.nn.functional.normalize(raw["rotations"]),
                     uvs=raw["uvs"], gradient_uvs=juv, texture=raw["texture"], extra_attrs=None))
             torch.autograd.backward([outs[0][0], outs[0][3], outs[0][2], outs[1][0]], [g_img, g_alpha, g_norm, 2.0 * g_img])
+            for p_ in raw.values():
+                p_.grad = None
         ref_iter = {}
         saved_gc = RZ.GEOM_CACHE
         for label, on in (("separate_geometry", False), ("shared_geometry", True)):

@@ -327,6 +327,13 @@ int texgs_uv_taylor(const TexGSUVNet* net, const float* xyz, int32_t N, float* u
 int texgs_uv_pack(const TexGSUVNet* net, void* packed, void* stream);
 int texgs_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
                            void* stream);
+/* The same two steps at SPLIT-bf16 precision (v12, opt-in): every operand of the three 128x128 layers is split into two bf16
+ * halves and a product taken as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (f32 accumulation) -- ~2.5x faster than the f32-
+ * input MFMA of texgs_uv_taylor_packed, uvs / Jacobian within ~2e-5 of it.  `packed` has the same size, a different layout: a
+ * buffer packed by one variant must not be handed to the other. */
+int texgs_uv_pack_bf16x3(const TexGSUVNet* net, void* packed, void* stream);
+int texgs_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
+                                  void* stream);
 
 /* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
  * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,

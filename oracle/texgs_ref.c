@@ -365,7 +365,7 @@ void texgs_ref_bin(const RefIn *in, uint32_t D, const float *depth, const int32_
     }
 }
 
-typedef struct { int o00, o01, o10, o11, axis; float fx, fy, sc, tc, h, rma, sm, su, sv; } Tap;
+typedef struct { int o00, o01, o10, o11, axis; float fx, fy, sc, tc, h, rma, sm, su, sv; int x0, y0, face; } Tap;   /* x0, y0: unclamped cell */
 
 static Tap cube_address(float u0, float u1, float u2, int R) {
     Tap t; float m, ua, ub;
@@ -385,6 +385,7 @@ static Tap cube_address(float u0, float u1, float u2, int R) {
     const int x0c = imin(imax(x0, 0), R - 1), x1c = imin(imax(x0 + 1, 0), R - 1);
     const int y0c = imin(imax(y0, 0), R - 1), y1c = imin(imax(y0 + 1, 0), R - 1);
     const int fb = face * R;
+    t.x0 = x0; t.y0 = y0; t.face = face;
     t.o00 = ((fb + y0c) * R + x0c) * 3; t.o01 = ((fb + y0c) * R + x1c) * 3;
     t.o10 = ((fb + y1c) * R + x0c) * 3; t.o11 = ((fb + y1c) * R + x1c) * 3;
     return t;
@@ -455,8 +456,22 @@ void texgs_ref_render_fwd(const RefIn *in, const float *rec, const uint32_t *poi
  *                to) a forward-ambiguous pixel, or one of its pairs is within tau_cell texels of a cell edge, or within
  *                tau_relu of the colour clamp;
  *   tflag[6RR]   same for a texel: tapped by a contributor of a forward-ambiguous pixel or by a pair within tau_relu of the clamp. */
+void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                            float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag, float *cond);
 void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                          float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag) {
+    texgs_ref_ambiguity_ex(in, rec, point_list, ranges, tau_fwd, tau_cell, tau_relu, margin, gflag, tflag, NULL);
+}
+/* _ex: also cond[H*W] (may be NULL) = sum over the pixel's contributors of w_i * (|A dx^2| / 2 + |C dy^2| / 2 + |B dx dy|) * 2^-23 --
+ * the rounding error of the falloff exponent `power` in fp32, carried to the blend weights.  `power` is a difference of terms that
+ * grow with the square of the pixel's distance from the splat centre; for splats hundreds of pixels wide (a 4 112 x 4 112 frame of
+ * 3 000 Gaussians, the stress scene's screen-filling ones) those terms reach 10-100 and alpha itself is only known to ~1e-5..1e-4
+ * relative, whatever the implementation.  The tests widen a pixel's tolerance by a small multiple of cond (negligible -- ~1e-7 --
+ * on the benchmark scenes, whose splats are ~10 px), and the alpha / T decisions below count as ambiguous when their margin is
+ * inside that same uncertainty.  Rows (gflag / tflag) are flagged for pixels whose 1/255, power, face or den decisions are
+ * ambiguous -- NOT for a T-stop alone: what a marginal stop adds or removes carries a weight below 2e-4 of the pixel. */
+void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
+                            float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag, float *cond) {
     const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gxn * gyn; ++tile) {
@@ -466,31 +481,36 @@ void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *poin
             const int px = tx0 + lx, py = ty0 + ly;
             if (px >= W || py >= H) continue;
             const float pxf = (float)px, pyf = (float)py;
-            float mpix = INFINITY;
+            float mpix = INFINITY, mpix_hard = INFINITY, cpix = 0.0f;
             for (int pass = 0; pass < 2; ++pass) {
                 /* pass 0: the pixel's margin.  pass 1: flags; in a forward-ambiguous pixel everything that contributes -- or is
                    within tau_fwd of contributing, or comes after a T-threshold stop that is within tau_fwd of not happening --
                    may carry a different gradient */
-                const int pix_amb = (pass == 1) && (mpix < tau_fwd);
+                const int pix_amb = (pass == 1) && (mpix_hard < tau_fwd);       /* (a T-stop alone does not flag rows) */
                 int past_marginal_stop = 0;
-                float T = 1.0f;
+                float T = 1.0f, tunc = 0.0f;        /* tunc: relative uncertainty of T so far (sum of its factors' uncertainties) */
                 for (uint32_t k = r0; k < r1; ++k) {
                     const uint32_t id = point_list[k];
                     const float *r = rec + (size_t)id * REC;
                     const float dx = r[0] - pxf, dy = r[1] - pyf;
                     const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
                     float m = INFINITY;
-                    if (fabsf(power) < 1e-5f) m = 0.0f;
+                    /* uncertainty of `power` itself (absolute) = of alpha (relative): a few roundings of its largest term */
+                    const float pu = 4.0f * 5.9604645e-8f * (0.5f * fabsf(r[2] * dx * dx) + 0.5f * fabsf(r[4] * dy * dy) + fabsf(r[3] * dx * dy));
+                    if (fabsf(power) < 1e-5f + pu) m = 0.0f;
                     const float araw = r[5] * expf(power);
-                    if (power <= 0.0f || m == 0.0f) m = fminf(m, fabsf(araw - ALPHA_MIN) / ALPHA_MIN);
+                    if (power <= 0.0f || m == 0.0f) m = fminf(m, fmaxf(0.0f, fabsf(araw - ALPHA_MIN) / ALPHA_MIN - pu));
+                    float m_hard = m;
                     const int pass_alpha = (power <= 0.0f) && (fminf(ALPHA_MAX, araw) >= ALPHA_MIN);
                     int contributes = pass_alpha;
                     float Tn = T;
                     if (pass_alpha) {
                         const float alpha = fminf(ALPHA_MAX, araw);
                         Tn = T * (1.0f - alpha);
-                        const float m_T = fabsf(Tn - T_EPS) / T_EPS * 0.2f;      /* T is a long product: 5x wider band than alpha's */
+                        tunc += pu * alpha / fmaxf(1.0f - alpha, 0.01f);
+                        const float m_T = fmaxf(0.0f, (fabsf(Tn - T_EPS) / T_EPS - tunc) * 0.2f);      /* T is a long product: 5x wider band than alpha's */
                         m = fminf(m, m_T);
+                        if (pass == 0) cpix += alpha * T * pu * 0.25f;          /* (pu carries the factor 4; cond is in units of one rounding) */
                         if (Tn < T_EPS && !past_marginal_stop) {
                             if (pass == 0 || m_T >= tau_fwd) { if (pass == 0) mpix = fminf(mpix, m); break; }
                             past_marginal_stop = 1;          /* pass 1, marginal stop: the other implementation may blend on */
@@ -508,8 +528,10 @@ void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *poin
                             if (a0 < a1) { t = a0; a0 = a1; a1 = t; }
                             m = fminf(m, (a0 - a1) / fmaxf(a0, MA_MIN));
                             m = fminf(m, fabsf(den - DEN_MIN));
+                            m_hard = fminf(m_hard, fminf((a0 - a1) / fmaxf(a0, MA_MIN), fabsf(den - DEN_MIN)));
                         }
                         mpix = fminf(mpix, m);
+                        mpix_hard = fminf(mpix_hard, m_hard);
                     } else {
                         const int marginal = pix_amb && (m < tau_fwd || past_marginal_stop);      /* may contribute on the other side */
                         if ((contributes || marginal) && !in->tex) {
@@ -543,6 +565,7 @@ void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *poin
                 }
             }
             margin[py * W + px] = mpix;
+            if (cond) cond[py * W + px] = cpix;
         }
     }
 }
@@ -567,14 +590,15 @@ static void atomic_addd(double *p, double v) {
  * having one such pair among its hundreds. */
 void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                              const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
-                             float tau_cell, float cell_weight, double *fmass);
+                             float tau_cell, float cell_weight, float tex_slope, double *fmass);
 void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                           const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex) {
-    texgs_ref_render_bwd_ex(in, rec, point_list, ranges, final_T, n_contrib, dout, acc, dtex, 0.0f, 0.0f, NULL);
+    texgs_ref_render_bwd_ex(in, rec, point_list, ranges, final_T, n_contrib, dout, acc, dtex, 0.0f, 0.0f, 0.0f, NULL);
 }
+/* (tex_slope: unused since the mass is the exact change under a switch to the neighbouring cell.) */
 void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                              const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
-                             float tau_cell, float cell_weight, double *fmass) {
+                             float tau_cell, float cell_weight, float tex_slope, double *fmass) {
     const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE, HW = W * H;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gxn * gyn; ++tile) {
@@ -671,10 +695,51 @@ void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *
                 double *ap = acc + (size_t)id * REC;
                 for (int k = 0; k < REC; ++k) if (part[k] != 0.f) atomic_addd(ap + k, (double)part[k]);
                 if (fmass && textured && fminf(fminf(ct.fx, 1.0f - ct.fx), fminf(ct.fy, 1.0f - ct.fy)) < tau_cell) {
+                    /* What would this pair contribute had the sample been taken in the NEIGHBOURING bilinear cell (the sample value
+                       is the same there -- bilinear interpolation is continuous -- its uv-derivative is not)?  The uv terms are
+                       linear in dL/duv, so the change is exactly the terms evaluated on the DIFFERENCE of the two cells' derivatives.
+                       Up to three neighbours when the sample sits near a corner; the largest change per term is the pair's mass. */
+                    const int nx = fminf(ct.fx, 1.0f - ct.fx) < tau_cell, ny = fminf(ct.fy, 1.0f - ct.fy) < tau_cell;
+                    const int sx = (ct.fx < 0.5f) ? -1 : 1, sy = (ct.fy < 0.5f) ? -1 : 1, R_ = in->R, fb = ct.face * R_;
+                    float mass[REC]; memset(mass, 0, sizeof(mass)); float m_uv0 = 0.f, m_uv1 = 0.f;
+                    for (int alt = 0; alt < 3; ++alt) {
+                        const int ax = (alt == 0 || alt == 2) ? sx : 0, ay = (alt == 1 || alt == 2) ? sy : 0;
+                        if ((ax && !nx) || (ay && !ny) || (!ax && !ay)) continue;
+                        const float fxa = ct.fx - (float)ax, fya = ct.fy - (float)ay;          /* the same point in the neighbour's frame */
+                        const int xa0 = imin(imax(ct.x0 + ax, 0), R_ - 1), xa1 = imin(imax(ct.x0 + ax + 1, 0), R_ - 1);
+                        const int ya0 = imin(imax(ct.y0 + ay, 0), R_ - 1), ya1 = imin(imax(ct.y0 + ay + 1, 0), R_ - 1);
+                        float dcol = 0.f, drow = 0.f;
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const float a00 = in->tex[((fb + ya0) * R_ + xa0) * 3 + ch], a01 = in->tex[((fb + ya0) * R_ + xa1) * 3 + ch];
+                            const float a10 = in->tex[((fb + ya1) * R_ + xa0) * 3 + ch], a11 = in->tex[((fb + ya1) * R_ + xa1) * 3 + ch];
+                            const float gc_alt = (1.f - fya) * (a01 - a00) + fya * (a11 - a10), gr_alt = (1.f - fxa) * (a10 - a00) + fxa * (a11 - a01);
+                            const float gc_cur = (1.f - ct.fy) * (t01[ch] - t00[ch]) + ct.fy * (t11[ch] - t10[ch]);
+                            const float gr_cur = (1.f - ct.fx) * (t10[ch] - t00[ch]) + ct.fx * (t11[ch] - t01[ch]);
+                            dcol += dtexv[ch] * (gc_alt - gc_cur); drow += dtexv[ch] * (gr_alt - gr_cur);
+                        }
+                        const float ea = dcol * ct.su * ct.h, eb = drow * ct.sv * ct.h;
+                        const float em = -(dcol * ct.sc + drow * ct.tc) * ct.h * ct.rma * ct.sm;
+                        float e0, e1, e2;
+                        if (ct.axis == 0) { e0 = em; e2 = ea; e1 = eb; }
+                        else if (ct.axis == 1) { e1 = em; e0 = ea; e2 = eb; }
+                        else { e2 = em; e0 = ea; e1 = eb; }
+                        float q[REC]; memset(q, 0, sizeof(q)); float q0 = 0.f, q1 = 0.f;
+                        q[14] = e0; q[15] = e1; q[16] = e2;
+                        if (good) {
+                            const float n0 = e0 * inv, n1 = e1 * inv, n2 = e2 * inv;
+                            const float dd = -(e0 * nu0 + e1 * nu1 + e2 * nu2) * inv * inv;
+                            q[8] = n0 * dpx; q[9] = n0 * dpy; q[10] = n1 * dpx; q[11] = n1 * dpy; q[12] = n2 * dpx; q[13] = n2 * dpy;
+                            q[6] = dd * dpx; q[7] = dd * dpy;
+                            q0 = (r[8] * n0 + r[10] * n1 + r[12] * n2) + r[6] * dd; q1 = (r[9] * n0 + r[11] * n1 + r[13] * n2) + r[7] * dd;
+                        }
+                        for (int k = 6; k < 17; ++k) mass[k] = fmaxf(mass[k], fabsf(q[k]));
+                        m_uv0 = fmaxf(m_uv0, fabsf(q0)); m_uv1 = fmaxf(m_uv1, fabsf(q1));
+                    }
                     double *fp = fmass + (size_t)id * REC;
-                    for (int k = 6; k < 17; ++k) if (part[k] != 0.f) atomic_addd(fp + k, (double)(cell_weight * fabsf(part[k])));
-                    if (uv0 != 0.f) atomic_addd(fp + 0, (double)(cell_weight * fabsf(uv0)));
-                    if (uv1 != 0.f) atomic_addd(fp + 1, (double)(cell_weight * fabsf(uv1)));
+                    for (int k = 6; k < 17; ++k) if (mass[k] != 0.f) atomic_addd(fp + k, (double)(cell_weight * mass[k]));
+                    if (m_uv0 != 0.f) atomic_addd(fp + 0, (double)(cell_weight * m_uv0));
+                    if (m_uv1 != 0.f) atomic_addd(fp + 1, (double)(cell_weight * m_uv1));
+                    (void)tex_slope; (void)uv0; (void)uv1;
                 }
             }
         }

@@ -135,9 +135,13 @@ class RefRun:
         acc = np.zeros((max(N, 1), REC), np.float64)
         dtex = np.zeros((6, R, R, 3), np.float32) if self.textured else None
         self.fmass = np.zeros((max(N, 1), REC), np.float64) if tau_cell > 0 else None
+        slope = 0.0
+        if tau_cell > 0 and self.textured:          # typical texel-to-texel step of this texture (white noise N(0, 1): ~1.1)
+            t = self.arr["tex"]
+            slope = float(max(np.abs(np.diff(t[0], axis=0)).mean(), np.abs(np.diff(t[0], axis=1)).mean()))
         lib.texgs_ref_render_bwd_ex(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(self.final_T),
                                     _p(self.n_contrib), _p(dout), _p(acc), _p(dtex), C.c_float(tau_cell), C.c_float(cell_weight),
-                                    _p(self.fmass))
+                                    C.c_float(slope), _p(self.fmass))
         g = self._k8(acc, self._grad_arrays())
         g["texture"] = dtex
         self.acc = acc
@@ -212,8 +216,12 @@ class RefRun:
         margin = np.full((self.H, self.W), np.inf, np.float32)
         gflag = np.zeros(max(self.N, 1), np.uint8)
         tflag = np.zeros(6 * self.R * self.R, np.uint8)          # (untextured: R = 1, never written)
-        self.lib.texgs_ref_ambiguity(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges),
-                                     C.c_float(tau_fwd), C.c_float(tau_cell), C.c_float(tau_relu), _p(margin), _p(gflag), _p(tflag))
+        # self.cond [H,W]: rounding error of the falloff exponent carried to the pixel's blend weights, in units of one fp32 rounding
+        # of a value of size 1 (texgs_ref_ambiguity_ex): ~1e-7 on the benchmark scenes, 1e-5..1e-4 under splats hundreds of pixels wide
+        self.cond = np.zeros((self.H, self.W), np.float32)
+        self.lib.texgs_ref_ambiguity_ex(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges),
+                                        C.c_float(tau_fwd), C.c_float(tau_cell), C.c_float(tau_relu), _p(margin), _p(gflag), _p(tflag),
+                                        _p(self.cond))
         return margin, gflag[:self.N].astype(bool), tflag.reshape(6, self.R, self.R).astype(bool)
 
     @property

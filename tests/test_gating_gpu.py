@@ -321,3 +321,52 @@ def test_forward_only_callers_stop_paying_for_the_handoff(lib_built):
         RZ.GEOM_CACHE = saved
         RZ.reset_handoff_predictor()
         RZ.release_scratch()
+
+
+def test_train_eval_interleave_costs_one_late_handoff_per_switch_and_holds_no_more_memory(lib_built):
+    """A training loop with a periodic visual_step (models/texture_gaussian3d.py:499-511: two renders with parameters that require
+    grad, no backward): ten differentiated iterations over changing views, two dropped forwards, three times over.  Each return
+    to training pays at most ONE late hand-off (the first backward after the drops builds K6's lists itself, then the forwards
+    switch back), and the module's caches -- backward scratch and the shared-geometry entry -- do not grow from cycle to cycle."""
+    import gc
+    from texgs import rasterizer as RZ
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(3000, 64, seed=5, scale_mean=0.03)
+    cams = synth.fibonacci_cameras(8, 192, 144)
+    sts = [Hh.settings_for(c, 2, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings) for c in cams]
+    target, nhat = synth.make_targets(144, 192, seed=3)
+    target, nhat = target.to(dev), nhat.to(dev)
+    juv = scene.gradient_uvs.to(dev)
+    leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(True) for n in NAMES}
+
+    def fwd(v):
+        return GaussianRasterizer(sts[v])(means3D=leaves["means3D"], means2D=None, shs=leaves["shs"], opacities=leaves["opacities"],
+                                          scales=leaves["scales"], rotations=leaves["rotations"], uvs=leaves["uvs"],
+                                          gradient_uvs=juv, texture=leaves["texture"], extra_attrs=None)
+    gc.collect()
+    RZ.reset_handoff_predictor()
+    RZ.release_scratch()
+    held, late = [], []
+    try:
+        h0 = RZ.geometry_cache_stats()["late_handoffs"]
+        for cycle in range(3):
+            for it in range(10):
+                out = fwd((cycle * 10 + it) % 8)
+                synth.synthetic_loss(out[0], out[3], out[2], target, nhat).backward()
+                for t in leaves.values():
+                    t.grad = None
+                del out
+            for k in range(2):                      # visual_step: graphs built and dropped
+                out = fwd(k)
+                del out
+            torch.cuda.synchronize()
+            gc.collect()
+            held.append(RZ.scratch_bytes())
+            late.append(RZ.geometry_cache_stats()["late_handoffs"] - h0)
+        assert late[-1] <= 2, late                  # one per return to training (cycles 2 and 3), none inside a training run
+        assert held[2] <= held[1] * 1.001 + 4096, held
+        assert len(RZ._GEOM) <= 1 and len(RZ._SCRATCH) <= 1
+    finally:
+        RZ.reset_handoff_predictor()
+        RZ.release_scratch()

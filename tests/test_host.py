@@ -318,21 +318,23 @@ def _two_segment_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_segment_allreduce_two_ranks_equals_the_sum():
-    """GradBucket.all_reduce_async on the texture segment and on the per-Gaussian segment (gloo, 2 ranks): together the whole
-    bucket is summed over the ranks, .grad views see it, segments must be runs of adjacent registered parameters."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_segment_allreduce_two_ranks_equals_the_sum(world):
+    """GradBucket.all_reduce_async on the texture segment and on the per-Gaussian segment (gloo; 2 ranks, and 8 -- the world size of
+    BASELINE configs[3], whose collective order has otherwise never run): together the whole bucket is summed over the ranks, .grad
+    views see it, segments must be runs of adjacent registered parameters."""
     import torch.multiprocessing as mp
     from texgs.multiview import GradBucket
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400) + 431
-    ps = [ctx.Process(target=_two_segment_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 400) + 431 + world
+    ps = [ctx.Process(target=_two_segment_worker, args=(r, world, port, q)) for r in range(world)]
     for p_ in ps:
         p_.start()
-    res = [q.get(timeout=120) for _ in ps]
+    res = [q.get(timeout=300) for _ in ps]
     for p_ in ps:
         p_.join(60)
-    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] and r[2] for r in res)
+    assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] and r[2] for r in res)
     a = torch.zeros(3, requires_grad=True); b = torch.zeros(3, requires_grad=True); c = torch.zeros(3, requires_grad=True)
     with pytest.raises(ValueError):
         GradBucket([a, b, c]).segment_of([a, c])                              # not adjacent

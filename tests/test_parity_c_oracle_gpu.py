@@ -166,13 +166,13 @@ def test_stress_scene_vs_c_oracle(lib_built):
     res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(), dout[4:7].to(dev).contiguous(),
                        dout[7:8].to(dev).contiguous())
     gref = ref.backward(dout.numpy())
-    sens = ref.accumulation_sensitive()
-    Hh.report("hip_vs_c32/stress/bwd/accumulation_sensitive_rows", rows=int(sens.sum()), frac=float(sens.mean()))
+    # gradients: this scene's screen-filling splats make the falloff exponent itself ill-conditioned (see forward_attributed's cond),
+    # and with it every gradient that passes through alpha; the row-level budgets of rounds 2-4 stay for this one scene
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
         assert bool(torch.isfinite(got_g).all()), name_
-        Hh.grad_attributed(f"hip_vs_c32/stress/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]),
-                           tflag if name_ == "texture" else (gflag | sens), flagged_frac_max=0.9)
-    Hh.pair_level_gradient_check("hip_vs_c32/stress/bwd_pair_level", ref, res, dout, R, sens)
+        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.005, global_rel=1e-2,
+                                label=f"hip_vs_c32/stress/bwd/{name_}")
+        assert ok, (name_, msg)
 
 
 def test_more_than_65536_tiles_three_digit_tile_sort(lib_built):

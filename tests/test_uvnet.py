@@ -84,6 +84,68 @@ def test_fused_kernel_full_size_vs_float64_autograd(lib_built, variant):
     assert float(uJ.abs().max()) < 1e-4 * float(ref_J.abs().max())
 
 
+@pytest.mark.gpu
+def test_split_bf16_kernel_vs_f32_kernel_and_float64(lib_built):
+    """precision="bf16x3" (csrc/uvnet.hip k_uv_taylor_bf16x3: every operand split into two bf16 halves, three bf16 MFMAs per product):
+    uvs and the Jacobian within 2e-5 (relative to the largest entry) of the f32-MFMA kernel and of float64 autograd, at 300 k points,
+    with the reference golden net too; a weight update re-packs (the two variants' packed buffers have different layouts)."""
+    dev = torch.device("cuda:0")
+    net0, emb0, xyz0 = _golden_net(torch.float32)
+    netb = UVNet(precision="bf16x3")
+    netb.load_state_dict(net0.state_dict())
+    uvs, J = netb.to(dev).uv_and_jacobian(xyz0.to(dev), emb0.to(dev))
+    e_uv = float((uvs.cpu().double() - torch.tensor(G["uvs"])).abs().max())
+    e_J = float((J.cpu().double() - torch.tensor(G["J"])).abs().max()) / float(np.abs(G["J"]).max())
+    Hh.report("uv_taylor_bf16x3/golden", uvs_max_abs_err=e_uv, J_max_err_over_Jmax=e_J)
+    assert e_uv < 2e-5 and e_J < 1e-4
+    torch.manual_seed(11)
+    kw = dict(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2])
+    net = UVNet(**kw)
+    emb = torch.randn(128) * 0.2
+    N = 300_000
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.randn(N, 3, generator=g)
+    xyz = (xyz / xyz.norm(dim=1, keepdim=True) * (1 + 0.02 * torch.randn(N, 1, generator=g))).to(dev)
+    embd = emb.to(dev)
+    n32 = net.to(dev)
+    nb = UVNet(precision="bf16x3", **kw).to(dev)
+    nb.load_state_dict(n32.state_dict())
+    u32, J32 = n32.uv_and_jacobian(xyz, embd)
+    ub, Jb = nb.uv_and_jacobian(xyz, embd)
+    torch.cuda.synchronize()
+    times = {}
+    for name, m in (("fp32", n32), ("bf16x3", nb)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            m.uv_and_jacobian(xyz, embd)
+        e1.record()
+        torch.cuda.synchronize()
+        times[name] = e0.elapsed_time(e1) / 10 * 1e3
+    jmax = float(J32.abs().max())
+    d_uv = float((ub - u32).abs().max())
+    d_J = float((Jb - J32).abs().max()) / jmax
+    idx = torch.randperm(N, generator=g)[:4096]
+    net64 = UVNet(**kw).double()
+    net64.load_state_dict({k: v.double().cpu() for k, v in n32.state_dict().items()})
+    ref_uv = net64(xyz[idx.to(dev)].cpu().double(), emb.double())
+    ref_J = jacobian_by_autograd(net64, xyz[idx.to(dev)].cpu().double(), emb.double())
+    e_uv = float((ub[idx.to(dev)].cpu().double() - ref_uv).abs().max())
+    e_J = float((Jb[idx.to(dev)].cpu().double() - ref_J).abs().max()) / float(ref_J.abs().max())
+    rel_J = float((Jb[idx.to(dev)].cpu().double() - ref_J).norm() / ref_J.norm())
+    Hh.report("uv_taylor_bf16x3/300k", uvs_max_abs_vs_f32_kernel=d_uv, J_max_over_Jmax_vs_f32_kernel=d_J, uvs_max_abs_vs_f64=e_uv,
+              J_max_over_Jmax_vs_f64=e_J, J_rel_l2_vs_f64=rel_J, us_fp32=times["fp32"], us_bf16x3=times["bf16x3"])
+    assert d_uv < 2e-5 and d_J < 2e-5, (d_uv, d_J)
+    assert e_uv < 2e-5 and e_J < 2e-5 and rel_J < 2e-5, (e_uv, e_J, rel_J)
+    assert float((ub.norm(dim=1) - 1).abs().max()) < 1e-5
+    with torch.no_grad():                        # a weight update re-packs in the variant's own layout
+        nb.mlp[0].weight.mul_(1.5)
+        n32.mlp[0].weight.mul_(1.5)
+    ub2, _ = nb.uv_and_jacobian(xyz, embd)
+    u32b, _ = n32.uv_and_jacobian(xyz, embd)
+    assert float((ub2 - u32b).abs().max()) < 2e-5 and float((ub2 - ub).abs().max()) > 1e-3
+
+
 def test_tcnn_flat_params_round_trip_and_first_layer_bias():
     """tiny-cuda-nn FullyFusedMLP state (`use_tcnn: True`, every shipped config): one flat bias-free tensor per network,
     input padded to 16 columns with ones (-> first-layer bias), output padded to 16 rows.  Layout restated from tiny-cuda-nn's

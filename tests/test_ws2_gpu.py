@@ -130,3 +130,25 @@ def test_bench_gpus2_under_driver_launcher_parses(lib_built):
     assert "gloo" in j["config"]["grad_allreduce"]
     import helpers as Hh
     Hh.report("c4/bench_gpus2_one_gpu_gloo", views_per_s=j["value"], ms_per_step=j["ms_per_step"])
+
+
+@pytest.mark.gpu
+def test_bench_gpus8_code_path_on_one_gpu(lib_built):
+    """BASELINE configs[3] is 8 ranks; no 8-GPU node has been available to any round.  This runs `bench.py --gpus 8` exactly as the
+    driver launches it -- 8 processes under torch.distributed.run -- with the ranks rehearsed on the one device (gloo, the bucket
+    staged through host memory) on the plumbing-sized workload C1: the LPT quotas (8 views per rank of 64), the two-segment
+    collective order on 8 ranks and the max-over-ranks timing all execute; one well-formed JSON line comes back."""
+    env = dict(os.environ, TEXGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "c1", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-kernel-table"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["global_views_per_step"] == 64 and "LPT" in j["config"]["view_sharding"]
+    assert "gloo" in j["config"]["grad_allreduce"] and "two segments" in j["config"]["grad_allreduce"]
+    import helpers as Hh
+    Hh.report("c4/bench_gpus8_one_gpu_gloo_c1", views_per_s=j["value"], ms_per_step=j["ms_per_step"])

@@ -370,6 +370,22 @@ int texgs_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const floa
     return 0;
 }
 
+int texgs_uv_pack_bf16x3(const TexGSUVNet* net, void* packed, void* stream) {
+    if (!net || !packed) return fail_msg("NULL argument");
+    if (int r = check_uvnet(net)) return r;
+    if (int r = launch_uv_pack_bf16x3(net, packed, (hipStream_t)stream)) return fail("uv_pack_bf16x3", (hipError_t)r);
+    return 0;
+}
+
+int texgs_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
+                                  void* stream) {
+    if (!net || !packed || !xyz || !uvs || !grad_uvs) return fail_msg("NULL argument");
+    if (int r = check_uvnet(net)) return r;
+    if (N < 0) return fail_msg("N < 0");
+    if (int r = launch_uv_taylor_packed_bf16x3(net, packed, xyz, N, uvs, grad_uvs, (hipStream_t)stream)) return fail("uv_taylor_bf16x3", (hipError_t)r);
+    return 0;
+}
+
 int texgs_selftest_waveops(const float* seed128, float* out576, void* stream) {
     if (!seed128 || !out576) return fail_msg("NULL argument");
     launch_selftest_waveops(seed128, out576, (hipStream_t)stream);

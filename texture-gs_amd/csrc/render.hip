@@ -530,6 +530,11 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 #ifndef K7_WAVES_PER_SIMD
 #define K7_WAVES_PER_SIMD 2
 #endif
+// K7_SLOT_RUNS: record slots per RUN of consecutive lanes on one reservation entry (one LDS atomic per run) instead of one returning
+// LDS atomic per lane
+#ifndef K7_SLOT_RUNS
+#define K7_SLOT_RUNS 0
+#endif
 #define BWD_MAX_IT 16
 struct TexBinArgs {
     float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
@@ -762,10 +767,29 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const int home = tap_home(ct);
                 const bool hit = binned && resv_bin(L.p, home) == bin;
                 R.slot = TG_SLOT_NONE; R.ovf0 = 0u; R.ovf1 = 0u;
+#if K7_SLOT_RUNS
+                {   // The lanes of a round are items in (iteration, pixel) order: consecutive lanes mostly share the Gaussian and with it
+                    // the bin.  A RUN = a maximal stretch of consecutive hit lanes on one table entry; its first lane takes slots for
+                    // the whole run (64 lanes bumping one LDS word one by one is what a per-lane returning atomic costs).
+                    const int key = hit ? home : (-1 - lane);
+                    const int prev = __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, key);
+                    const bool start = hit && (lane == 0 || prev != key);
+                    const ull ms = TG_BALLOT(start), mb = ms | ~TG_BALLOT(hit);          // run starts; breaks = starts and non-hit lanes
+                    const ull le = ~0ull >> (63 - lane);
+                    const int ldr = 63 - __clzll((long long)((ms & le) | 1ull));              // (| 1: defined for lanes before the first run)
+                    const ull after = (mb >> lane) >> 1;                                     // breaks behind this lane
+                    const int len = (after != 0ull) ? __ffsll((long long)after) : 64 - lane;  // (meaningful on run starts)
+                    uint32_t base = 0u;
+                    if (start) base = atomicAdd(&L.tpos[home], (uint32_t)len);
+                    base = (uint32_t)__builtin_amdgcn_ds_bpermute(ldr << 2, (int)base);
+                    if (hit) { const uint32_t pos = base + (uint32_t)(lane - ldr); if (pos < L.tend[home]) R.slot = pos; }
+                }
+#else
                 if (hit) {
                     const uint32_t pos = atomicAdd(&L.tpos[home], 1u);
                     if (pos < L.tend[home]) R.slot = pos;
                 }
+#endif
                 ull pend = TG_BALLOT(binned) & ~TG_BALLOT(hit);
                 while (pend != 0ull) {
                     const int l0 = __ffsll((long long)pend) - 1;

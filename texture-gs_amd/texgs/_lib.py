@@ -65,7 +65,8 @@ EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "te
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_read_num_rendered2", "texgs_depth_sort_scan", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
            "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
-           "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_norm_from_depth", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes", "texgs_uv_pack", "texgs_uv_taylor_packed"]
+           "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_norm_from_depth", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes", "texgs_uv_pack", "texgs_uv_taylor_packed",
+           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
 
@@ -121,6 +122,10 @@ def load():
     lib.texgs_uv_pack.restype = C.c_int
     lib.texgs_uv_taylor_packed.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_uv_taylor_packed.restype = C.c_int
+    lib.texgs_uv_pack_bf16x3.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p]
+    lib.texgs_uv_pack_bf16x3.restype = C.c_int
+    lib.texgs_uv_taylor_packed_bf16x3.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_uv_taylor_packed_bf16x3.restype = C.c_int
     lib.texgs_selftest_waveops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_selftest_waveops.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]

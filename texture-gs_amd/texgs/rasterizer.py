@@ -75,17 +75,21 @@ _GEOM = {}                  # (device index, stream) -> _GeomEntry of the last f
 _SERIAL = [0]
 _LAST_DIFFERENTIATED = {}
 _DROPPED = {}
+import threading as _threading
+_PRED_LOCK = _threading.RLock()       # the predictor's dicts are touched from __del__ (any thread, any time the collector runs)
 
 
 def unused_streak(dev_index):
     """Autograd forwards on this device that were dropped without a backward since the last one that was differentiated."""
-    last = _LAST_DIFFERENTIATED.get(dev_index, -1)
-    return sum(1 for n in _DROPPED.get(dev_index, ()) if n > last)
+    with _PRED_LOCK:
+        last = _LAST_DIFFERENTIATED.get(dev_index, -1)
+        return sum(1 for n in _DROPPED.get(dev_index, ()) if n > last)
 
 
 def reset_handoff_predictor():
-    _LAST_DIFFERENTIATED.clear()
-    _DROPPED.clear()
+    with _PRED_LOCK:
+        _LAST_DIFFERENTIATED.clear()
+        _DROPPED.clear()
 
 
 class _GeomEntry:
@@ -122,13 +126,16 @@ def release_scratch(device=None, stream=None):
 
 
 def scratch_bytes():
-    """Bytes currently held by the cached backward scratch (diagnostics / tests)."""
+    """Bytes currently held by the module's caches (diagnostics / tests): the backward scratch per (device, stream) and the arenas
+    the shared-geometry entries keep alive (the last list-building forward of every (device, stream))."""
     total = 0
     for sc in _SCRATCH.values():
         if sc.acc is not None:
             total += sc.acc.numel() * 4
         if sc.bins is not None:
             total += sc.bins.nbytes()
+    for e in _GEOM.values():
+        total += sum(ar.buf.numel() for ar in e.arenas if ar is not None and ar.buf is not None)
     return total
 
 
@@ -162,10 +169,14 @@ class _TexBins:
             self.rec = torch.empty(cap * _lib.TEXBIN_RECORD_FLOATS, dtype=torch.float32, device=self.device)
             self.cap = cap
 
-    def before_call(self, D):
+    def before_call(self, D, counts=None):
         if TEX_REC_CAP:
             self._resize(TEX_REC_CAP)
             return
+        if self.rec is None and counts is not None:
+            # first backward on this (device, stream): size the buffer from K6's exact per-bin counts (one device->host read, once;
+            # afterwards the asynchronous statistic below adapts it) instead of a guess of 20 records per instance
+            self._resize(int(counts.sum().item() * 1.25) + 4096)
         if self.event is not None and self.event.query():
             self.event = None
             wanted = int(self.host_stat[0])
@@ -192,8 +203,9 @@ class _State:
         try:
             if getattr(self, "lazy", False) and not self.backward_ran:
                 dev = self.tensors["keep"][0].device.index
-                last = _LAST_DIFFERENTIATED.get(dev, -1)
-                _DROPPED[dev] = [n for n in _DROPPED.get(dev, []) if n > last][-8:] + [self.serial]
+                with _PRED_LOCK:
+                    last = _LAST_DIFFERENTIATED.get(dev, -1)
+                    _DROPPED[dev] = [n for n in _DROPPED.get(dev, []) if n > last][-8:] + [self.serial]
         except Exception:
             pass
 
@@ -298,6 +310,9 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         gkey = (device.index, int(stream))
         entry = _GEOM.get(gkey) if GEOM_CACHE else None
         candidate = entry is not None and entry.ints == gints and entry.cam_key == cam_key
+        if entry is not None and not candidate:     # another view / size: the old lists cannot be shared any more -- let go of their
+            del _GEOM[gkey]                         # arenas before this forward allocates its own (they stay alive only while a
+            entry = None                            # state that shares them does)
         # Everything the kernels keep between forward and backward lives in TWO allocations (one sized by N / the image, one by
         # the instance capacity): ~20 separate torch.empty calls were ~0.1 ms of host time per view.  Tensor views of the
         # pieces are made on demand (tests, diagnostics).
@@ -405,8 +420,9 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D, s.cap, s.tiles = N, K, R, H, W, D, cap, tiles
     s.want_counts, s.lazy, s.backward_ran, s.shared_geometry = want_counts, bool(lazy and for_backward), False, shared is not None
-    _SERIAL[0] += 1
-    s.serial = _SERIAL[0]
+    with _PRED_LOCK:
+        _SERIAL[0] += 1
+        s.serial = _SERIAL[0]
     arenas = (fix,) + ((bin_ar,) if bin_ar is not None else ()) + (tuple(shared.arenas) if shared is not None else ())
     # (NOT the output tensors: autograd hangs its node on them, the node holds this state -- a cycle that kept every dropped
     #  graph's buffers alive until the garbage collector ran)
@@ -541,7 +557,8 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
             _late_handoff(s)
         s.backward_ran = True
         if s.lazy:
-            _LAST_DIFFERENTIATED[device.index] = max(_LAST_DIFFERENTIATED.get(device.index, -1), s.serial)
+            with _PRED_LOCK:
+                _LAST_DIFFERENTIATED[device.index] = max(_LAST_DIFFERENTIATED.get(device.index, -1), s.serial)
         skey = (device.index, int(stream))
         sc = _SCRATCH.pop(skey, None) or _StreamScratch()     # re-cached only after a successful call (an exception drops it)
         acc = None
@@ -586,7 +603,7 @@ def backward_raw(s: _State, dL_dcolor, dL_ddepth, dL_dnorm, dL_dalpha, sinks=Non
         if want_t and USE_TEX_BINS and s.tensors.get("tex_bin_count") is not None:
             bins = sc.bins if (sc.bins is not None and sc.bins.R == R) else _TexBins(lib, device, R)
             sc.bins = None
-            bins.before_call(s.D)
+            bins.before_call(s.D, s.tensors.get("tex_bin_count"))
         grads = _lib.Grads(_ptr(dc), _ptr(dd), _ptr(dn), _ptr(da), _ptr(acc), _ptr(outs.get("means3D")), _ptr(outs.get("means2D")),
                            _ptr(outs.get("shs")), _ptr(outs.get("opacities")), _ptr(outs.get("scales")), _ptr(outs.get("rotations")),
                            _ptr(outs.get("uvs")), _ptr(d_tex), _ptr(outs.get("color_offset")), _ptr(outs.get("cov3D")), want,

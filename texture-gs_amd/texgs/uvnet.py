@@ -90,8 +90,13 @@ def pack_tcnn_params(layers, n_in, n_out, width=HIDDEN):
 class UVNet(nn.Module):
     """pre_mlp: 3 -> 128 -> emb_dim(128); relu(. + emb); mlp: 128 -> 128 -> 128 -> 3; F.normalize  (configs/*.yaml uv_net_cfg)."""
 
-    def __init__(self, xyz_offset=None, xyz_scale=None):
+    def __init__(self, xyz_offset=None, xyz_scale=None, precision="fp32"):
         super().__init__()
+        # arithmetic of the fused kernel's three 128x128 layers: "fp32" = f32-input MFMA (exact f32 products; the checked default),
+        # "bf16x3" = every operand split into two bf16 halves, three bf16 MFMAs per product (~2.5x faster, uvs / J within ~2e-5)
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        self.precision = precision
         self.pre_mlp = _mlp(1, 3, HIDDEN)
         self.mlp = _mlp(2, HIDDEN, 3)
         # device-resident (buffers follow .to() / .cuda()): the reference moves them to the device on every call (uv_net.py:23-24)
@@ -173,7 +178,9 @@ class UVNet(nn.Module):
         p = lambda t: None if t is None else t.data_ptr()
         net = _lib.UVNetStruct(*[p(t) for t in ws], HIDDEN)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        key = tuple((t.data_ptr(), t._version) for t in (self.pre_mlp[2].weight, self.mlp[0].weight, self.mlp[2].weight)) + (dev,)
+        split = self.precision == "bf16x3"
+        pack_fn, eval_fn = (lib.texgs_uv_pack_bf16x3, lib.texgs_uv_taylor_packed_bf16x3) if split else (lib.texgs_uv_pack, lib.texgs_uv_taylor_packed)
+        key = tuple((t.data_ptr(), t._version) for t in (self.pre_mlp[2].weight, self.mlp[0].weight, self.mlp[2].weight)) + (dev, split)
         uvs = torch.empty(N, 3, dtype=torch.float32, device=dev)
         juv = torch.empty(N, 9, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -181,10 +188,9 @@ class UVNet(nn.Module):
             ent = self._packed.get(slot)
             if ent is None or ent[0] != key:
                 buf = ent[1] if ent is not None else torch.empty(lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)
-                _lib.check(lib.texgs_uv_pack(C.byref(net), p(buf), stream), "texgs_uv_pack")       # (re-packed in place: same stream, in order)
+                _lib.check(pack_fn(C.byref(net), p(buf), stream), "texgs_uv_pack")       # (re-packed in place: same stream, in order)
                 self._packed[slot] = ent = (key, buf)
-            _lib.check(lib.texgs_uv_taylor_packed(C.byref(net), p(ent[1]), p(x), N, p(uvs), p(juv), stream),
-                       "texgs_uv_taylor_packed")
+            _lib.check(eval_fn(C.byref(net), p(ent[1]), p(x), N, p(uvs), p(juv), stream), "texgs_uv_taylor_packed")
         return uvs, juv
 
     def uvs_and_jacobian_with_grad(self, xyz, emb):
