@@ -144,7 +144,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import bench_iteration
         if rank == 0:
-            res = bench_iteration.run(N, R, W, H, iters=max(args.steps, 4), warm=max(args.warmup, 2), dev_index=dev_index)
+            res = bench_iteration.run(N, R, W, H, iters=max(args.steps, 4), warm=max(args.warmup, 2), dev_index=dev_index,
+                                      precision=os.environ.get("TEXGS_UV_PRECISION", "fp32"))
             print(json.dumps({"metric": f"reference training iteration (texture stage), ms per iteration ({args.workload})",
                               "value": res["uv_once_ms_per_iteration"], "unit": "ms/iteration", "higher_is_better": False, "n_gpus": 1,
                               "dtype": "f32", "data": "synthetic", **res}), flush=True)

@@ -457,10 +457,11 @@ void texgs_ref_render_fwd(const RefIn *in, const float *rec, const uint32_t *poi
  *                tau_relu of the colour clamp;
  *   tflag[6RR]   same for a texel: tapped by a contributor of a forward-ambiguous pixel or by a pair within tau_relu of the clamp. */
 void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
-                            float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag, float *cond);
+                            float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag, float *cond,
+                            int own_only);
 void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                          float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag) {
-    texgs_ref_ambiguity_ex(in, rec, point_list, ranges, tau_fwd, tau_cell, tau_relu, margin, gflag, tflag, NULL);
+    texgs_ref_ambiguity_ex(in, rec, point_list, ranges, tau_fwd, tau_cell, tau_relu, margin, gflag, tflag, NULL, 0);
 }
 /* _ex: also cond[H*W] (may be NULL) = sum over the pixel's contributors of w_i * (|A dx^2| / 2 + |C dy^2| / 2 + |B dx dy|) * 2^-23 --
  * the rounding error of the falloff exponent `power` in fp32, carried to the blend weights.  `power` is a difference of terms that
@@ -469,9 +470,14 @@ void texgs_ref_ambiguity(const RefIn *in, const float *rec, const uint32_t *poin
  * relative, whatever the implementation.  The tests widen a pixel's tolerance by a small multiple of cond (negligible -- ~1e-7 --
  * on the benchmark scenes, whose splats are ~10 px), and the alpha / T decisions below count as ambiguous when their margin is
  * inside that same uncertainty.  Rows (gflag / tflag) are flagged for pixels whose 1/255, power, face or den decisions are
- * ambiguous -- NOT for a T-stop alone: what a marginal stop adds or removes carries a weight below 2e-4 of the pixel. */
+ * ambiguous -- NOT for a T-stop alone: what a marginal stop adds or removes carries a weight below 2e-4 of the pixel.
+ * own_only (the pair-level checks): a marginal alpha >= 1/255 decision flags only the row of the Gaussian whose decision it is --
+ * the pixel's OTHER contributors see their transmittance change by 1/255 when it flips, which texgs_ref_render_bwd_ex books as
+ * mass (2/255 of each of their terms) instead of excusing their rows; power ~ 0, face and den decisions still flag every
+ * contributor of the pixel (rare). */
 void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
-                            float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag, float *cond) {
+                            float tau_fwd, float tau_cell, float tau_relu, float *margin, uint8_t *gflag, uint8_t *tflag, float *cond,
+                            int own_only) {
     const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gxn * gyn; ++tile) {
@@ -481,12 +487,13 @@ void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *p
             const int px = tx0 + lx, py = ty0 + ly;
             if (px >= W || py >= H) continue;
             const float pxf = (float)px, pyf = (float)py;
-            float mpix = INFINITY, mpix_hard = INFINITY, cpix = 0.0f;
+            float mpix = INFINITY, mpix_hard = INFINITY, mpix_strict = INFINITY, cpix = 0.0f;
             for (int pass = 0; pass < 2; ++pass) {
                 /* pass 0: the pixel's margin.  pass 1: flags; in a forward-ambiguous pixel everything that contributes -- or is
                    within tau_fwd of contributing, or comes after a T-threshold stop that is within tau_fwd of not happening --
                    may carry a different gradient */
                 const int pix_amb = (pass == 1) && (mpix_hard < tau_fwd);       /* (a T-stop alone does not flag rows) */
+                const int pix_strict = (pass == 1) && (mpix_strict < tau_fwd);  /* a power ~ 0, face or den decision */
                 int past_marginal_stop = 0;
                 float T = 1.0f, tunc = 0.0f;        /* tunc: relative uncertainty of T so far (sum of its factors' uncertainties) */
                 for (uint32_t k = r0; k < r1; ++k) {
@@ -497,9 +504,13 @@ void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *p
                     float m = INFINITY;
                     /* uncertainty of `power` itself (absolute) = of alpha (relative): a few roundings of its largest term */
                     const float pu = 4.0f * 5.9604645e-8f * (0.5f * fabsf(r[2] * dx * dx) + 0.5f * fabsf(r[4] * dy * dy) + fabsf(r[3] * dx * dy));
-                    if (fabsf(power) < 1e-5f + pu) m = 0.0f;
+                    /* power > 0 skips the instance; mathematically power <= 0, so the decision can only differ where |power| is inside
+                       its own rounding error (until round 5 a blanket 1e-5: every pixel within ~0.01 px of a splat centre) */
+                    if (fabsf(power) <= 4.0f * pu + 1e-20f) m = 0.0f;
+                    float m_strict = m;
                     const float araw = r[5] * expf(power);
                     if (power <= 0.0f || m == 0.0f) m = fminf(m, fmaxf(0.0f, fabsf(araw - ALPHA_MIN) / ALPHA_MIN - pu));
+                    const float m_own = m;                  /* this instance's own power / alpha decisions */
                     float m_hard = m;
                     const int pass_alpha = (power <= 0.0f) && (fminf(ALPHA_MAX, araw) >= ALPHA_MIN);
                     int contributes = pass_alpha;
@@ -529,15 +540,17 @@ void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *p
                             m = fminf(m, (a0 - a1) / fmaxf(a0, MA_MIN));
                             m = fminf(m, fabsf(den - DEN_MIN));
                             m_hard = fminf(m_hard, fminf((a0 - a1) / fmaxf(a0, MA_MIN), fabsf(den - DEN_MIN)));
+                            m_strict = fminf(m_strict, fminf((a0 - a1) / fmaxf(a0, MA_MIN), fabsf(den - DEN_MIN)));
                         }
                         mpix = fminf(mpix, m);
                         mpix_hard = fminf(mpix_hard, m_hard);
+                        mpix_strict = fminf(mpix_strict, m_strict);
                     } else {
                         const int marginal = pix_amb && (m < tau_fwd || past_marginal_stop);      /* may contribute on the other side */
                         if ((contributes || marginal) && !in->tex) {
                             float m_relu = INFINITY;
                             for (int ch = 0; ch < 3; ++ch) m_relu = fminf(m_relu, fabsf(r[17 + ch] + 0.5f));
-                            if (pix_amb || m_relu < tau_relu) gflag[id] = 1;
+                            if ((own_only ? (pix_strict || (pix_amb && m_own < tau_fwd)) : pix_amb) || m_relu < tau_relu) gflag[id] = 1;
                         } else if (contributes || marginal) {
                             const float dpx = -dx, dpy = -dy;
                             const float den = 1.0f + r[6] * dpx + r[7] * dpy;
@@ -555,7 +568,7 @@ void texgs_ref_ambiguity_ex(const RefIn *in, const float *rec, const uint32_t *p
                                 m_relu = fminf(m_relu, fabsf(SH_C0 * tv + r[17 + ch] + 0.5f));
                             }
                             const float m_cell = fminf(fminf(ct.fx, 1.0f - ct.fx), fminf(ct.fy, 1.0f - ct.fy));
-                            if (pix_amb || m_cell < tau_cell || m_relu < tau_relu) gflag[id] = 1;
+                            if ((own_only ? (pix_strict || (pix_amb && m_own < tau_fwd)) : pix_amb) || m_cell < tau_cell || m_relu < tau_relu) gflag[id] = 1;
                             if (pix_amb || m_relu < tau_relu) {
                                 tflag[ct.o00 / 3] = 1; tflag[ct.o01 / 3] = 1; tflag[ct.o10 / 3] = 1; tflag[ct.o11 / 3] = 1;
                             }
@@ -590,15 +603,19 @@ static void atomic_addd(double *p, double v) {
  * having one such pair among its hundreds. */
 void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                              const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
-                             float tau_cell, float cell_weight, float tex_slope, double *fmass);
+                             float tau_cell, float cell_weight, float tex_slope, double *fmass, const float *margin, float tau_fwd);
 void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                           const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex) {
-    texgs_ref_render_bwd_ex(in, rec, point_list, ranges, final_T, n_contrib, dout, acc, dtex, 0.0f, 0.0f, 0.0f, NULL);
+    texgs_ref_render_bwd_ex(in, rec, point_list, ranges, final_T, n_contrib, dout, acc, dtex, 0.0f, 0.0f, 0.0f, NULL, NULL, 0.0f);
 }
-/* (tex_slope: unused since the mass is the exact change under a switch to the neighbouring cell.) */
+/* tex_slope: (re-used argument) tau_relu for the pair-level treatment of the colour clamp, 0 = off.
+ * margin / tau_fwd (optional, with fmass): in a pixel whose forward decisions are within tau_fwd of flipping (texgs_ref_ambiguity's
+ * map) a contributor may appear or vanish with alpha ~ 1/255 -- every OTHER pair of the pixel then sees its transmittance, and with
+ * it all of its terms, move by at most 1/255: 2/255 of each term is booked as mass.  (The row of the marginal Gaussian itself is
+ * the one texgs_ref_ambiguity_ex(own_only) flags.) */
 void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                              const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
-                             float tau_cell, float cell_weight, float tex_slope, double *fmass) {
+                             float tau_cell, float cell_weight, float tex_slope, double *fmass, const float *margin, float tau_fwd) {
     const int W = in->W, H = in->H, gxn = (W + TILE - 1) / TILE, gyn = (H + TILE - 1) / TILE, HW = W * H;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gxn * gyn; ++tile) {
@@ -694,6 +711,45 @@ void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *
                 }
                 double *ap = acc + (size_t)id * REC;
                 for (int k = 0; k < REC; ++k) if (part[k] != 0.f) atomic_addd(ap + k, (double)part[k]);
+                if (fmass && tex_slope > 0.0f) {
+                    /* colour clamp max(0, pre) within tex_slope (= tau_relu) of switching for a channel: the pair's colour gradient of
+                       that channel is all or nothing -- w dL/dcolour for the view-dependent slots, and through C0 the texture's
+                       derivative for the uv slots (bounded with absolute values) */
+                    float dcol_b = 0.f, drow_b = 0.f; int any = 0;
+                    double *fp = fmass + (size_t)id * REC;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        if (fabsf(pre[ch]) >= tex_slope) continue;
+                        any = 1;
+                        const float pot = fabsf(w * dpix[ch]);
+                        if (pot != 0.f) atomic_addd(fp + 17 + ch, (double)pot);
+                        if (textured) {
+                            dcol_b += SH_C0 * pot * fabsf((1.f - ct.fy) * (t01[ch] - t00[ch]) + ct.fy * (t11[ch] - t10[ch]));
+                            drow_b += SH_C0 * pot * fabsf((1.f - ct.fx) * (t10[ch] - t00[ch]) + ct.fx * (t11[ch] - t01[ch]));
+                        }
+                    }
+                    if (any && textured) {
+                        const float ea = dcol_b * ct.h, eb = drow_b * ct.h, em = (dcol_b * fabsf(ct.sc) + drow_b * fabsf(ct.tc)) * ct.h * ct.rma;
+                        float e0, e1, e2;
+                        if (ct.axis == 0) { e0 = em; e2 = ea; e1 = eb; } else if (ct.axis == 1) { e1 = em; e0 = ea; e2 = eb; } else { e2 = em; e0 = ea; e1 = eb; }
+                        float q[REC]; memset(q, 0, sizeof(q)); float q0 = 0.f, q1 = 0.f;
+                        q[14] = e0; q[15] = e1; q[16] = e2;
+                        if (good) {
+                            const float n0 = e0 * inv, n1 = e1 * inv, n2 = e2 * inv;
+                            const float dd = (e0 * fabsf(nu0) + e1 * fabsf(nu1) + e2 * fabsf(nu2)) * inv * inv;
+                            q[8] = n0 * fabsf(dpx); q[9] = n0 * fabsf(dpy); q[10] = n1 * fabsf(dpx); q[11] = n1 * fabsf(dpy);
+                            q[12] = n2 * fabsf(dpx); q[13] = n2 * fabsf(dpy); q[6] = dd * fabsf(dpx); q[7] = dd * fabsf(dpy);
+                            q0 = (fabsf(r[8]) * n0 + fabsf(r[10]) * n1 + fabsf(r[12]) * n2) + fabsf(r[6]) * dd;
+                            q1 = (fabsf(r[9]) * n0 + fabsf(r[11]) * n1 + fabsf(r[13]) * n2) + fabsf(r[7]) * dd;
+                        }
+                        for (int k = 6; k < 17; ++k) if (q[k] != 0.f) atomic_addd(fp + k, (double)q[k]);
+                        if (q0 != 0.f) atomic_addd(fp + 0, (double)q0);
+                        if (q1 != 0.f) atomic_addd(fp + 1, (double)q1);
+                    }
+                }
+                if (fmass && margin && margin[pix] < tau_fwd) {
+                    double *fp = fmass + (size_t)id * REC;
+                    for (int k = 0; k < REC; ++k) if (part[k] != 0.f) atomic_addd(fp + k, (double)((2.0f / 255.0f) * fabsf(part[k])));
+                }
                 if (fmass && textured && fminf(fminf(ct.fx, 1.0f - ct.fx), fminf(ct.fy, 1.0f - ct.fy)) < tau_cell) {
                     /* What would this pair contribute had the sample been taken in the NEIGHBOURING bilinear cell (the sample value
                        is the same there -- bilinear interpolation is continuous -- its uv-derivative is not)?  The uv terms are
@@ -739,7 +795,7 @@ void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *
                     for (int k = 6; k < 17; ++k) if (mass[k] != 0.f) atomic_addd(fp + k, (double)(cell_weight * mass[k]));
                     if (m_uv0 != 0.f) atomic_addd(fp + 0, (double)(cell_weight * m_uv0));
                     if (m_uv1 != 0.f) atomic_addd(fp + 1, (double)(cell_weight * m_uv1));
-                    (void)tex_slope; (void)uv0; (void)uv1;
+                    (void)uv0; (void)uv1;
                 }
             }
         }

@@ -126,22 +126,23 @@ class RefRun:
                                  _p(self.final_T), _p(self.n_contrib))
         return self.out
 
-    def backward(self, dout, tau_cell=0.0, cell_weight=1.0):
+    def backward(self, dout, tau_cell=0.0, cell_weight=1.0, margin=None, tau_fwd=0.0, tau_relu=0.0):
         """dout: float32 [8,H,W] (r,g,b,depth,nx,ny,nz,alpha).  Returns dict of input gradients.
         tau_cell > 0: also collects self.fmass [N,24] -- per Gaussian, the absolute mass of the terms that hang on a bilinear cell
-        choice within tau_cell texels of flipping (texgs_ref_render_bwd_ex) -- for cell_edge_deviation()."""
+        choice within tau_cell texels of flipping (texgs_ref_render_bwd_ex) -- for cell_edge_deviation().  margin [H,W] (from
+        ambiguity()) + tau_fwd: also 2/255 of every term of the pairs in forward-ambiguous pixels (a marginal contributor flipping
+        moves the others' transmittance by 1/255).  tau_relu > 0: also the all-or-nothing colour gradient of pairs whose
+        max(0, .) argument is within tau_relu of zero (then ambiguity() need not flag their rows: pass it tau_relu=0)."""
         N, K, R, lib = self.N, self.K, self.R, self.lib
         dout = np.ascontiguousarray(dout.astype(np.float32))
         acc = np.zeros((max(N, 1), REC), np.float64)
         dtex = np.zeros((6, R, R, 3), np.float32) if self.textured else None
         self.fmass = np.zeros((max(N, 1), REC), np.float64) if tau_cell > 0 else None
-        slope = 0.0
-        if tau_cell > 0 and self.textured:          # typical texel-to-texel step of this texture (white noise N(0, 1): ~1.1)
-            t = self.arr["tex"]
-            slope = float(max(np.abs(np.diff(t[0], axis=0)).mean(), np.abs(np.diff(t[0], axis=1)).mean()))
+        slope = float(tau_relu)          # (the C argument `tex_slope` carries tau_relu of the pair-level colour-clamp treatment; 0 = off)
         lib.texgs_ref_render_bwd_ex(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(self.final_T),
                                     _p(self.n_contrib), _p(dout), _p(acc), _p(dtex), C.c_float(tau_cell), C.c_float(cell_weight),
-                                    C.c_float(slope), _p(self.fmass))
+                                    C.c_float(slope), _p(self.fmass),
+                                    _p(None if margin is None else np.ascontiguousarray(margin, np.float32)), C.c_float(tau_fwd))
         g = self._k8(acc, self._grad_arrays())
         g["texture"] = dtex
         self.acc = acc
@@ -210,7 +211,7 @@ class RefRun:
         g["texture"] = dtex
         return out, nc, g
 
-    def ambiguity(self, tau_fwd=2e-5, tau_cell=1e-4, tau_relu=1e-5):
+    def ambiguity(self, tau_fwd=2e-5, tau_cell=1e-4, tau_relu=1e-5, own_only=False):
         """After forward(): (margin[H,W], gflag[N] bool, tflag[6,R,R] bool) -- where two fp32 implementations of the operator may
         legitimately differ by more than rounding (texgs_ref_ambiguity in texgs_ref.c says which decisions are looked at)."""
         margin = np.full((self.H, self.W), np.inf, np.float32)
@@ -221,7 +222,7 @@ class RefRun:
         self.cond = np.zeros((self.H, self.W), np.float32)
         self.lib.texgs_ref_ambiguity_ex(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges),
                                         C.c_float(tau_fwd), C.c_float(tau_cell), C.c_float(tau_relu), _p(margin), _p(gflag), _p(tflag),
-                                        _p(self.cond))
+                                        _p(self.cond), C.c_int(1 if own_only else 0))
         return margin, gflag[:self.N].astype(bool), tflag.reshape(6, self.R, self.R).astype(bool)
 
     @property

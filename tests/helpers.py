@@ -324,16 +324,18 @@ def band_limited_parity(label, scene, cam, bg, seed=9, flagged_frac_max=0.05):
     dev = outs[0].device
     res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(), dout[4:7].to(dev).contiguous(),
                        dout[7:8].to(dev).contiguous())
-    gref = ref.backward(dout.numpy(), tau_cell=tau_cell(R), cell_weight=BAND_LIMITED_CELL_WEIGHT)
+    _, hard, _ = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=0.0, tau_relu=0.0, own_only=True)
+    gref = ref.backward(dout.numpy(), tau_cell=tau_cell(R), cell_weight=BAND_LIMITED_CELL_WEIGHT, margin=margin, tau_fwd=TAU_FWD,
+                        tau_relu=1e-5)
     cdev = ref.cell_edge_deviation()
     sens = ref.accumulation_sensitive()
     report(f"{label}/bwd/accumulation_sensitive_rows", rows=int(sens.sum()), frac=float(sens.mean()))
-    gflag = gflag | sens
+    hard = hard | sens
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
         if name_ == "texture":
             grad_attributed(f"{label}/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]), tflag, flagged_frac_max=flagged_frac_max)
         else:
-            r = grad_mass_attributed(f"{label}/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]), gflag, cdev[name_],
+            r = grad_mass_attributed(f"{label}/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]), hard, cdev[name_],
                                      hard_frac_max=flagged_frac_max)
             assert r["rows_with_tolerance_more_than_doubled_frac"] < flagged_frac_max, (name_, r)
 
@@ -341,9 +343,9 @@ def band_limited_parity(label, scene, cam, bg, seed=9, flagged_frac_max=0.05):
 def pair_level_gradient_check(label, ref, res, dout, R, sens):
     """The white-noise runs, per-Gaussian gradients at PAIR level (grad_mass_attributed): `ref` a C-oracle run after forward(),
     `res` the HIP backward's 8 gradients for upstream `dout`."""
-    gref = ref.backward(dout.numpy(), tau_cell=tau_cell(R), cell_weight=1.0)
+    margin, hard, _ = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=0.0, tau_relu=0.0, own_only=True)
+    gref = ref.backward(dout.numpy(), tau_cell=tau_cell(R), cell_weight=1.0, margin=margin, tau_fwd=TAU_FWD, tau_relu=tau_relu(R))
     cdev = ref.cell_edge_deviation()
-    _, hard, _ = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=0.0, tau_relu=tau_relu(R))
     hard = hard | sens
     for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs"], res[:7]):
         grad_mass_attributed(f"{label}/{name_}", got_g.cpu(), torch.tensor(gref[name_]), hard, cdev[name_])

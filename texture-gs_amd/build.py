@@ -29,7 +29,8 @@ UNITS = {
     "uvnet.hip": [],
     "abi.hip": [],
 }
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "texgs.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wave_ops.h"), os.path.join(CSRC, "render_bwd_body.h"),
+           os.path.join(ROOT, "include", "texgs.h")]
 
 
 def _newer(src_list, target):
