@@ -19,7 +19,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["render.hip", "preprocess.hip", "binning.hip", "common.h", "wave_ops.h"]
+KERNEL_SOURCES = ["render.hip", "render_bwd_body.h", "preprocess.hip", "binning.hip", "common.h", "wave_ops.h"]
 
 
 def source_hash():
