@@ -136,8 +136,8 @@ int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint3
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RB_MAX_DEVICES) return fail_msg("hipGetDevice failed");
     Readback& g_rb = g_rb_dev[dev];
-    // K1 left five words per workgroup (three partial sums + the depth-key range the device-side sort uses; no atomics, nothing to
-    // zero-fill): copy them, add the sums up here
+    // K1 left five words per workgroup (three partial sums + the depth-key range, which only the device-side sort reads; no atomics,
+    // nothing to zero-fill): copy the three sums (3 * nblk words), add them up here
     const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK, nw = 3 * nblk;
     if (g_rb.words < nw) {
         if (g_rb.host) (void)hipHostFree(g_rb.host);
