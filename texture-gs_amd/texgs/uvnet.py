@@ -202,6 +202,21 @@ class UVNet(nn.Module):
         return uvs, juv
 
 
+def _tn(a, b, chunk=2048):
+    """a^T b for tall a [N, m], b [N, n] (weight gradients: N = 300 000 points, m, n <= 128).  As ONE GEMM this is a 128 x 128
+    output with K = N: the library runs it on a handful of CUs (measured: the five of them were ~8 of the 10.5 ms of an iteration's
+    backward).  As a batch of N / chunk products summed afterwards it fills the chip."""
+    N = a.shape[0]
+    if N < 8 * chunk:
+        return a.t() @ b
+    B = N // chunk
+    main = B * chunk
+    out = torch.bmm(a[:main].view(B, chunk, a.shape[1]).transpose(1, 2), b[:main].view(B, chunk, b.shape[1])).sum(0)
+    if main < N:
+        out = out + a[main:].t() @ b[main:]
+    return out
+
+
 def uvnet_backward(xn, emb, weights, biases, g, inv_scale=None):
     """Gradients of uvs = normalize(MLP(xn)) w.r.t. (xn, emb, weights, biases) for an upstream gradient g [N,3], by hand: the
     activations are recomputed with five GEMMs, the chain rule is six more.  Pure torch (runs anywhere; tests run it in
@@ -217,15 +232,15 @@ def uvnet_backward(xn, emb, weights, biases, g, inv_scale=None):
     n = o.norm(dim=1, keepdim=True).clamp_min(1e-12)
     u = o / n
     do = (g - u * (u * g).sum(dim=1, keepdim=True)) / n                 # F.normalize backward
-    dW5 = do.t() @ h3; db5 = do.sum(0)
+    dW5 = _tn(do, h3); db5 = do.sum(0)
     d4 = (do @ W5) * (z4 > 0)
-    dW4 = d4.t() @ h2; db4 = d4.sum(0)
+    dW4 = _tn(d4, h2); db4 = d4.sum(0)
     d3 = (d4 @ W4) * (z3 > 0)
-    dW3 = d3.t() @ a; db3 = d3.sum(0)
+    dW3 = _tn(d3, a); db3 = d3.sum(0)
     d2 = (d3 @ W3) * (z2 > 0)
-    dW2 = d2.t() @ h1; db2 = d2.sum(0); demb = db2
+    dW2 = _tn(d2, h1); db2 = d2.sum(0); demb = db2
     d1 = (d2 @ W2) * (z1 > 0)
-    dW1 = d1.t() @ xn; db1 = d1.sum(0)
+    dW1 = _tn(d1, xn); db1 = d1.sum(0)
     dxn = d1 @ W1
     return dxn, demb, [dW1, dW2, dW3, dW4, dW5], [db1, db2, db3, db4, db5]
 
