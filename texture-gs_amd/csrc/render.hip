@@ -231,6 +231,9 @@ __device__ __forceinline__ void init_dummy(Planes& P, int lane) {
 // of every contributing (pixel, Gaussian) pair is added by the dense phase into the pixel's LDS accumulator as Q32.32
 // fixed point with integer atomics -- the sum is order-independent, so it equals the in-order blend and is bit-reproducible.
 #define FQ_CAP 128
+#ifndef K6_UNROLL2
+#define K6_UNROLL2 1
+#endif
 struct __attribute__((aligned(16))) FwdLds {
     Planes p;                           // 6768 B
     uint2 q[FQ_CAP];                    // 1024: dense-phase queue {w, key}
@@ -424,6 +427,65 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         // ---- lock-step test loop: iteration t tests list entry t of every quadrant.  Parameters of iteration t + 1 and the
         // list entry of t + 2 are in flight while t is evaluated.
         int tmax = max(max(len[0], len[1]), max(len[2], len[3]));
+        // one tested list entry per quadrant; returns true when every pixel of the block is done
+        auto test_one = [&](const float4& A, const float4& B, const float4& Cc, const int j) -> bool {
+                // One exit per tested instance: alpha is evaluated for every candidate that survived the culls.  Wave-level decisions
+                // are PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask and the combination is
+                // scalar ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip.
+                const float power = gauss_power(A.z, A.w, B.x, A.x - pxf, A.y - pyf);
+                const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(B.y, power));
+                const ull m_ok = TG_BALLOT(power <= 0.0f) & ~done_mask & TG_BALLOT(alpha >= TG_ALPHA_MIN);
+                if (m_ok == 0ull) return false;
+                bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
+                const float Tn = T * (1.0f - alpha);
+                const ull m_kill = m_ok & TG_BALLOT(Tn < TG_T_EPS);
+                if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
+                done_mask |= m_kill;
+                const ull bal = m_ok & ~m_kill;
+                if (bal != 0ull) {
+                    if (ok) {
+                        const float w = alpha * T;
+                        Dp += w * Cc.x; N0 += w * Cc.y; N1 += w * Cc.z; N2 += w * Cc.w; Al += w;
+                        T = Tn;
+                        last = __float_as_uint(B.z) + 1u;
+                        L.q[(qtail + mbcnt64(bal)) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), keybase | (uint32_t)j);
+                    }
+                    qtail += __popcll(bal);
+                    if (qtail - qhead >= 64) {
+                        __builtin_amdgcn_wave_barrier();
+                        drain(64);
+                        qhead += 64;
+                    }
+                }
+                if (m_kill != 0ull) {               // some pixels finished: quadrants whose 16 pixels are all done stop walking their lists
+                    if (~done_mask == 0ull) { all_done = true; return true; }
+                    int tm = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (((done_mask >> (16 * q)) & 0xFFFFull) != 0xFFFFull) tm = max(tm, len[q]);
+                    tmax = tm;
+                }
+            return false;
+        };
+#if K6_UNROLL2
+        // Two register sets, used and refilled alternately: set X holds the even entries, set Y the odd ones; while one is evaluated
+        // the other is loaded (one iteration ahead), the list index two ahead.  (One set rotated through a "next" copy cost eight
+        // 64-bit register moves per iteration: a fifth of the loop's VALU instructions.)
+        int jx = mylist[0], jy = mylist[1];
+        float4 xA = L.p.A[jx], xB = L.p.B[jx], xC = L.p.C[jx];
+        float4 yA = xA, yB = xB, yC = xC;
+        for (int t = 0; t < tmax; t += 2) {
+            yA = L.p.A[jy]; yB = L.p.B[jy]; yC = L.p.C[jy];
+            const int j0 = jx;
+            jx = mylist[min(t + 2, 63)];
+            if (test_one(xA, xB, xC, j0)) break;
+            if (t + 1 >= tmax) break;
+            xA = L.p.A[jx]; xB = L.p.B[jx]; xC = L.p.C[jx];
+            const int j1 = jy;
+            jy = mylist[min(t + 3, 63)];
+            if (test_one(yA, yB, yC, j1)) break;
+        }
+#else
         int cj = mylist[0], nj = mylist[1], nnj = mylist[2];
         float4 cA = L.p.A[cj], cB = L.p.B[cj], cC = L.p.C[cj];
         float4 nA = L.p.A[nj], nB = L.p.B[nj], nC = L.p.C[nj];
@@ -434,43 +496,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             nj = nnj;
             nA = L.p.A[nj]; nB = L.p.B[nj]; nC = L.p.C[nj];
             nnj = mylist[min(t + 3, 63)];
-            // One exit per tested instance: alpha is evaluated for every candidate that survived the culls.  Wave-level decisions
-            // are PRODUCTS of single-compare ballots: a ballot of one compare is the v_cmp's own lane mask and the combination is
-            // scalar ALU; a ballot of a compound predicate costs a v_cndmask + v_cmp round trip.
-            const float power = gauss_power(A.z, A.w, B.x, A.x - pxf, A.y - pyf);
-            const float alpha = fminf(TG_ALPHA_MAX, gauss_alpha_raw(B.y, power));
-            const ull m_ok = TG_BALLOT(power <= 0.0f) & ~done_mask & TG_BALLOT(alpha >= TG_ALPHA_MIN);
-            if (m_ok == 0ull) continue;
-            bool ok = (!done) && (power <= 0.0f) && (alpha >= TG_ALPHA_MIN);
-            const float Tn = T * (1.0f - alpha);
-            const ull m_kill = m_ok & TG_BALLOT(Tn < TG_T_EPS);
-            if (ok && Tn < TG_T_EPS) { done = true; ok = false; }
-            done_mask |= m_kill;
-            const ull bal = m_ok & ~m_kill;
-            if (bal != 0ull) {
-                if (ok) {
-                    const float w = alpha * T;
-                    Dp += w * Cc.x; N0 += w * Cc.y; N1 += w * Cc.z; N2 += w * Cc.w; Al += w;
-                    T = Tn;
-                    last = __float_as_uint(B.z) + 1u;
-                    L.q[(qtail + mbcnt64(bal)) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), keybase | (uint32_t)j);
-                }
-                qtail += __popcll(bal);
-                if (qtail - qhead >= 64) {
-                    __builtin_amdgcn_wave_barrier();
-                    drain(64);
-                    qhead += 64;
-                }
-            }
-            if (m_kill != 0ull) {               // some pixels finished: quadrants whose 16 pixels are all done stop walking their lists
-                if (~done_mask == 0ull) { all_done = true; break; }
-                int tm = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (((done_mask >> (16 * q)) & 0xFFFFull) != 0xFFFFull) tm = max(tm, len[q]);
-                tmax = tm;
-            }
+            if (test_one(A, B, Cc, j)) break;
         }
+#endif
         // items reference this chunk's LDS planes: start them before the next chunk is loaded
         if (qtail - qhead > 0) {
             __builtin_amdgcn_wave_barrier();

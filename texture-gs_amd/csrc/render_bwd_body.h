@@ -330,10 +330,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         // ================================================================ stage A (lock-step test loop) of ONE segment, items -> L.abuf
         auto stage_a = [&](Seg& sg) {
             sg.n_it = 0; sg.n_items = 0; sg.it_lo = 0u; sg.it_hi = 0u; sg.it_first = 0u;
-            int cj = mylist[min(t, 63)], nj = mylist[min(t + 1, 63)], nnj = mylist[min(t + 2, 63)];
-            float4 cA = L.p.A[cj], cB = L.p.B[cj];
-            float4 nA = L.p.A[nj], nB = L.p.B[nj];
-            while (t < tmax && sg.n_it < BWD_MAX_IT) {
+            // one tested list entry per quadrant; returns true when the segment is full (the entry is tested again in the next one)
+            auto test_one = [&](const float4& cA, const float4& cB, const int cj) -> bool {
                 const float power = gauss_power(cA.z, cA.w, cB.x, cA.x - pxf, cA.y - pyf);
                 const float araw = gauss_alpha_raw(cB.y, power);
                 const float alpha = fminf(TG_ALPHA_MAX, araw);
@@ -342,7 +340,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 const ull bal = TG_BALLOT(power <= 0.0f) & TG_BALLOT(before) & TG_BALLOT(alpha >= TG_ALPHA_MIN);
                 const int nb = __popcll(bal);
                 if (nb != 0) {
-                    if (sg.n_items + nb > BQ_CAP) break;               // segment full; this iteration is re-tested in the next one
+                    if (sg.n_items + nb > BQ_CAP) return true;         // segment full; this iteration is re-tested in the next one
                     if (lane == sg.n_it) { sg.it_lo = (uint32_t)bal; sg.it_hi = (uint32_t)(bal >> 32); sg.it_first = (uint32_t)sg.n_items; }
                     if (ok) {
                         T = T * __builtin_amdgcn_rcpf(1.0f - alpha);     // v_rcp_f32 (1 ulp): an IEEE divide is ~10 VALU
@@ -350,11 +348,24 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                     }
                     sg.n_items += nb; ++sg.n_it;
                 }
+                return false;
+            };
+            // two register sets used and refilled alternately (no register rotation: see K6's loop)
+            int jx = mylist[min(t, 63)], jy = mylist[min(t + 1, 63)];
+            float4 xA = L.p.A[jx], xB = L.p.B[jx];
+            float4 yA = xA, yB = xB;
+            while (t < tmax && sg.n_it < BWD_MAX_IT) {
+                yA = L.p.A[jy]; yB = L.p.B[jy];
+                const int j0 = jx;
+                jx = mylist[min(t + 2, 63)];
+                if (test_one(xA, xB, j0)) break;
                 ++t;
-                cj = nj; cA = nA; cB = nB;
-                nj = nnj;
-                nA = L.p.A[nj]; nB = L.p.B[nj];
-                nnj = mylist[min(t + 2, 63)];
+                if (!(t < tmax && sg.n_it < BWD_MAX_IT)) break;
+                xA = L.p.A[jx]; xB = L.p.B[jx];
+                const int j1 = jy;
+                jy = mylist[min(t + 2, 63)];
+                if (test_one(yA, yB, j1)) break;
+                ++t;
             }
         };
         auto stage_c = [&](const Seg& sg) {
