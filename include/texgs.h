@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 12
+#define TEXGS_ABI_VERSION 13
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
 #define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
@@ -334,6 +334,23 @@ int texgs_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const floa
 int texgs_uv_pack_bf16x3(const TexGSUVNet* net, void* packed, void* stream);
 int texgs_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
                                   void* stream);
+
+/* Backward of the UV map (v13): gradients of uvs = UVNet(xyz) w.r.t. every weight, bias and the embedding for an upstream
+ * gradient g_uvs f32[N,3] -- what loss.backward() does through models/modules/uv_net.py:19-36 in the reference (autograd over
+ * five nn.Linear + F.normalize; reached from models/texture_gaussian3d.py:410 via `uvs`, :229-236).  ONE persistent kernel
+ * (activations recomputed per tile of 64 points in LDS, the three 128x128 weight gradients in registers, fp32 MFMA) + a
+ * deterministic reduction of its <= 256 partial sums.  Outputs are nn.Linear-shaped, OVERWRITTEN (not accumulated); a NULL
+ * pointer skips that gradient; d emb = db2 (the embedding is added where b2 is).  d xyz is not produced here: it is J^T g with
+ * the Jacobian texgs_uv_taylor already returned.  temp: texgs_uv_backward_temp_bytes(N) bytes. */
+typedef struct TexGSUVNetGrad {
+    float *dW1, *db1;          /* [128,3], [128]   */
+    float *dW2, *db2;          /* [128,128], [128] */
+    float *dW3, *db3, *dW4, *db4;
+    float *dW5, *db5;          /* [3,128], [3]     */
+} TexGSUVNetGrad;
+size_t texgs_uv_backward_temp_bytes(int32_t N);
+int texgs_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
+                      void* stream);
 
 /* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
  * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,

@@ -138,6 +138,23 @@ def run(N=300_000, R=1024, W=800, H=800, iters=12, warm=4, dev_index=0, precisio
     kt = _lib.profile_read()
     _lib.profile_enable(False)
     out["rasterizer_kernels_us_per_iteration"] = {n: round(1e3 * ms / 4, 1) for n, (ms, c) in kt.items() if c}
+    # the UV map's own backward, alone: the fused kernel against the per-layer library chain it replaced (same inputs)
+    from texgs.uvnet import uvnet_backward
+    gq = torch.randn(N, 3, device=dev) / N
+    lins = net._linears()
+    ws, bs = [l.weight.detach() for l in lins], [l.bias.detach() for l in lins]
+
+    def timed(fn, n=6):
+        fn(); torch.cuda.synchronize(dev)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        return round(1e3 * e0.elapsed_time(e1) / n, 1)
+    with torch.no_grad():
+        out["uvnet_backward_us"] = {"fused_hip_kernel": timed(lambda: net.backward_fused(xs, emb, gq)),
+                                    "library_gemm_chain": timed(lambda: uvnet_backward(net._norm_in(xs), emb.detach(), ws, bs, gq))}
     out["geometry_cache"] = RZ.geometry_cache_stats()
     out["uv_map_fit_mean_1_minus_cos"] = round(fit, 6)
     out["config"] = (f"N={N}, R={R}, {W}x{H}, sh_degree 3 then 0, UVNet 3-128-128|128-128-128-3 fitted to x/|x| (400 Adam steps), "

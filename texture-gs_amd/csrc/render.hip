@@ -582,22 +582,29 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 //           C3 pipelined 856 -> 903-926 views/s.  Used by every flavour that runs the per-Gaussian stages.
 //   lds  -- the round-4 shape (records in LDS planes, segments of 128 items, two rounds of taps in flight, 9 waves per CU): the
 //           texture-only flavour has no stage C to hide a dependent L2 round trip behind and is faster this way (405 vs 512 us).
+#ifndef K7_OCC_PREFETCH
+#define K7_OCC_PREFETCH 0
+#endif
 namespace k7_occ {
 #define BQ_CAP 64
 #define K7_GATHER 1
 #define K7_WAVES_PER_SIMD 4
+#define K7_PREFETCH K7_OCC_PREFETCH
 #include "render_bwd_body.h"
 #undef BQ_CAP
 #undef K7_GATHER
 #undef K7_WAVES_PER_SIMD
+#undef K7_PREFETCH
 }  // namespace k7_occ
 namespace k7_lds {
 #define BQ_CAP 128
 #define K7_GATHER 0
+#define K7_PREFETCH 0
 #define K7_WAVES_PER_SIMD 2
 #include "render_bwd_body.h"
 #undef BQ_CAP
 #undef K7_GATHER
+#undef K7_PREFETCH
 #undef K7_WAVES_PER_SIMD
 }  // namespace k7_lds
 

@@ -260,6 +260,335 @@ k_uv_taylor_bf16x3(UVArgsB a, const float* __restrict__ xyz, int N, float* __res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward (round 5)
+// Gradients of uvs = UVNet(xyz) w.r.t. every weight, bias and the embedding for an upstream gradient g [N,3]: what
+// loss.backward() does through models/modules/uv_net.py:19-36 in the reference (autograd over five Linear layers + F.normalize).
+// As library calls this is 14 tall-skinny GEMMs and ~30 elementwise passes over [N,128] tensors (5.5 ms of a 10 ms iteration at
+// N = 300 000); here it is ONE persistent kernel that keeps a tile of 64 points in LDS from the recomputed forward to the last
+// gradient and the three 128x128 weight gradients in registers across all of a workgroup's tiles:
+//     forward   h1 = relu(W1 x + b1) (VALU) | a = relu(W2 h1 + b2 + emb) | h2 = relu(W3 a + b3) | h3 = relu(W4 h2 + b4)   3 GEMMs
+//               o = W5 h3 + b5, u = o / |o|, do = (g - u (u.g)) / |o|                                                       VALU
+//     backward  d4 = (W5^T do) . [h3 > 0]  -> overwrites h3 in LDS            dW5 += do h3^T, db5 += do, db4 += d4           VALU
+//               d3 = (W4^T d4) . [h2 > 0]  -> overwrites h2                   dW4 += d4 h2^T                              2 GEMMs
+//               d2 = (W3^T d3) . [a  > 0]  -> overwrites a                    dW3 += d3 a^T,  db3 += d3                   2 GEMMs
+//               d1 = (W2^T d2) . [h1 > 0]  -> overwrites h1                   dW2 += d2 h1^T, db2 (= d emb) += d2         2 GEMMs
+//               dW1 += d1 x^T, db1 += d1                                                                                    VALU
+// (d phi / d xyz is not produced: the caller has the Jacobian from the forward launch, d xyz = J^T g.)
+// All nine GEMMs are v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate), 1152 per wave and tile.  Wave w owns output rows
+// [32 w, 32 w + 32): for W x and W^T d the A operand is its slice of the pre-packed (transposed) weights, 64 VGPRs, loaded one
+// GEMM AHEAD into a second register set (one wave per SIMD: nothing else would hide the L2 round trip); for d h^T the A operand
+// is the wave's rows of d and B the rows of h, both read point-major from LDS (row pitch 65 floats: conflict-free both ways).
+// LDS: four activation planes [128][65] f32 = 133 KB -> one workgroup per CU, launched as a persistent grid of <= 256 workgroups;
+// each writes its partial sums once (k_uv_backward_reduce adds the <= 256 partials: deterministic, no atomics).
+constexpr int BW_P = 64;             // points per tile
+constexpr int BW_PITCH = BW_P + 1;
+constexpr int BW_SMALL = 10;         // per-neuron vectors a thread accumulates: dW1[.][0..2], db1, db2, db3, db4, dW5[0..2][.]
+
+struct UVBwdArgs {
+    const float *W1, *b1, *b2, *emb, *b3, *b4, *W5, *b5, *off, *scale;
+    const float4* pk4;               // A operands of W2, W3, W4, W2^T, W3^T, W4^T (k_uv_pack_bwd)
+    const float* xyz;
+    const float* g;
+    int N, n_tiles;
+    float* partW;                    // [grid][3][128][128]   dW2, dW3, dW4
+    float* partS;                    // [grid][2][BW_SMALL][128]
+    float* partB5;                   // [grid][4]
+};
+
+// W2, W3, W4, W2^T, W3^T, W4^T in A-operand order, four k-steps per 16-byte load:
+//   pk4[m][band][g][lane] = (M_m[32 band + (lane & 31)][2 (4 g + j) + (lane >> 5)], j = 0..3),  M = W for m < 3, W^T for m >= 3
+__global__ void __launch_bounds__(256)
+k_uv_pack_bwd(const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ W4, float* __restrict__ pk) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 6 * 4 * 64 * 64) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 15, band = (idx >> 12) & 3, m = idx >> 14;
+    const int layer = m % 3;
+    const float* W = layer == 0 ? W2 : (layer == 1 ? W3 : W4);
+    const int r = band * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+    pk[idx] = m < 3 ? W[r * UV_H + k] : W[k * UV_H + r];
+}
+
+typedef float BwPlane[BW_PITCH];
+
+// One wave's 32 x 128 slice of a packed matrix: buffer loads -- the descriptor and the slice's byte offset are scalars, the only
+// per-lane part is lane * 16 (as flat loads the compiler kept 6 x 16 64-bit per-lane addresses alive across the tile loop and spilled)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bw_load_a(float (&A)[64], __amdgpu_buffer_rsrc_t rsrc, int slice_bytes, int lane) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, slice_bytes + g * 1024, 0);
+        A[4 * g] = __uint_as_float(v.x); A[4 * g + 1] = __uint_as_float(v.y); A[4 * g + 2] = __uint_as_float(v.z); A[4 * g + 3] = __uint_as_float(v.w);
+    }
+}
+
+// c[128 x 64 points] rows of this wave = A (the wave's 32 x 128 slice, in registers) x sIn[128][64]
+__device__ __forceinline__ void bw_gemm(const float (&A)[64], const BwPlane* sIn, int bn, int bk, f32x16& c0, f32x16& c1) {
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const float* row = &sIn[2 * s + bk][bn];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], row[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], row[32], c1, 0, 0, 0);
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // (keeps the scheduler from hoisting all 128 LDS reads: 512 VGPRs are spoken for)
+    }
+}
+
+// dW[32 rows of this wave x 128] += sD[rows][64 points] x sH[128][64 points]^T
+__device__ __forceinline__ void bw_outer(const BwPlane* sD, const BwPlane* sH, int wave, int bn, int bk, f32x16 (&dW)[4]) {
+#pragma unroll
+    for (int s = 0; s < BW_P / 2; ++s) {
+        const float av = sD[32 * wave + bn][2 * s + bk];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            dW[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sH[32 * t + bn][2 * s + bk], dW[t], 0, 0, 0);
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_uv_backward(UVBwdArgs a) {
+    __shared__ float sH1[UV_H][BW_PITCH], sA[UV_H][BW_PITCH], sH2[UV_H][BW_PITCH], sH3[UV_H][BW_PITCH];
+    __shared__ float sX[BW_P][4], sG[BW_P][4];            // the tile's (normalised) inputs and upstream gradients
+    __shared__ float sW1[UV_H][4];                        // W1 | b1
+    __shared__ float sW5[3][UV_H];
+    __shared__ float sBias[3][UV_H];                      // b2 + emb, b3, b4
+    __shared__ float sO[4][3][BW_P];
+    __shared__ float sDo[3][BW_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bn = lane & 31, bk = lane >> 5;
+    const int ni = tid & 127, hf = tid >> 7;              // the neuron / half of the tile's points this thread owns in the VALU phases
+    for (int e = tid; e < UV_H; e += 256) {
+        sW1[e][0] = a.W1[3 * e]; sW1[e][1] = a.W1[3 * e + 1]; sW1[e][2] = a.W1[3 * e + 2]; sW1[e][3] = a.b1 ? a.b1[e] : 0.0f;
+        sBias[0][e] = (a.b2 ? a.b2[e] : 0.0f) + a.emb[e];
+        sBias[1][e] = a.b3 ? a.b3[e] : 0.0f;
+        sBias[2][e] = a.b4 ? a.b4[e] : 0.0f;
+        sW5[0][e] = a.W5[e]; sW5[1][e] = a.W5[UV_H + e]; sW5[2][e] = a.W5[2 * UV_H + e];
+    }
+    float inv[3], off[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { inv[c] = a.scale ? 1.0f / a.scale[c] : 1.0f; off[c] = a.off ? a.off[c] : 0.0f; }
+    const float b5[3] = {a.b5 ? a.b5[0] : 0.0f, a.b5 ? a.b5[1] : 0.0f, a.b5 ? a.b5[2] : 0.0f};
+
+    f32x16 dW2[4], dW3[4], dW4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dW2[t] = f32x16{0.f}; dW3[t] = f32x16{0.f}; dW4[t] = f32x16{0.f}; }
+    float acc_s[BW_SMALL];
+#pragma unroll
+    for (int q = 0; q < BW_SMALL; ++q) acc_s[q] = 0.0f;
+    float acc_b5[3] = {0.0f, 0.0f, 0.0f};
+
+    const __amdgpu_buffer_rsrc_t pk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.pk4), 0, 6 * UV_H * UV_H * 4, 0x00020000);
+    constexpr int LSTR = 4 * 16 * 64 * 16;                                                        // bytes per packed matrix
+    const int pF = __builtin_amdgcn_readfirstlane(wave) * 16 * 64 * 16;                          // + m * LSTR: W2, W3, W4
+    const int pT = pF + 3 * LSTR;                                                                 //             W2^T, W3^T, W4^T
+    float RA[64], RB[64];
+    bw_load_a(RA, pk, pF, lane);                                    // W2
+    auto relu_out = [&](BwPlane* sOut, const float* bias, const f32x16& c0, const f32x16& c1) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * bk;             // C/D layout: col = lane & 31
+            const float b = bias[i];
+            sOut[i][bn] = fmaxf(c0[v] + b, 0.0f);
+            sOut[i][32 + bn] = fmaxf(c1[v] + b, 0.0f);
+        }
+    };
+    auto mask_into = [&](BwPlane* sH, const f32x16& c0, const f32x16& c1) {       // d_in = c . [h > 0], in place of h
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * bk;
+            sH[i][bn] = sH[i][bn] > 0.0f ? c0[v] : 0.0f;
+            sH[i][32 + bn] = sH[i][32 + bn] > 0.0f ? c1[v] : 0.0f;
+        }
+    };
+    auto row_sum = [&](const BwPlane* sD) {
+        float r = 0.0f;
+#pragma unroll 8
+        for (int p = 0; p < BW_P / 2; ++p) r += sD[ni][32 * hf + p];
+        return r;
+    };
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int p0 = tile * BW_P;
+        // ---- inputs of the tile (points past N: g = 0, so they add nothing anywhere)
+        if (tid < BW_P) {
+            const int n = min(p0 + tid, a.N - 1);
+            const bool ok = p0 + tid < a.N;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sX[tid][c] = (a.xyz[3 * n + c] - off[c]) * inv[c];
+                sG[tid][c] = ok ? a.g[3 * n + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 (3 -> 128), VALU
+        for (int e = tid; e < UV_H * BW_P; e += 256) {
+            const int i = e >> 6, p = e & 63;
+            sH1[i][p] = fmaxf(sW1[i][0] * sX[p][0] + sW1[i][1] * sX[p][1] + sW1[i][2] * sX[p][2] + sW1[i][3], 0.0f);
+        }
+        __syncthreads();
+        // ---- forward, three GEMMs; the next GEMM's A slice is loaded while this one runs
+        {
+            bw_load_a(RB, pk, pF + LSTR, lane);                     // W3
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm(RA, sH1, bn, bk, c0, c1);
+            relu_out(sA, sBias[0], c0, c1);
+        }
+        __syncthreads();
+        {
+            bw_load_a(RA, pk, pF + 2 * LSTR, lane);                 // W4
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm(RB, sA, bn, bk, c0, c1);
+            relu_out(sH2, sBias[1], c0, c1);
+        }
+        __syncthreads();
+        {
+            bw_load_a(RB, pk, pT + 2 * LSTR, lane);                 // W4^T
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm(RA, sH2, bn, bk, c0, c1);
+            relu_out(sH3, sBias[2], c0, c1);
+        }
+        __syncthreads();
+        // ---- output layer + F.normalize and its backward
+        {
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll 8
+            for (int ii = 0; ii < 32; ++ii) {
+                const int i = 32 * wave + ii;
+                const float h = sH3[i][lane];
+                o0 += sW5[0][i] * h; o1 += sW5[1][i] * h; o2 += sW5[2][i] * h;
+            }
+            sO[wave][0][lane] = o0; sO[wave][1][lane] = o1; sO[wave][2][lane] = o2;
+        }
+        __syncthreads();
+        if (tid < BW_P) {
+            float o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = b5[c] + ((sO[0][c][tid] + sO[1][c][tid]) + (sO[2][c][tid] + sO[3][c][tid]));
+            const float rn = 1.0f / fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]), 1e-12f);
+            const float u0 = o[0] * rn, u1 = o[1] * rn, u2 = o[2] * rn;
+            const float g0 = sG[tid][0], g1 = sG[tid][1], g2 = sG[tid][2];
+            const float ug = u0 * g0 + u1 * g1 + u2 * g2;
+            const float d0 = (g0 - u0 * ug) * rn, d1 = (g1 - u1 * ug) * rn, d2 = (g2 - u2 * ug) * rn;
+            sDo[0][tid] = d0; sDo[1][tid] = d1; sDo[2][tid] = d2;
+            acc_b5[0] += d0; acc_b5[1] += d1; acc_b5[2] += d2;
+        }
+        __syncthreads();
+        // ---- dW5, d4 (in place of h3), db4
+        {
+            const float w0 = sW5[0][ni], w1 = sW5[1][ni], w2 = sW5[2][ni];
+#pragma unroll 8
+            for (int pp = 0; pp < BW_P / 2; ++pp) {
+                const int p = 32 * hf + pp;
+                const float h = sH3[ni][p], d0 = sDo[0][p], d1 = sDo[1][p], d2 = sDo[2][p];
+                acc_s[7] += d0 * h; acc_s[8] += d1 * h; acc_s[9] += d2 * h;
+                const float d4 = h > 0.0f ? w0 * d0 + w1 * d1 + w2 * d2 : 0.0f;
+                acc_s[6] += d4;
+                sH3[ni][p] = d4;
+            }
+        }
+        __syncthreads();
+        // ---- layer 4: d3 = W4^T d4 . [h2 > 0], dW4 += d4 h2^T
+        {
+            bw_load_a(RA, pk, pT + LSTR, lane);                     // W3^T
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm(RB, sH3, bn, bk, c0, c1);
+            bw_outer(sH3, sH2, wave, bn, bk, dW4);
+            __syncthreads();
+            mask_into(sH2, c0, c1);
+        }
+        __syncthreads();
+        // ---- layer 3
+        {
+            bw_load_a(RB, pk, pT, lane);                            // W2^T
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm(RA, sH2, bn, bk, c0, c1);
+            bw_outer(sH2, sA, wave, bn, bk, dW3);
+            acc_s[5] += row_sum(sH2);
+            __syncthreads();
+            mask_into(sA, c0, c1);
+        }
+        __syncthreads();
+        // ---- layer 2
+        {
+            bw_load_a(RA, pk, pF, lane);                            // W2, for the next tile
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm(RB, sA, bn, bk, c0, c1);
+            bw_outer(sA, sH1, wave, bn, bk, dW2);
+            acc_s[4] += row_sum(sA);
+            __syncthreads();
+            mask_into(sH1, c0, c1);
+        }
+        __syncthreads();
+        // ---- layer 1: dW1 += d1 x^T, db1 += d1
+#pragma unroll 8
+        for (int pp = 0; pp < BW_P / 2; ++pp) {
+            const int p = 32 * hf + pp;
+            const float d = sH1[ni][p];
+            acc_s[0] += d * sX[p][0]; acc_s[1] += d * sX[p][1]; acc_s[2] += d * sX[p][2];
+            acc_s[3] += d;
+        }
+        __syncthreads();
+    }
+    // ---- this workgroup's partial sums
+    float* __restrict__ pw = a.partW + (size_t)blockIdx.x * 3 * UV_H * UV_H;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * bk, col = 32 * t + bn;
+            pw[r * UV_H + col] = dW2[t][v];
+            pw[UV_H * UV_H + r * UV_H + col] = dW3[t][v];
+            pw[2 * UV_H * UV_H + r * UV_H + col] = dW4[t][v];
+        }
+    float* __restrict__ ps = a.partS + ((size_t)blockIdx.x * 2 + hf) * BW_SMALL * UV_H;
+#pragma unroll
+    for (int q = 0; q < BW_SMALL; ++q) ps[q * UV_H + ni] = acc_s[q];
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = acc_b5[c];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) a.partB5[blockIdx.x * 4 + c] = v;
+        }
+    }
+}
+
+struct UVGradOut {
+    float *dW1, *db1, *dW2, *db2, *dW3, *db3, *dW4, *db4, *dW5, *db5;
+};
+
+// partial sums of the <= 256 workgroups -> the gradients (one thread per output element, partials added in workgroup order)
+__global__ void __launch_bounds__(256)
+k_uv_backward_reduce(const float* __restrict__ partW, const float* __restrict__ partS, const float* __restrict__ partB5, int G,
+                     UVGradOut o) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    constexpr int NW = 3 * UV_H * UV_H, NS = BW_SMALL * UV_H;
+    if (e < NW) {
+        float* dst = e < UV_H * UV_H ? o.dW2 : (e < 2 * UV_H * UV_H ? o.dW3 : o.dW4);
+        if (!dst) return;
+        float v = 0.0f;
+        for (int g = 0; g < G; ++g) v += partW[(size_t)g * NW + e];
+        dst[e & (UV_H * UV_H - 1)] = v;
+    } else if (e < NW + NS) {
+        const int k = e - NW, q = k >> 7, i = k & 127;
+        float v = 0.0f;
+        for (int g = 0; g < 2 * G; ++g) v += partS[(size_t)g * NS + k];
+        if (q < 3) { if (o.dW1) o.dW1[3 * i + q] = v; }
+        else if (q == 3) { if (o.db1) o.db1[i] = v; }
+        else if (q == 4) { if (o.db2) o.db2[i] = v; }
+        else if (q == 5) { if (o.db3) o.db3[i] = v; }
+        else if (q == 6) { if (o.db4) o.db4[i] = v; }
+        else { if (o.dW5) o.dW5[(q - 7) * UV_H + i] = v; }
+    } else if (e < NW + NS + 3) {
+        const int c = e - NW - NS;
+        float v = 0.0f;
+        for (int g = 0; g < G; ++g) v += partB5[g * 4 + c];
+        if (o.db5) o.db5[c] = v;
+    }
+}
+
 }  // namespace
 
 size_t uv_taylor_temp_bytes() { return (size_t)3 * UV_H * UV_H * sizeof(float); }
@@ -300,5 +629,34 @@ int launch_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, co
     a.W1 = net->W1; a.b1 = net->b1; a.b2 = net->b2; a.emb = net->emb; a.b3 = net->b3; a.b4 = net->b4; a.W5 = net->W5; a.b5 = net->b5;
     a.off = net->xyz_offset; a.scale = net->xyz_scale; a.packed = reinterpret_cast<const uint4*>(packed);
     hipLaunchKernelGGL(k_uv_taylor_bf16x3, dim3((N + UV_P - 1) / UV_P), dim3(256), 0, s, a, xyz, N, uvs, grad_uvs);
+    return (int)hipGetLastError();
+}
+
+// ---- backward: temp = [packed W2..W4][packed W2^T..W4^T][partials of `uv_backward_blocks(N)` workgroups]
+static int uv_backward_blocks(int N) { const int t = (N + BW_P - 1) / BW_P; return t < 256 ? (t < 1 ? 1 : t) : 256; }
+static size_t uv_backward_part_floats() { return (size_t)3 * UV_H * UV_H + 2 * BW_SMALL * UV_H + 4; }
+size_t uv_backward_temp_bytes(int N) {
+    return 2 * uv_taylor_temp_bytes() + (size_t)uv_backward_blocks(N) * uv_backward_part_floats() * sizeof(float);
+}
+
+int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, int N, const TexGSUVNetGrad* out, void* temp, hipStream_t s) {
+    const int G = uv_backward_blocks(N);
+    float* packed = reinterpret_cast<float*>(temp);
+    float* partW = packed + 6 * UV_H * UV_H;
+    float* partS = partW + (size_t)G * 3 * UV_H * UV_H;
+    float* partB5 = partS + (size_t)G * 2 * BW_SMALL * UV_H;
+    UVGradOut o{out->dW1, out->db1, out->dW2, out->db2, out->dW3, out->db3, out->dW4, out->db4, out->dW5, out->db5};
+    if (N <= 0) {                                          // no points: every gradient is zero
+        (void)hipMemsetAsync(partW, 0, (size_t)G * uv_backward_part_floats() * sizeof(float), s);
+    } else {
+        hipLaunchKernelGGL(k_uv_pack_bwd, dim3(6 * 4 * 64 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4, packed);
+        UVBwdArgs a;
+        a.W1 = net->W1; a.b1 = net->b1; a.b2 = net->b2; a.emb = net->emb; a.b3 = net->b3; a.b4 = net->b4; a.W5 = net->W5; a.b5 = net->b5;
+        a.off = net->xyz_offset; a.scale = net->xyz_scale; a.pk4 = reinterpret_cast<const float4*>(packed); a.xyz = xyz; a.g = g;
+        a.N = N; a.n_tiles = (N + BW_P - 1) / BW_P; a.partW = partW; a.partS = partS; a.partB5 = partB5;
+        hipLaunchKernelGGL(k_uv_backward, dim3(G), dim3(256), 0, s, a);
+    }
+    const int n_out = 3 * UV_H * UV_H + BW_SMALL * UV_H + 3;
+    hipLaunchKernelGGL(k_uv_backward_reduce, dim3((n_out + 255) / 256), dim3(256), 0, s, partW, partS, partB5, G, o);
     return (int)hipGetLastError();
 }

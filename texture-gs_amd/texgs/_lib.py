@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8
@@ -61,12 +61,16 @@ class UVNetStruct(C.Structure):
         + [("hidden", C.c_int32)]
 
 
+class UVNetGradStruct(C.Structure):
+    _fields_ = [(n, _fp) for n in ("dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4", "dW5", "db5")]
+
+
 EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_read_num_rendered2", "texgs_depth_sort_scan", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
            "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
            "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_norm_from_depth", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes", "texgs_uv_pack", "texgs_uv_taylor_packed",
-           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3"]
+           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3", "texgs_uv_backward", "texgs_uv_backward_temp_bytes"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
 
@@ -126,6 +130,10 @@ def load():
     lib.texgs_uv_pack_bf16x3.restype = C.c_int
     lib.texgs_uv_taylor_packed_bf16x3.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_uv_taylor_packed_bf16x3.restype = C.c_int
+    lib.texgs_uv_backward_temp_bytes.argtypes = [C.c_int32]
+    lib.texgs_uv_backward_temp_bytes.restype = C.c_size_t
+    lib.texgs_uv_backward.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, P(UVNetGradStruct), C.c_void_p, C.c_void_p]
+    lib.texgs_uv_backward.restype = C.c_int
     lib.texgs_selftest_waveops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_selftest_waveops.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]

@@ -12,9 +12,10 @@ Three ways to evaluate:
                                           forward-mode propagation in one launch, instead of UVNet.forward plus the three backward
                                           passes of torch.autograd.functional.jacobian (models/texture_gaussian3d.py:216-236)
   uvs_and_jacobian_with_grad(xyz, emb)    the same launch inside an autograd node: `uvs` carries gradients to xyz (= J^T g, free:
-                                          J is there), to the embedding and to every weight (plain library GEMMs over the
-                                          recomputed activations), so the training graph of `uvs` stays on the device with one
-                                          fused forward instead of a second, torch-side evaluation of the network.
+                                          J is there), to the embedding and to every weight (ONE fused HIP backward kernel that
+                                          recomputes the activations per tile, `backward_fused`), so the training graph of `uvs`
+                                          stays on the device with one fused forward and one fused backward instead of a second,
+                                          torch-side evaluation of the network and autograd's per-layer passes.
 """
 import ctypes as C
 
@@ -193,6 +194,34 @@ class UVNet(nn.Module):
             _lib.check(eval_fn(C.byref(net), p(ent[1]), p(x), N, p(uvs), p(juv), stream), "texgs_uv_taylor_packed")
         return uvs, juv
 
+    @torch.no_grad()
+    def backward_fused(self, xyz, emb, g):
+        """[dW1, db1, dW2, db2, dW3, db3, dW4, db4, dW5, db5] of sum(uvs * g) from the fused HIP backward (csrc/uvnet.hip
+        k_uv_backward: one persistent kernel, activations recomputed per tile in LDS, weight gradients in registers; d emb = db2).
+        What autograd does through models/modules/uv_net.py:19-36 under loss.backward() in the reference.  No CPU fallback
+        (`uvnet_backward` below is the plain-torch statement the tests check this kernel against)."""
+        lib = _lib.load()
+        dev = xyz.device
+        if dev.type != "cuda":
+            raise RuntimeError("UVNet.backward_fused runs on an AMD GPU; there is no CPU fallback")
+        x = xyz.detach().to(dtype=torch.float32).contiguous()
+        gg = g.detach().to(dtype=torch.float32).contiguous()
+        N = x.shape[0]
+        if gg.shape != (N, 3):
+            raise ValueError(f"g must be [N, 3], got {tuple(gg.shape)}")
+        ws = self._kernel_args(dev, emb)
+        p = lambda t: None if t is None else t.data_ptr()
+        netp = _lib.UVNetStruct(*[p(t) for t in ws], HIDDEN)
+        shapes = [(HIDDEN, 3), (HIDDEN,), (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN, HIDDEN), (HIDDEN,),
+                  (3, HIDDEN), (3,)]
+        outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            temp = torch.empty(lib.texgs_uv_backward_temp_bytes(N), dtype=torch.uint8, device=dev)
+            gr = _lib.UVNetGradStruct(*[p(t) for t in outs])
+            _lib.check(lib.texgs_uv_backward(C.byref(netp), p(x), p(gg), N, C.byref(gr), p(temp), stream), "texgs_uv_backward")
+        return outs
+
     def uvs_and_jacobian_with_grad(self, xyz, emb):
         """(uvs, gradient_uvs) from ONE fused launch, with `uvs` differentiable w.r.t. xyz, emb and the network's weights
         (`gradient_uvs` carries no gradient, as in the reference)."""
@@ -265,15 +294,11 @@ class _FusedUV(torch.autograd.Function):
             d_xyz = (g[:, :, None] * juv.reshape(-1, 3, 3)).sum(dim=1)      # (elementwise: as an einsum this is 300 000 batched 1x3 . 3x3 products)
         d_emb, d_params = None, [None] * 10
         if any(need[2:]):
-            with torch.no_grad():
-                xn = net._norm_in(xyz.detach().to(torch.float32))
-                ws, bs = list(params[0::2]), list(params[1::2])
-                _, d_emb, dW, db = uvnet_backward(xn, emb.detach().to(torch.float32), [w.detach() for w in ws], [b.detach() for b in bs], g)
-            for k in range(5):
-                d_params[2 * k] = dW[k] if need[3 + 2 * k] else None
-                d_params[2 * k + 1] = db[k] if need[4 + 2 * k] else None
-            if not need[2]:
-                d_emb = None
+            grads = net.backward_fused(xyz, emb, g)
+            for k in range(10):
+                d_params[k] = grads[k] if need[3 + k] else None
+            if need[2]:
+                d_emb = (grads[3].clone() if need[6] else grads[3]).reshape(emb.shape)        # d emb = db2 (the embedding is added where b2 is)
         return (None, d_xyz, d_emb, *d_params)
 
 
