@@ -28,6 +28,8 @@ TEXGS_UV_PRECISION=bf16x3 timeout 300 python bench.py --leg iteration --steps 10
 echo "[bench $(( $(date +%s) - T0 )) s]"
 bash scripts/prof_ref_pattern.sh > gpurun_out/ref_pattern_profile.txt 2>&1
 echo "[ref pattern $(( $(date +%s) - T0 )) s]"
+bash scripts/prof_iteration.sh > gpurun_out/iteration_profile.txt 2>&1
+echo "[iteration profile $(( $(date +%s) - T0 )) s]"
 python - <<'PY'
 import json
 for n in ("c3", "c3_serial", "c3_s4", "c2", "c5", "c3_diff_gauss", "c3_rccl1"):
@@ -44,11 +46,12 @@ for n in ("c3", "c3_serial", "c3_s4", "c2", "c5", "c3_diff_gauss", "c3_rccl1"):
 for n in ("fp32", "bf16x3"):
     try:
         j = json.loads([l for l in open(f"gpurun_out/bench_iteration_{n}.json").read().splitlines() if l.startswith("{")][-1])
-        print("iteration", n, j["uv_per_render_ms_per_iteration"], j["uv_once_ms_per_iteration"], j["split_uv_once_ms"], j["rasterizer_kernels_us_per_iteration"])
+        print("iteration", n, j["uv_per_render_ms_per_iteration"], j["uv_once_ms_per_iteration"], j["split_uv_once_ms"], j["rasterizer_kernels_us_per_iteration"], j.get("uvnet_backward_us"))
     except Exception as e:
         print("iteration", n, "ERR", e, open(f"gpurun_out/bench_iteration_{n}.err").read()[-800:])
 PY
 cat gpurun_out/variants.jsonl | cut -c1-400
 cat gpurun_out/ref_pattern_profile.txt | head -50
+cat gpurun_out/iteration_profile.txt | head -34
 grep -E "k_render|k_texgrad|k_preprocess|k_bin_off|k_radix|k_depth|k_dup|k_ranges|k_tile" gpurun_out/prof_summary.txt | grep calls | head -40
 cat gpurun_out/traffic.json | head -40
