@@ -264,6 +264,8 @@ int texgs_backward_preprocess(const TexGSFrame* frame, const TexGSInputs* in, co
     return check(frame, s, "preprocess_bwd");
 }
 
+// (Round 5, measured null: the texture-gradient reduce on a side stream next to K8 -- both wait only for K7 -- changed nothing:
+// reference call pattern 728.0 vs 728.2 and 720.7 vs 712.5 views/s, iteration leg 5.172 vs 5.170 ms, profiles/r05_ablation.md.)
 int texgs_backward(const TexGSFrame* frame, const TexGSInputs* in, const TexGSGeom* geom,
                    const TexGSBinning* bin, const TexGSImage* img, TexGSGrads* grads, void* stream) {
     if (int r = texgs_backward_render(frame, in, geom, bin, img, grads, stream)) return r;

@@ -582,8 +582,17 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 //           C3 pipelined 856 -> 903-926 views/s.  Used by every flavour that runs the per-Gaussian stages.
 //   lds  -- the round-4 shape (records in LDS planes, segments of 128 items, two rounds of taps in flight, 9 waves per CU): the
 //           texture-only flavour has no stage C to hide a dependent L2 round trip behind and is faster this way (405 vs 512 us).
+#ifdef K7_TRACE
+// experiment builds only (scripts/exp_build.sh trace "-DK7_TRACE"; scripts/k7_trace.py): per block of the last K7 launch
+// {start, end (100 MHz wall clock), XCC | HW_ID << 8, survivors | list length << 32}
+#define K7_TRACE_BLOCKS 16384
+__device__ unsigned long long k7_trace[4 * K7_TRACE_BLOCKS];
+#endif
 #ifndef K7_OCC_PREFETCH
 #define K7_OCC_PREFETCH 0
+#endif
+#ifndef K7_PRIO
+#define K7_PRIO 0
 #endif
 namespace k7_occ {
 #define BQ_CAP 64
@@ -855,3 +864,9 @@ void launch_texgrad_reduce(const CamConst& c, const TexGSImage* img, TexGSGrads*
     if (!tb.rec) return;
     hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(TB_THREADS), 0, s, c.R, tb, gr->dL_dtexture);
 }
+
+#ifdef K7_TRACE
+extern "C" __attribute__((visibility("default"))) int texgs_debug_k7_trace(void* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k7_trace), sizeof(unsigned long long) * 4 * K7_TRACE_BLOCKS);
+}
+#endif

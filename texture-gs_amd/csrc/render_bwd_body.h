@@ -35,6 +35,9 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     const int lane = (int)threadIdx.x;
     int tile, wave;
     if (!wave_block(a, tile, wave)) return;
+#ifdef K7_TRACE
+    const unsigned long long trace_t0 = wall_clock64();   // experiment builds only (scripts/k7_trace.py): when each block ran, and where
+#endif
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int wave_px = tile_x * TEXGS_TILE + ((wave & 1) << 3), wave_py = tile_y * TEXGS_TILE + ((wave >> 1) << 3);
     int ox, oy;
@@ -319,7 +322,16 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             }
         }
     };
+#if K7_PRIO == 1
+    // issue priority by the block's length (experiment): the launch runs longest-list-first, so the 4 096 longest blocks start
+    // together and share their SIMDs equally; the longest of them (460-500 us) then ends the kernel (profiles/r05_k7_block_trace.json)
+    if (ns >= 190) __builtin_amdgcn_s_setprio(3); else if (ns >= 150) __builtin_amdgcn_s_setprio(2); else if (ns >= 100) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int hi = ns; hi > 0; hi -= 64) {
+#if K7_PRIO == 2
+        // issue priority by what the block still has to do (experiment): longest REMAINING list first
+        if (hi > 128) __builtin_amdgcn_s_setprio(3); else if (hi > 64) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
         const bool live = hi - 1 - lane >= 0;
         const uint32_t id = nsv.x, pos = nsv.y, qm = nqm;
         nsv = make_uint2(0u, 0xFFFFFFFFu); nqm = 0u;
@@ -556,5 +568,13 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             rp[0] = 0.f; rp[tb.cap] = 0.f; rp[2 * (size_t)tb.cap] = 0.f; rp[3 * (size_t)tb.cap] = 0.f; rp[4 * (size_t)tb.cap] = 0.f;
         }
     }
+#ifdef K7_TRACE
+    if (lane == 0 && blockIdx.x < K7_TRACE_BLOCKS) {
+        unsigned long long* tr = k7_trace + 4 * (size_t)blockIdx.x;
+        tr[0] = trace_t0; tr[1] = wall_clock64();
+        tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(6164) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8);     // XCC_ID[3:0] | HW_ID << 8
+        tr[3] = (unsigned long long)(uint32_t)ns | ((unsigned long long)(uint32_t)todo << 32);
+    }
+#endif
 }
 
