@@ -54,11 +54,11 @@ dbg.texgs_debug_k7_trace.restype = C.c_int
 res = []
 for v in (0, 0, 17, 40):                                  # (the first pass of view 0 warms up)
     view(v)
-    buf = np.zeros(4 * 16384, dtype=np.uint64)
+    buf = np.zeros(4 * 32768, dtype=np.uint64)
     rc = dbg.texgs_debug_k7_trace(buf.ctypes.data_as(C.c_void_p))
     assert rc == 0, rc
     tr = buf.reshape(-1, 4)
-    nb = 10016
+    nb = int(os.environ.get("K7_TRACE_NB", "10016"))
     t0, t1 = tr[:nb, 0].astype(np.int64), tr[:nb, 1].astype(np.int64)
     ran = t1 > 0
     base = t0[ran].min()
