@@ -29,12 +29,6 @@
 // view are one contiguous array (~0.37 GB at C3) -- no per-bin capacity, no chunk tables, nothing to wait for.
 // No MFMA: there is no dense contraction on this path.
 #include "common.h"
-#ifndef K6_PRIO
-#define K6_PRIO 0
-#endif
-#ifndef K7_SPLIT
-#define K7_SPLIT 0
-#endif
 #include "wave_ops.h"
 
 namespace {
@@ -151,16 +145,6 @@ __device__ __forceinline__ bool wave_block(const PixArgs& a, int& tile, int& wav
     tile = (int)a.tile_order[rank];
     return true;
 }
-#if K7_SPLIT
-__device__ __forceinline__ bool wave_block_at(const PixArgs& a, int b, int& tile, int& wave) {
-    const int k = b >> 3;
-    wave = k & 3;
-    const int rank = ((k >> 2) << 3) | (b & 7);
-    if (rank >= a.num_tiles) return false;
-    tile = (int)a.tile_order[rank];
-    return true;
-}
-#endif
 inline int blend_grid(int num_tiles) { return 4 * ((num_tiles + 7) & ~7); }
 
 // HIP's __ballot(int) materialises the predicate as 0/1 in a VGPR and compares it again (v_cndmask + v_cmp per ballot);
@@ -392,11 +376,6 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     uint32_t nid = (64 + lane < todo) ? a.point_list[range.x + 64 + lane] : 0u;      // Gaussian ids of the batch at r + 64
     bool all_done = (~done_mask == 0ull);
     while (!all_done) {
-#if K6_PRIO
-        // issue priority by what is left of the block's list (experiment; K7's version of this bought 3 %: profiles/r05_ablation.md)
-        { const int rem = todo - r + nq;
-          if (rem > 384) __builtin_amdgcn_s_setprio(3); else if (rem > 192) __builtin_amdgcn_s_setprio(2); else if (rem > 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#endif
         // ---- raw batches: 8x8 cull on the 32-byte test records, survivors queued in list order
         while (nq < 64 && r < todo) {
             const int idx = r + lane;
@@ -609,17 +588,8 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 #define K7_TRACE_BLOCKS 32768
 __device__ unsigned long long k7_trace[4 * K7_TRACE_BLOCKS];
 #endif
-#if K7_SPLIT
-#define K7_SPLIT_BLOCKS 16384
-__device__ unsigned long long k7_split_state[(size_t)K7_SPLIT_BLOCKS * 64];
-__device__ uint32_t k7_split_tpos[(size_t)K7_SPLIT_BLOCKS * 64];
-__device__ uint32_t k7_split_flag[K7_SPLIT_BLOCKS + 1];       // [K7_SPLIT_BLOCKS]: waits that gave up
-#endif
 #ifndef K7_OCC_PREFETCH
 #define K7_OCC_PREFETCH 0
-#endif
-#ifndef K7_PRIO
-#define K7_PRIO 2
 #endif
 namespace k7_occ {
 #define BQ_CAP 64
@@ -872,11 +842,7 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     if (tex && tb.rec)      // list offsets + cursors from the counts the forward left (one small workgroup)
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
                            gr->tex_bin_base, gr->tex_bin_cursor, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
-#if K7_SPLIT
-    const dim3 grid(2 * blend_grid(a.num_tiles)), blk(64);
-#else
     const dim3 grid(blend_grid(a.num_tiles)), blk(64);
-#endif
 #define K7_LAUNCH(NS, TEX, GEO, UVG, TAPS) hipLaunchKernelGGL((NS::k_render_bwd<TEX, GEO, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
         img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
     if (!taps)            K7_LAUNCH(k7_occ, false, true, false, false);

@@ -34,17 +34,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     __shared__ BwdLds L;
     const int lane = (int)threadIdx.x;
     int tile, wave;
-#if K7_SPLIT
-    // EXPERIMENT (static buffers: one launch at a time).  The launch holds every block twice: block b < half walks the REAR chunks of
-    // its survivor list and leaves {T, behind} per pixel + the reservation cursors; block b + half (same XCD: half is a multiple of
-    // 8, workgroups go round the XCDs) waits for that and walks the front chunks.  Twice as many, half as long work units.
-    const int split_half = (int)(gridDim.x >> 1);
-    const bool second = (int)blockIdx.x >= split_half;
-    const int bid = (int)blockIdx.x - (second ? split_half : 0);
-    if (!wave_block_at(a, bid, tile, wave)) return;
-#else
     if (!wave_block(a, tile, wave)) return;
-#endif
 #ifdef K7_TRACE
     const unsigned long long trace_t0 = wall_clock64();   // experiment builds only (scripts/k7_trace.py): when each block ran, and where
 #endif
@@ -57,11 +47,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = a.ranges[tile];
     const int todo = (int)(range.y - range.x);
-#if K7_SPLIT
-    const int ns_all = min((int)a.surv_cnt[4 * tile + wave], todo);
-    const int split_hi = ns_all - 64 * ((((ns_all + 63) >> 6) + 1) >> 1);      // the rear pass takes ceil(chunks / 2) chunks from the back
-    if (second && split_hi <= 0) return;                                          // one chunk (or none): the rear pass did everything
-#endif
     const int HW = a.W * a.H, pix = py * a.W + px;
     const float* __restrict__ tex = a.texture;
     const uint32_t keybase = ((uint32_t)lane << 8) | ((uint32_t)ox << 14) | ((uint32_t)oy << 17);
@@ -85,11 +70,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
 #else
     init_dummy(L.p, lane);
 #endif
-    if (TEX && tb.rec != nullptr
-#if K7_SPLIT
-        && !second
-#endif
-        ) {
+    if (TEX && tb.rec != nullptr) {
         // image-wide bound on the texture-gradient records (|x| <= C0 |dL/dpixel|): the reduce kernel's fixed-point scale of THIS
         // call (k_bin_offsets, launched just before this kernel, cleared the word).  Non-negative floats order like their bit
         // patterns, and so do +inf (0x7F800000) and NaN (above it): an INTEGER maximum carries a non-finite upstream gradient to the
@@ -126,13 +107,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     // The survivors of this block's cull come from K6 (it culled exactly this list, at least as far as the last contributor):
     // chunks of 64 from the back, lane = survivor in descending list position.  The next chunk's entries are loaded one chunk ahead.
     const size_t sbase = 4 * (size_t)range.x + (size_t)wave * (size_t)todo;
-#if K7_SPLIT
-    const int ns = second ? split_hi : ns_all;
-    const int hi_stop = second ? 0 : max(split_hi, 0);
-#else
     const int ns = min((int)a.surv_cnt[4 * tile + wave], todo);      // (a count beyond the block's region can only be a stale buffer)
-    constexpr int hi_stop = 0;
-#endif
     uint2 nsv = make_uint2(0u, 0xFFFFFFFFu);
     uint32_t nqm = 0u;
     if (ns - 1 - lane >= 0) { nsv = a.surv[sbase + (ns - 1 - lane)]; nqm = a.surv_qm[sbase + (ns - 1 - lane)]; }
@@ -347,37 +322,12 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             }
         }
     };
-#if K7_PRIO == 1
-    // issue priority by the block's length (experiment): the launch runs longest-list-first, so the 4 096 longest blocks start
-    // together and share their SIMDs equally; the longest of them (460-500 us) then ends the kernel (profiles/r05_k7_block_trace.json)
-    if (ns >= 190) __builtin_amdgcn_s_setprio(3); else if (ns >= 150) __builtin_amdgcn_s_setprio(2); else if (ns >= 100) __builtin_amdgcn_s_setprio(1);
-#endif
-#if K7_SPLIT
-    if (second) {
-        // wait for the rear pass of this block (dispatched long before this one: the launch runs blocks in order), then take over
-        if (lane == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&k7_split_flag[bid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(16);
-            if (spins >= (1 << 21)) atomicAdd(&k7_split_flag[K7_SPLIT_BLOCKS], 1u);      // (never seen: a bounded wait cannot hang the device)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long sv = __hip_atomic_load(&k7_split_state[(size_t)bid * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T = __uint_as_float((uint32_t)sv); behind = __uint_as_float((uint32_t)(sv >> 32));
-        if constexpr (TEX) L.tpos[lane] = __hip_atomic_load(&k7_split_tpos[(size_t)bid * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&k7_split_flag[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // clean for the next launch
-        __builtin_amdgcn_wave_barrier();
-    }
-#endif
-    for (int hi = ns; hi > hi_stop; hi -= 64) {
-#if K7_PRIO == 2
+    for (int hi = ns; hi > 0; hi -= 64) {
         // Issue priority by what the block still has to do -- longest REMAINING list first.  The launch is 10 000 one-wave blocks on
         // 4 096 wave slots and a block is long (median a third of the kernel, profiles/r05_k7_block_trace.json): with equal shares
-        // the longest blocks end the kernel alone.  K7 645 -> 626 us (static priority by the block's total length: no change).
+        // the longest blocks end the kernel alone.  K7 645 -> 626 us (661 -> 646 on another box); priority by the block's TOTAL
+        // length, four levels instead of three, the same in K6: no change (profiles/r05_ablation.md).
         if (hi > 128) __builtin_amdgcn_s_setprio(3); else if (hi > 64) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#elif K7_PRIO == 3
-        if (hi > 192) __builtin_amdgcn_s_setprio(3); else if (hi > 128) __builtin_amdgcn_s_setprio(2); else if (hi > 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
         const bool live = hi - 1 - lane >= 0;
         const uint32_t id = nsv.x, pos = nsv.y, qm = nqm;
         nsv = make_uint2(0u, 0xFFFFFFFFu); nqm = 0u;
@@ -604,20 +554,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             __builtin_amdgcn_wave_barrier();
         }
     }
-#if K7_SPLIT
-    if (!second && split_hi > 0) {
-        __builtin_amdgcn_wave_barrier();
-        __hip_atomic_store(&k7_split_state[(size_t)bid * 64 + lane], (unsigned long long)__float_as_uint(T) | ((unsigned long long)__float_as_uint(behind) << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if constexpr (TEX) __hip_atomic_store(&k7_split_tpos[(size_t)bid * 64 + lane], L.tpos[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // both are in the XCD's L2 before the flag is
-        if (lane == 0) __hip_atomic_store(&k7_split_flag[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef K7_TRACE
-        if (lane == 0 && blockIdx.x < K7_TRACE_BLOCKS) { unsigned long long* tr = k7_trace + 4 * (size_t)blockIdx.x; tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(6164); tr[3] = (unsigned long long)(uint32_t)ns; }
-#endif
-        return;
-    }
-#endif
     if constexpr (TEX) {
         // A reservation this block did not use up -- impossible while K6 and K7 agree on every footprint (same decisions, same uv
         // arithmetic); should they ever not, the reduce must not sum whatever an earlier call left in the unused slots.
