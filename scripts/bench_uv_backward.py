@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""The UV map's kernels alone at N = 300 000 (for rocprofv3): fused forward + Jacobian (fp32 and split-bf16), fused backward."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "texture-gs_amd")):
+    sys.path.insert(0, p)
+from texgs.uvnet import UVNet      # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+N = 300_000
+xyz = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=1)
+g = torch.randn(N, 3, device=dev) / N
+emb = (0.2 * torch.randn(128)).to(dev)
+for prec in ("fp32", "bf16x3"):
+    net = UVNet(precision=prec).to(dev)
+    for _ in range(reps):
+        net.uv_and_jacobian(xyz, emb)
+net = UVNet().to(dev)
+ev = lambda: torch.cuda.Event(enable_timing=True)
+net.backward_fused(xyz, emb, g)
+torch.cuda.synchronize()
+e0, e1 = ev(), ev()
+e0.record()
+for _ in range(reps):
+    net.backward_fused(xyz, emb, g)
+e1.record()
+torch.cuda.synchronize()
+print({"uv_backward_fused_us": round(1e3 * e0.elapsed_time(e1) / reps, 1), "N": N})
