@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol(lib_built):
 def test_ctypes_structs_match_c_layout(tmp_path):
     from texgs import _lib
     structs = {"TexGSFrame": _lib.Frame, "TexGSInputs": _lib.Inputs, "TexGSGeom": _lib.Geom,
-               "TexGSBinning": _lib.Binning, "TexGSImage": _lib.Image, "TexGSGrads": _lib.Grads}
+               "TexGSBinning": _lib.Binning, "TexGSImage": _lib.Image, "TexGSGrads": _lib.Grads,
+               "TexGSUVNet": _lib.UVNetStruct, "TexGSUVNetGrad": _lib.UVNetGradStruct}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "texgs.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
