@@ -257,6 +257,55 @@ def test_manual_backward_matches_autograd_float64(n):
         assert torch.allclose(w, l.weight.grad, atol=1e-9 * max(1, n // 200)) and torch.allclose(b, l.bias.grad, atol=1e-9 * max(1, n // 200))
 
 
+def test_fused_autograd_node_routes_gradients(monkeypatch):
+    """The autograd node around the two fused kernels (texgs.uvnet._FusedUV), with both kernels replaced by their plain-torch
+    statements so that it runs on the CPU: which gradient goes to which input, d emb = db2 in the embedding's own shape, inputs
+    that do not require grad get None, d xyz = J^T g -- against autograd of UVNet.forward."""
+    from texgs.uvnet import uvnet_backward
+    torch.manual_seed(3)
+    n = 50
+    net = UVNet(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2]).double()
+
+    def fake_forward(self, xyz, emb):
+        with torch.enable_grad():
+            return self.forward(xyz.detach(), emb.detach()).detach(), jacobian_by_autograd(self, xyz, emb.detach())
+
+    def fake_backward(self, xyz, emb, g):
+        lins = self._linears()
+        _, _, dW, db = uvnet_backward(self._norm_in(xyz.detach()), emb.detach().reshape(-1), [l.weight.detach() for l in lins],
+                                      [l.bias.detach() for l in lins], g)
+        return [t for pair in zip(dW, db) for t in pair]
+    monkeypatch.setattr(UVNet, "uv_and_jacobian", fake_forward)
+    monkeypatch.setattr(UVNet, "backward_fused", fake_backward)
+    g = torch.randn(n, 3).double()
+    for frozen in ((), ("mlp.2.weight", "pre_mlp.0.bias"), ("emb",), ("xyz",)):
+        for name, p_ in net.named_parameters():
+            p_.requires_grad_(name not in frozen)
+            p_.grad = None
+        emb = (torch.randn(128) * 0.2).double().requires_grad_("emb" not in frozen)
+        xyz = torch.randn(n, 3).double().requires_grad_("xyz" not in frozen)
+        uvs, juv = net.uvs_and_jacobian_with_grad(xyz, emb)
+        assert not juv.requires_grad
+        (uvs * g).sum().backward()
+        got = {name: (None if p_.grad is None else p_.grad.clone()) for name, p_ in net.named_parameters()}
+        got["emb"], got["xyz"] = emb.grad, xyz.grad
+        for p_ in net.parameters():
+            p_.grad = None
+        e2, x2 = emb.detach().clone().requires_grad_(emb.requires_grad), xyz.detach().clone().requires_grad_(xyz.requires_grad)
+        (net(x2, e2) * g).sum().backward()
+        exp = {name: p_.grad for name, p_ in net.named_parameters()}
+        exp["emb"], exp["xyz"] = e2.grad, x2.grad
+        for name in exp:
+            if name in frozen:
+                assert got[name] is None, (frozen, name)
+            else:
+                assert got[name] is not None and got[name].shape == exp[name].shape, (frozen, name)
+                # (the node takes the upstream gradient in float32, as the kernel does: 6e-8 relative)
+                assert torch.allclose(got[name], exp[name], rtol=1e-5, atol=1e-6), (frozen, name, float((got[name] - exp[name]).abs().max()))
+    for p_ in net.parameters():
+        p_.requires_grad_(True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,bias,norm", [(1, True, False), (63, True, True), (64, False, False), (200, True, True), (16_385, False, True),
                                          (40_000, True, False)])
