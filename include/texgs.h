@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 13
+#define TEXGS_ABI_VERSION 14
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
 #define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
@@ -334,6 +334,14 @@ int texgs_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const floa
 int texgs_uv_pack_bf16x3(const TexGSUVNet* net, void* packed, void* stream);
 int texgs_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
                                   void* stream);
+
+/* The same two steps with the VALUE column on the f32-input MFMA and the three TANGENT columns at split-bf16 precision (v14,
+ * opt-in): uvs and every ReLU mask are those of texgs_uv_taylor_packed (the value column decides everything discrete and runs
+ * exactly as there); the Jacobian is within ~1e-5 relative of it; ~2x faster.  `packed` holds BOTH layouts back to back:
+ * 2 * texgs_uv_taylor_temp_bytes() bytes. */
+int texgs_uv_pack_mixed(const TexGSUVNet* net, void* packed, void* stream);
+int texgs_uv_taylor_packed_mixed(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
+                                 void* stream);
 
 /* Backward of the UV map (v13): gradients of uvs = UVNet(xyz) w.r.t. every weight, bias and the embedding for an upstream
  * gradient g_uvs f32[N,3] -- what loss.backward() does through models/modules/uv_net.py:19-36 in the reference (autograd over

@@ -17,7 +17,7 @@ N = 300_000
 xyz = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=1)
 g = torch.randn(N, 3, device=dev) / N
 emb = (0.2 * torch.randn(128)).to(dev)
-for prec in ("fp32", "bf16x3"):
+for prec in ("fp32", "bf16x3", "mixed"):
     net = UVNet(precision=prec).to(dev)
     for _ in range(reps):
         net.uv_and_jacobian(xyz, emb)

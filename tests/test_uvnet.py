@@ -163,6 +163,67 @@ def test_split_bf16_kernel_vs_f32_kernel_and_float64(lib_built):
     assert float((ub2 - u32b).abs().max()) < 2e-5 and float((ub2 - ub).abs().max()) > 1e-3
 
 
+@pytest.mark.gpu
+def test_mixed_precision_kernel_keeps_value_column_exact(lib_built):
+    """`UVNet(precision="mixed")` (k_uv_taylor_mixed): the value column runs on the f32-input MFMA exactly as in the f32 kernel, so
+    uvs and the ReLU masks are that kernel's, and the Jacobian differs only by the split-bf16 arithmetic of the tangent columns,
+    ~1e-5 relative, at EVERY point -- no kink exclusions as in the all-bf16 test; against the golden vector of the reference's own
+    UVNet class; weight updates re-pack both layouts."""
+    dev = torch.device("cuda:0")
+    net0, emb0, xyz0 = _golden_net(torch.float32)
+    netm = UVNet(precision="mixed")
+    netm.load_state_dict(net0.state_dict())
+    uvs, J = netm.to(dev).uv_and_jacobian(xyz0.to(dev), emb0.to(dev))
+    e_uv = float((uvs.cpu().double() - torch.tensor(G["uvs"])).abs().max())
+    e_J = float((J.cpu().double() - torch.tensor(G["J"])).abs().max()) / float(np.abs(G["J"]).max())
+    Hh.report("uv_taylor_mixed/golden", uvs_max_abs_err=e_uv, J_max_err_over_Jmax=e_J)
+    assert e_uv < 2e-6 and e_J < 1e-4
+    torch.manual_seed(11)
+    kw = dict(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2])
+    net = UVNet(**kw)
+    emb = torch.randn(128) * 0.2
+    N = 300_000
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.randn(N, 3, generator=g)
+    xyz = (xyz / xyz.norm(dim=1, keepdim=True) * (1 + 0.02 * torch.randn(N, 1, generator=g))).to(dev)
+    embd = emb.to(dev)
+    n32 = net.to(dev)
+    nm = UVNet(precision="mixed", **kw).to(dev)
+    nm.load_state_dict(n32.state_dict())
+    u32, J32 = n32.uv_and_jacobian(xyz, embd)
+    um, Jm = nm.uv_and_jacobian(xyz, embd)
+    torch.cuda.synchronize()
+    times = {}
+    for name, m in (("fp32", n32), ("mixed", nm)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            m.uv_and_jacobian(xyz, embd)
+        e1.record()
+        torch.cuda.synchronize()
+        times[name] = e0.elapsed_time(e1) / 10 * 1e3
+    jmax = float(J32.abs().max())
+    d_uv = float((um - u32).abs().max())
+    same = float((um == u32).float().mean())
+    dJ = (Jm - J32).abs().amax(dim=1) / jmax
+    d_J_max = float(dJ.max())
+    d_J_p9999 = float(torch.quantile(dJ[torch.randperm(N, device=dev)[:100_000]], 0.9999))
+    rel_all = float((Jm - J32).norm() / J32.norm())
+    Hh.report("uv_taylor_mixed/300k", uvs_max_abs_vs_f32_kernel=d_uv, uvs_bit_identical_frac=same, J_max_over_Jmax_vs_f32_kernel_all_points=d_J_max,
+              J_p9999_over_Jmax=d_J_p9999, J_rel_l2_vs_f32_kernel_all_points=rel_all, us_fp32=times["fp32"], us_mixed=times["mixed"])
+    # the first layer and the bias / embedding adds are written with explicit roundings shared by all kernels of csrc/uvnet.hip, the
+    # 128x128 layers' value column is the same MFMA sequence: same pre-activations, same masks, same uvs (up to how the compiler
+    # contracts the 128 -> 3 layer's sums); the Jacobian differs by the tangents' split-bf16 arithmetic only -- at EVERY point
+    assert d_uv < 2.5e-7, d_uv
+    assert d_J_max < 1e-4 and rel_all < 2e-5, (d_J_max, rel_all)
+    with torch.no_grad():
+        nm.mlp[0].weight.mul_(1.5)
+        n32.mlp[0].weight.mul_(1.5)
+    um2, _ = nm.uv_and_jacobian(xyz, embd)
+    u32b, _ = n32.uv_and_jacobian(xyz, embd)
+    assert float((um2 - u32b).abs().max()) < 1e-6 and float((um2 - um).abs().max()) > 1e-3
+
+
 def test_tcnn_flat_params_round_trip_and_first_layer_bias():
     """tiny-cuda-nn FullyFusedMLP state (`use_tcnn: True`, every shipped config): one flat bias-free tensor per network,
     input padded to 16 columns with ones (-> first-layer bias), output padded to 16 rows.  Layout restated from tiny-cuda-nn's

@@ -388,6 +388,28 @@ int texgs_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, con
     return 0;
 }
 
+// (declared here, not in common.h: csrc/uvnet.hip's mixed-precision launchers -- C++ linkage like the rest of common.h's)
+extern "C++" {
+int launch_uv_pack_mixed(const TexGSUVNet* net, void* packed, hipStream_t s);
+int launch_uv_taylor_packed_mixed(const TexGSUVNet* net, const void* packed, const float* xyz, int N, float* uvs, float* grad_uvs, hipStream_t s);
+}
+
+int texgs_uv_pack_mixed(const TexGSUVNet* net, void* packed, void* stream) {
+    if (!net || !packed) return fail_msg("NULL argument");
+    if (int r = check_uvnet(net)) return r;
+    if (int r = launch_uv_pack_mixed(net, packed, (hipStream_t)stream)) return fail("uv_pack_mixed", (hipError_t)r);
+    return 0;
+}
+
+int texgs_uv_taylor_packed_mixed(const TexGSUVNet* net, const void* packed, const float* xyz, int32_t N, float* uvs, float* grad_uvs,
+                                 void* stream) {
+    if (!net || !packed || !xyz || !uvs || !grad_uvs) return fail_msg("NULL argument");
+    if (int r = check_uvnet(net)) return r;
+    if (N < 0) return fail_msg("N < 0");
+    if (int r = launch_uv_taylor_packed_mixed(net, packed, xyz, N, uvs, grad_uvs, (hipStream_t)stream)) return fail("uv_taylor_mixed", (hipError_t)r);
+    return 0;
+}
+
 size_t texgs_uv_backward_temp_bytes(int32_t N) { return uv_backward_temp_bytes(N < 0 ? 0 : N); }
 
 int texgs_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,

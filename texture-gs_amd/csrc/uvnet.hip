@@ -28,6 +28,16 @@ struct UVArgs {
     const float* packed;           // [3 layers][4 bands][64 steps][64 lanes]
 };
 
+// The thin first layer, written with explicit roundings: every kernel of this file (f32, split-bf16, mixed, backward) forms the SAME
+// f32 pre-activation from the same inputs, whatever the compiler would have contracted -- so the f32-MFMA value columns of the f32
+// kernel, of the mixed kernel and of the backward's recomputation agree bit for bit, and with them the ReLU masks.
+__device__ __forceinline__ float uv_norm_in(float x, float off, float inv) { return __fmul_rn(__fsub_rn(x, off), inv); }
+__device__ __forceinline__ float uv_layer1_pre(float w0, float w1, float w2, float b, float x0, float x1, float x2) {
+    return __fmaf_rn(w2, x2, __fmaf_rn(w1, x1, __fmaf_rn(w0, x0, b)));
+}
+// (bias, then the embedding: the order the f32 kernel's epilogue has always used)
+__device__ __forceinline__ float uv_bias_emb(float acc, float bias, float emb) { return __fadd_rn(__fadd_rn(acc, bias), emb); }
+
 // W (row-major [128][128]) -> A-operand order of mfma_f32_32x32x2f32: lane l of band b at step s holds W[32b + (l & 31)][2s + (l >> 5)]
 __global__ void __launch_bounds__(256)
 k_uv_pack(const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ W4, float* __restrict__ packed) {
@@ -51,10 +61,10 @@ k_uv_taylor(UVArgs a, const float* __restrict__ xyz, int N, float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             inv[c] = a.scale ? 1.0f / a.scale[c] : 1.0f;
-            x[c] = (xyz[3 * n + c] - (a.off ? a.off[c] : 0.0f)) * inv[c];
+            x[c] = uv_norm_in(xyz[3 * n + c], a.off ? a.off[c] : 0.0f, inv[c]);
         }
         const float w0 = a.W1[3 * i], w1 = a.W1[3 * i + 1], w2 = a.W1[3 * i + 2];
-        const float pre = w0 * x[0] + w1 * x[1] + w2 * x[2] + (a.b1 ? a.b1[i] : 0.0f);
+        const float pre = uv_layer1_pre(w0, w1, w2, a.b1 ? a.b1[i] : 0.0f, x[0], x[1], x[2]);
         const bool on = pre > 0.0f;
         sX[i][p] = on ? pre : 0.0f;
         sX[i][UV_P + p] = on ? w0 * inv[0] : 0.0f;
@@ -83,8 +93,7 @@ k_uv_taylor(UVArgs a, const float* __restrict__ xyz, int N, float* __restrict__ 
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int i = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * bk;          // C/D layout: col = lane & 31
-            float val = acc0[v] + (bias ? bias[i] : 0.0f);
-            if (layer == 0) val += a.emb[i];
+            const float val = uv_bias_emb(acc0[v], bias ? bias[i] : 0.0f, layer == 0 ? a.emb[i] : 0.0f);
             const bool on = val > 0.0f;
             sX[i][bn] = on ? val : 0.0f;
             sX[i][UV_P + bn] = on ? acc1[v] : 0.0f;
@@ -175,10 +184,10 @@ k_uv_taylor_bf16x3(UVArgsB a, const float* __restrict__ xyz, int N, float* __res
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             inv[c] = a.scale ? 1.0f / a.scale[c] : 1.0f;
-            x[c] = (xyz[3 * n + c] - (a.off ? a.off[c] : 0.0f)) * inv[c];
+            x[c] = uv_norm_in(xyz[3 * n + c], a.off ? a.off[c] : 0.0f, inv[c]);
         }
         const float w0 = a.W1[3 * i], w1 = a.W1[3 * i + 1], w2 = a.W1[3 * i + 2];
-        const float pre = w0 * x[0] + w1 * x[1] + w2 * x[2] + (a.b1 ? a.b1[i] : 0.0f);
+        const float pre = uv_layer1_pre(w0, w1, w2, a.b1 ? a.b1[i] : 0.0f, x[0], x[1], x[2]);
         const bool on = pre > 0.0f;
         put(p, i, on ? pre : 0.0f);
         put(UV_P + p, i, on ? w0 * inv[0] : 0.0f);
@@ -216,8 +225,7 @@ k_uv_taylor_bf16x3(UVArgsB a, const float* __restrict__ xyz, int N, float* __res
             bf16x4 h, l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float val = acc[0][4 * q + r] + (bias ? bias[i0 + r] : 0.0f);
-                if (layer == 0) val += a.emb[i0 + r];
+                const float val = uv_bias_emb(acc[0][4 * q + r], bias ? bias[i0 + r] : 0.0f, layer == 0 ? a.emb[i0 + r] : 0.0f);
                 on[r] = val > 0.0f;
                 __bf16 x, y; split_bf16(on[r] ? val : 0.0f, x, y); h[r] = x; l[r] = y;
             }
@@ -260,6 +268,142 @@ k_uv_taylor_bf16x3(UVArgsB a, const float* __restrict__ xyz, int N, float* __res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ mixed variant (round 5)
+// VALUE in f32, TANGENTS in split bf16.  The value column decides everything discrete -- the ReLU masks, and through uvs the
+// texel a pixel samples -- so it stays on the f32-input MFMA exactly as in k_uv_taylor (same masks, same uvs to the last bit of
+// the accumulation order); the three tangent columns only ever multiply pixel offsets of a few pixels, where 1e-5 relative is two
+// orders below the operator's tolerance, and they are 3/4 of the work: they take the three-product bf16 path of
+// k_uv_taylor_bf16x3.  MFMA cycles per wave and layer: 64 x 64 (value) + 72 x 32 (tangents) = 6 400 against 16 384 all-f32.
+struct UVArgsM {
+    const float *W1, *b1, *b2, *emb, *b3, *b4, *W5, *b5, *off, *scale;
+    const float* packed_f32;       // k_uv_pack layout
+    const uint4* packed_b16;       // k_uv_pack_bf16x3 layout
+};
+
+__global__ void __launch_bounds__(256, 2)
+k_uv_taylor_mixed(UVArgsM a, const float* __restrict__ xyz, int N, float* __restrict__ uvs, float* __restrict__ J) {
+    __shared__ float sV[UV_H][UV_P];                                            // value activations [neuron][point]
+    __shared__ __attribute__((aligned(16))) __bf16 sH[3 * UV_P][UV_PITCH];     // tangent activations, high halves [plane * 32 + point][neuron]
+    __shared__ __attribute__((aligned(16))) __bf16 sL[3 * UV_P][UV_PITCH];     // low halves
+    __shared__ float sO[3][4 * UV_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = blockIdx.x * UV_P;
+    auto put = [&](int col, int i, float v) { __bf16 h, l; split_bf16(v, h, l); sH[col][i] = h; sL[col][i] = l; };
+    auto layer1 = [&](int i, int p, float& pre, float (&t)[3]) {
+        const int n = min(p0 + p, N - 1);
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float inv = a.scale ? 1.0f / a.scale[c] : 1.0f;
+            x[c] = uv_norm_in(xyz[3 * n + c], a.off ? a.off[c] : 0.0f, inv);
+            t[c] = a.W1[3 * i + c] * inv;
+        }
+        pre = uv_layer1_pre(a.W1[3 * i], a.W1[3 * i + 1], a.W1[3 * i + 2], a.b1 ? a.b1[i] : 0.0f, x[0], x[1], x[2]);
+    };
+    // ---- layer 1 (3 -> 128) on the VALU, twice: point-fastest for the f32 plane, neuron-fastest for the bf16 planes (each
+    // layout wants its own lane order; the recomputation is five FMAs)
+    for (int e = tid; e < UV_H * UV_P; e += 256) {
+        const int i = e >> 5, p = e & 31;
+        float pre, t[3];
+        layer1(i, p, pre, t);
+        sV[i][p] = pre > 0.0f ? pre : 0.0f;
+    }
+    for (int e = tid; e < UV_H * UV_P; e += 256) {
+        const int p = e >> 7, i = e & 127;
+        float pre, t[3];
+        layer1(i, p, pre, t);
+        const bool on = pre > 0.0f;
+        put(p, i, on ? t[0] : 0.0f); put(UV_P + p, i, on ? t[1] : 0.0f); put(2 * UV_P + p, i, on ? t[2] : 0.0f);
+    }
+    __syncthreads();
+    const int bn = lane & 31, bk = lane >> 5;
+    for (int layer = 0; layer < 3; ++layer) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x16{0.f};
+        {   // value: f32-input MFMA, as k_uv_taylor
+            float areg[64];
+            const float* __restrict__ pk = a.packed_f32 + ((size_t)(layer * 4 + wave) * 64) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 64; ++s) areg[s] = pk[s * 64];
+#pragma unroll
+            for (int s = 0; s < 64; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], sV[2 * s + bk][bn], acc[0], 0, 0, 0);
+        }
+        {   // tangents: three bf16 products per f32 product, as k_uv_taylor_bf16x3
+            bf16x8 ah[8], al[8];
+            const uint4* __restrict__ pk = a.packed_b16 + ((size_t)((layer * 4 + wave) * 8) * 2) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { ah[s] = __builtin_bit_cast(bf16x8, pk[(2 * s) * 64]); al[s] = __builtin_bit_cast(bf16x8, pk[(2 * s + 1) * 64]); }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sH[t * UV_P + bn][16 * s + 8 * bk]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sL[t * UV_P + bn][16 * s + 8 * bk]);
+                    acc[1 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc[1 + t], 0, 0, 0);
+                    acc[1 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc[1 + t], 0, 0, 0);
+                    acc[1 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc[1 + t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                           // every wave has read the layer's input
+        const float* bias = layer == 0 ? a.b2 : (layer == 1 ? a.b3 : a.b4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // C/D layout: col = lane & 31, rows (v & 3) + 8 (v >> 2) + 4 (lane >> 5): four consecutive per q
+            const int i0 = wave * 32 + 8 * q + 4 * bk;
+            bool on[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float val = uv_bias_emb(acc[0][4 * q + r], bias ? bias[i0 + r] : 0.0f, layer == 0 ? a.emb[i0 + r] : 0.0f);
+                on[r] = val > 0.0f;
+                sV[i0 + r][bn] = on[r] ? val : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x4 h, l;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { __bf16 x, y; split_bf16(on[r] ? acc[1 + t][4 * q + r] : 0.0f, x, y); h[r] = x; l[r] = y; }
+                *reinterpret_cast<bf16x4*>(&sH[t * UV_P + bn][i0]) = h; *reinterpret_cast<bf16x4*>(&sL[t * UV_P + bn][i0]) = l;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- output layer (128 -> 3): the value column from the f32 plane, the tangents from the re-joined halves
+    for (int e = tid; e < 3 * 4 * UV_P; e += 256) {
+        const int c = e >> 7, col = e & 127;
+        float o;
+        if (col < UV_P) {
+            o = a.b5 ? a.b5[c] : 0.0f;
+            for (int i = 0; i < UV_H; ++i) o += a.W5[c * UV_H + i] * sV[i][col];
+        } else {
+            o = 0.0f;
+            const int tc = col - UV_P;
+            for (int i = 0; i < UV_H; i += 8) {
+                const bf16x8 h = *reinterpret_cast<const bf16x8*>(&sH[tc][i]), l = *reinterpret_cast<const bf16x8*>(&sL[tc][i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o += a.W5[c * UV_H + i + j] * ((float)h[j] + (float)l[j]);
+            }
+        }
+        sO[c][col] = o;
+    }
+    __syncthreads();
+    if (tid < UV_P && p0 + tid < N) {
+        const int p = tid, n = p0 + p;
+        const float o0 = sO[0][p], o1 = sO[1][p], o2 = sO[2][p];
+        const float rn = 1.0f / fmaxf(sqrtf(o0 * o0 + o1 * o1 + o2 * o2), 1e-12f);
+        const float u0 = o0 * rn, u1 = o1 * rn, u2 = o2 * rn;
+        uvs[3 * n] = u0; uvs[3 * n + 1] = u1; uvs[3 * n + 2] = u2;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float d0 = sO[0][(j + 1) * UV_P + p], d1 = sO[1][(j + 1) * UV_P + p], d2 = sO[2][(j + 1) * UV_P + p];
+            const float ud = u0 * d0 + u1 * d1 + u2 * d2;
+            J[9 * n + j] = (d0 - u0 * ud) * rn;
+            J[9 * n + 3 + j] = (d1 - u1 * ud) * rn;
+            J[9 * n + 6 + j] = (d2 - u2 * ud) * rn;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ backward (round 5)
 // Gradients of uvs = UVNet(xyz) w.r.t. every weight, bias and the embedding for an upstream gradient g [N,3]: what
@@ -351,7 +495,8 @@ k_uv_backward(UVBwdArgs a) {
     __shared__ float sX[BW_P][4], sG[BW_P][4];            // the tile's (normalised) inputs and upstream gradients
     __shared__ float sW1[UV_H][4];                        // W1 | b1
     __shared__ float sW5[3][UV_H];
-    __shared__ float sBias[3][UV_H];                      // b2 + emb, b3, b4
+    __shared__ float sBias[3][UV_H];                      // b2, b3, b4
+    __shared__ float sEmb[UV_H];
     __shared__ float sO[4][3][BW_P];
     __shared__ float sDo[3][BW_P];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -359,7 +504,8 @@ k_uv_backward(UVBwdArgs a) {
     const int ni = tid & 127, hf = tid >> 7;              // the neuron / half of the tile's points this thread owns in the VALU phases
     for (int e = tid; e < UV_H; e += 256) {
         sW1[e][0] = a.W1[3 * e]; sW1[e][1] = a.W1[3 * e + 1]; sW1[e][2] = a.W1[3 * e + 2]; sW1[e][3] = a.b1 ? a.b1[e] : 0.0f;
-        sBias[0][e] = (a.b2 ? a.b2[e] : 0.0f) + a.emb[e];
+        sBias[0][e] = a.b2 ? a.b2[e] : 0.0f;
+        sEmb[e] = a.emb[e];
         sBias[1][e] = a.b3 ? a.b3[e] : 0.0f;
         sBias[2][e] = a.b4 ? a.b4[e] : 0.0f;
         sW5[0][e] = a.W5[e]; sW5[1][e] = a.W5[UV_H + e]; sW5[2][e] = a.W5[2 * UV_H + e];
@@ -383,13 +529,13 @@ k_uv_backward(UVBwdArgs a) {
     const int pT = pF + 3 * LSTR;                                                                 //             W2^T, W3^T, W4^T
     float RA[64], RB[64];
     bw_load_a(RA, pk, pF, lane);                                    // W2
-    auto relu_out = [&](BwPlane* sOut, const float* bias, const f32x16& c0, const f32x16& c1) {
+    auto relu_out = [&](BwPlane* sOut, const float* bias, const float* emb_or_null, const f32x16& c0, const f32x16& c1) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int i = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * bk;             // C/D layout: col = lane & 31
-            const float b = bias[i];
-            sOut[i][bn] = fmaxf(c0[v] + b, 0.0f);
-            sOut[i][32 + bn] = fmaxf(c1[v] + b, 0.0f);
+            const float b = bias[i], em = emb_or_null ? emb_or_null[i] : 0.0f;      // (the forward kernels' rounding order: same masks)
+            sOut[i][bn] = fmaxf(uv_bias_emb(c0[v], b, em), 0.0f);
+            sOut[i][32 + bn] = fmaxf(uv_bias_emb(c1[v], b, em), 0.0f);
         }
     };
     auto mask_into = [&](BwPlane* sH, const f32x16& c0, const f32x16& c1) {       // d_in = c . [h > 0], in place of h
@@ -416,7 +562,7 @@ k_uv_backward(UVBwdArgs a) {
             const bool ok = p0 + tid < a.N;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                sX[tid][c] = (a.xyz[3 * n + c] - off[c]) * inv[c];
+                sX[tid][c] = uv_norm_in(a.xyz[3 * n + c], off[c], inv[c]);
                 sG[tid][c] = ok ? a.g[3 * n + c] : 0.0f;
             }
         }
@@ -424,7 +570,7 @@ k_uv_backward(UVBwdArgs a) {
         // ---- layer 1 (3 -> 128), VALU
         for (int e = tid; e < UV_H * BW_P; e += 256) {
             const int i = e >> 6, p = e & 63;
-            sH1[i][p] = fmaxf(sW1[i][0] * sX[p][0] + sW1[i][1] * sX[p][1] + sW1[i][2] * sX[p][2] + sW1[i][3], 0.0f);
+            sH1[i][p] = fmaxf(uv_layer1_pre(sW1[i][0], sW1[i][1], sW1[i][2], sW1[i][3], sX[p][0], sX[p][1], sX[p][2]), 0.0f);
         }
         __syncthreads();
         // ---- forward, three GEMMs; the next GEMM's A slice is loaded while this one runs
@@ -432,21 +578,21 @@ k_uv_backward(UVBwdArgs a) {
             bw_load_a(RB, pk, pF + LSTR, lane);                     // W3
             f32x16 c0 = {0.f}, c1 = {0.f};
             bw_gemm(RA, sH1, bn, bk, c0, c1);
-            relu_out(sA, sBias[0], c0, c1);
+            relu_out(sA, sBias[0], sEmb, c0, c1);
         }
         __syncthreads();
         {
             bw_load_a(RA, pk, pF + 2 * LSTR, lane);                 // W4
             f32x16 c0 = {0.f}, c1 = {0.f};
             bw_gemm(RB, sA, bn, bk, c0, c1);
-            relu_out(sH2, sBias[1], c0, c1);
+            relu_out(sH2, sBias[1], nullptr, c0, c1);
         }
         __syncthreads();
         {
             bw_load_a(RB, pk, pT + 2 * LSTR, lane);                 // W4^T
             f32x16 c0 = {0.f}, c1 = {0.f};
             bw_gemm(RA, sH2, bn, bk, c0, c1);
-            relu_out(sH3, sBias[2], c0, c1);
+            relu_out(sH3, sBias[2], nullptr, c0, c1);
         }
         __syncthreads();
         // ---- output layer + F.normalize and its backward
@@ -668,5 +814,23 @@ int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, 
     }
     const int n_out = 3 * UV_H * UV_H + BW_SMALL * UV_H + 3;
     hipLaunchKernelGGL(k_uv_backward_reduce, dim3((n_out + 255) / 256), dim3(256), 0, s, partW, partS, partB5, G, o);
+    return (int)hipGetLastError();
+}
+
+// mixed variant: `packed` holds BOTH layouts back to back (2 x uv_taylor_temp_bytes(): f32 pack, then split-bf16 pack)
+int launch_uv_pack_mixed(const TexGSUVNet* net, void* packed, hipStream_t s) {
+    if (int r = launch_uv_pack(net, packed, s)) return r;
+    return launch_uv_pack_bf16x3(net, reinterpret_cast<char*>(packed) + uv_taylor_temp_bytes(), s);
+}
+
+int launch_uv_taylor_packed_mixed(const TexGSUVNet* net, const void* packed, const float* xyz, int N, float* uvs, float* grad_uvs,
+                                  hipStream_t s) {
+    if (N <= 0) return 0;
+    UVArgsM a;
+    a.W1 = net->W1; a.b1 = net->b1; a.b2 = net->b2; a.emb = net->emb; a.b3 = net->b3; a.b4 = net->b4; a.W5 = net->W5; a.b5 = net->b5;
+    a.off = net->xyz_offset; a.scale = net->xyz_scale;
+    a.packed_f32 = reinterpret_cast<const float*>(packed);
+    a.packed_b16 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(packed) + uv_taylor_temp_bytes());
+    hipLaunchKernelGGL(k_uv_taylor_mixed, dim3((N + UV_P - 1) / UV_P), dim3(256), 0, s, a, xyz, N, uvs, grad_uvs);
     return (int)hipGetLastError();
 }

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8
@@ -70,7 +70,7 @@ EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "te
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
            "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
            "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_norm_from_depth", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes", "texgs_uv_pack", "texgs_uv_taylor_packed",
-           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3", "texgs_uv_backward", "texgs_uv_backward_temp_bytes"]
+           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3", "texgs_uv_backward", "texgs_uv_backward_temp_bytes", "texgs_uv_pack_mixed", "texgs_uv_taylor_packed_mixed"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
 
@@ -130,6 +130,10 @@ def load():
     lib.texgs_uv_pack_bf16x3.restype = C.c_int
     lib.texgs_uv_taylor_packed_bf16x3.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_uv_taylor_packed_bf16x3.restype = C.c_int
+    lib.texgs_uv_pack_mixed.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p]
+    lib.texgs_uv_pack_mixed.restype = C.c_int
+    lib.texgs_uv_taylor_packed_mixed.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.texgs_uv_taylor_packed_mixed.restype = C.c_int
     lib.texgs_uv_backward_temp_bytes.argtypes = [C.c_int32]
     lib.texgs_uv_backward_temp_bytes.restype = C.c_size_t
     lib.texgs_uv_backward.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, P(UVNetGradStruct), C.c_void_p, C.c_void_p]

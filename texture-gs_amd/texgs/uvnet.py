@@ -94,9 +94,10 @@ class UVNet(nn.Module):
     def __init__(self, xyz_offset=None, xyz_scale=None, precision="fp32"):
         super().__init__()
         # arithmetic of the fused kernel's three 128x128 layers: "fp32" = f32-input MFMA (exact f32 products; the checked default),
-        # "bf16x3" = every operand split into two bf16 halves, three bf16 MFMAs per product (~2.5x faster, uvs / J within ~2e-5)
-        if precision not in ("fp32", "bf16x3"):
-            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        # "bf16x3" = every operand split into two bf16 halves, three bf16 MFMAs per product (~2.5x faster, uvs / J within ~2e-5),
+        # "mixed" = the value column as "fp32" (same uvs, same ReLU masks), the three tangent columns as "bf16x3" (J within ~1e-5)
+        if precision not in ("fp32", "bf16x3", "mixed"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'mixed'")
         self.precision = precision
         self.pre_mlp = _mlp(1, 3, HIDDEN)
         self.mlp = _mlp(2, HIDDEN, 3)
@@ -179,8 +180,10 @@ class UVNet(nn.Module):
         p = lambda t: None if t is None else t.data_ptr()
         net = _lib.UVNetStruct(*[p(t) for t in ws], HIDDEN)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        split = self.precision == "bf16x3"
-        pack_fn, eval_fn = (lib.texgs_uv_pack_bf16x3, lib.texgs_uv_taylor_packed_bf16x3) if split else (lib.texgs_uv_pack, lib.texgs_uv_taylor_packed)
+        split = self.precision
+        pack_fn, eval_fn = {"fp32": (lib.texgs_uv_pack, lib.texgs_uv_taylor_packed),
+                            "bf16x3": (lib.texgs_uv_pack_bf16x3, lib.texgs_uv_taylor_packed_bf16x3),
+                            "mixed": (lib.texgs_uv_pack_mixed, lib.texgs_uv_taylor_packed_mixed)}[split]
         key = tuple((t.data_ptr(), t._version) for t in (self.pre_mlp[2].weight, self.mlp[0].weight, self.mlp[2].weight)) + (dev, split)
         uvs = torch.empty(N, 3, dtype=torch.float32, device=dev)
         juv = torch.empty(N, 9, dtype=torch.float32, device=dev)
@@ -188,7 +191,7 @@ class UVNet(nn.Module):
             slot = (dev.index, int(stream))
             ent = self._packed.get(slot)
             if ent is None or ent[0] != key:
-                buf = ent[1] if ent is not None else torch.empty(lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)
+                buf = ent[1] if ent is not None else torch.empty(2 * lib.texgs_uv_taylor_temp_bytes(), dtype=torch.uint8, device=dev)   # ("mixed" holds both layouts)
                 _lib.check(pack_fn(C.byref(net), p(buf), stream), "texgs_uv_pack")       # (re-packed in place: same stream, in order)
                 self._packed[slot] = ent = (key, buf)
             _lib.check(eval_fn(C.byref(net), p(ent[1]), p(x), N, p(uvs), p(juv), stream), "texgs_uv_taylor_packed")
