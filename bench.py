@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the extra serial steps behind the per-kernel table (profiling runs: every launch is then a pipelined one)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the reference-call-pattern / reference-iteration / retexture legs after the timed region (A/B runs)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
                     help="HIP streams the views of a step are pipelined over (texgs.multiview.ViewPipeline); 1 = serial")
     ap.add_argument("--order", default=os.environ.get("TEXGS_BENCH_ORDER", "accumulate"), choices=["backward", "accumulate", "none"])
@@ -394,7 +396,7 @@ def main():
     # inputs, a fresh non-leaf means2D per view, plain autograd (no grad_sink) -- what render/uv_tex_render.py does.
     compat = None
     ref_iter = None
-    if rank == 0 and with_bwd and not args.no_kernel_table and not untextured:
+    if rank == 0 and with_bwd and not args.no_kernel_table and not args.no_extra_legs and not untextured:
         raw = {n: leaves[n].detach().clone().requires_grad_(True) for n in names}
         raw["scales"] = leaves["scales"].detach().log().requires_grad_(True)
         op = leaves["opacities"].detach().clamp(1e-6, 1 - 1e-6)
@@ -467,7 +469,7 @@ def main():
 
     # ---- forward-only callers that build a graph (retexture.py:27, visual_step: parameters require grad, backward never runs)
     retex = None
-    if rank == 0 and not with_bwd and not args.no_kernel_table and not untextured:
+    if rank == 0 and not with_bwd and not args.no_kernel_table and not args.no_extra_legs and not untextured:
         from texgs import rasterizer as RZ
         saved_gc = RZ.GEOM_CACHE
         RZ.GEOM_CACHE = False               # (every frame here is a different view anyway)

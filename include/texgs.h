@@ -26,10 +26,11 @@
 extern "C" {
 #endif
 
-#define TEXGS_ABI_VERSION 14
+#define TEXGS_ABI_VERSION 15
 #define TEXGS_TILE 16          /* 16x16 pixel tiles, one 256-thread workgroup (4 wave64) per tile     */
 #define TEXGS_REC_TEST_FLOATS 8    /* per-Gaussian TEST record (32 B): what the per-block culls and the alpha test read  */
-#define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull */
+#define TEXGS_REC_SHADE_FLOATS 20  /* per-Gaussian SHADING record (80 B): fetched only for Gaussians that survive a cull (one record per
+                                      128-byte line, 32 floats, was measured: K6 -6 us, K1 +3, K7 +-0 -- not kept) */
 #define TEXGS_ACC_FLOATS 32    /* per-Gaussian moment accumulators of the backward: one 128-byte line  */
 
 /* Per-call configuration = GaussianRasterizationSettings (render/uv_tex_render.py:25-38). */
@@ -76,8 +77,9 @@ typedef struct TexGSInputs {
 /* Per-Gaussian state written by texgs_preprocess_forward (K1) and texgs_read_num_rendered (K2). */
 typedef struct TexGSGeom {
     float*    rec_test;        /* f32[N,8]:  xy(2) conic(-a/2,-b,-c/2) opacity rcull thr -- read for EVERY (8x8 block, instance) pair */
-    float*    rec_shade;       /* f32[N,20]: g(2) G(6) | phi(3) viewdep(3) | depth normal(3) pad(2) -- read only for instances
-                                  that can reach alpha >= 1/255 somewhere in the block (about a third of them)            */
+    float*    rec_shade;       /* f32[N,20]: g(2) G(6) | phi(3) viewdep(3) | depth normal(3) xy(2) -- read only for instances
+                                  that can reach alpha >= 1/255 somewhere in the block (about a third of them); the last two
+                                  words repeat the test record's xy (v15) so that K7's per-item gather needs one record    */
     float*    depth;           /* f32[N] view-space z = the depth sort key (its bit pattern); 0xFFFFFFFF for culled Gaussians */
     int32_t*  radii;           /* i32[N] screen radius in px; 0 = culled (operator output `radii`)     */
     uint32_t* rect;            /* u32[N,2]: (minx | miny<<16), (maxx | maxy<<16) tile rectangle        */
@@ -133,8 +135,29 @@ typedef struct TexGSImage {
                                   grouping).  Footprints whose entry belongs to another bin (~2 %) are counted in the second half
                                   of tex_bin_count and appended through TexGSGrads.tex_bin_cursor.  No initialisation; written
                                   for every block.                                                                       */
+    /* K6 -> K7 ITEM STREAM (v15), all NULL / 0 or all set.  Set = "a backward that wants per-Gaussian gradients will follow": K6
+       appends, per 8x8 pixel block and in blend order (front to back), one 12-byte item {T before the pair, alpha_raw = opacity *
+       exp(power), Gaussian id << 6 | pixel lane} for every CONTRIBUTING (pixel, Gaussian) pair -- what the lineage's backward
+       recomputes per pair by replaying the tile list -- and K7 walks the block's items back to front instead of
+       re-testing the survivor lists: no test loop, no transmittance recurrence (T /= 1 - alpha), decisions identical by
+       construction.  Pages of TEXGS_ITEM_PAGE items (three planes of TEXGS_ITEM_PAGE words: T, alpha_raw, key) are taken from
+       item_sub_pools sub-pools of the buffer with one returning atomic per page; a block's pages are chained backwards through
+       item_link.  A buffer that is too small is not an error: K6 raises item_ctl[TEXGS_ITEM_CTL_FLAG], the stream kernel does
+       nothing and the survivor-replay kernel (the hand-off above, always written) runs instead; the cursors keep counting, so
+       max(item_ctl[16 * s]) * item_sub_pools is what the view needed (the caller sizes the next buffer from it). */
+    uint32_t* item_pages;      /* u32[item_page_cap * 3 * TEXGS_ITEM_PAGE]; no initialisation                                     */
+    uint32_t* item_link;       /* u32[item_page_cap]: the block's previous page (0xFFFFFFFF: none); no initialisation              */
+    uint32_t* item_tail;       /* u32[4 * T * 2]: per block {last page, items}; written for every block                            */
+    uint32_t* item_ctl;        /* u32[TEXGS_ITEM_CTL_WORDS]: sub-pool cursors (one per 64-byte line) + the overflow flag; zero-filled
+                                  by the library before K6                                                                         */
+    uint32_t  item_page_cap;   /* pages item_pages / item_link hold; sub-pool s owns pages [s * cap / pools, (s + 1) * cap / pools) */
+    uint32_t  item_sub_pools;  /* power of two, 1..TEXGS_ITEM_MAX_POOLS (one hot atomic word serialises at ~13 ns per request)    */
 } TexGSImage;
 #define TEXGS_RESV_WORDS 192
+#define TEXGS_ITEM_PAGE 256
+#define TEXGS_ITEM_MAX_POOLS 64
+#define TEXGS_ITEM_CTL_FLAG (16 * TEXGS_ITEM_MAX_POOLS)
+#define TEXGS_ITEM_CTL_WORDS (16 * TEXGS_ITEM_MAX_POOLS + 16)
 
 #define TEXGS_ACC_MEANS3D 1
 #define TEXGS_ACC_MEANS2D 2
@@ -176,15 +199,16 @@ typedef struct TexGSGrads {
     float* dL_dcov3D;          /* f32[N,6] or NULL (required with TexGSInputs.cov3D_precomp when Gaussian gradients are wanted;
                                   off-diagonal entries carry both symmetric halves, as the lineage's do)                 */
     uint32_t want;             /* TEXGS_WANT_* bit mask, non-zero                                      */
-    float*    tex_bins;        /* texture-gradient records, f32[5 * tex_rec_cap] (plane-major), or NULL.
-                                  The texture is cut into 32x32-texel blocks ("bins", 6 * ceil(R/32)^2 of them).  K7 appends
-                                  one 20-byte record {fx | cell x, fy | cell y, dL/dtexel-colour rgb} per bilinear footprint
-                                  to the list of the bin the footprint is anchored in; the lists are contiguous and exactly
-                                  sized from TexGSImage.tex_bin_count (~0.37 GB for a C3 view).  The reduce kernel at the end
-                                  of texgs_backward_render sums each list in LDS and adds every texel to dL_dtexture once.
-                                  NULL (or no counts, or cap 0) = fp32 atomics straight into dL_dtexture (~20 G requests/s
-                                  memory-side: 0.7 ms per C3 view).  Contents need no initialisation.  The 5 low mantissa
-                                  bits of fx / fy carry the cell (fx, fy keep 18 bits, rounded).                         */
+    float*    tex_bins;        /* texture-gradient records, 16 bytes each: u32[4 * tex_rec_cap] (TEXGS_TEXBIN_RECORD_FLOATS words per
+                                  record), 16-byte aligned, or NULL.  The texture is cut into 32x32-texel blocks ("bins", 6 *
+                                  ceil(R/32)^2 of them).  K7 writes one record {fx, fy (18 bits each), tap-00 cell inside the bin
+                                  (5 + 5 bits, in the low mantissa bits of r and g), dL/dtexel-colour rgb} per bilinear footprint
+                                  with one 16-byte store into the list of the bin the footprint is anchored in (v15; 20 bytes in
+                                  five planes until v14); the lists are contiguous and exactly sized from
+                                  TexGSImage.tex_bin_count (~0.3 GB for a C3 view).  The reduce kernel at the end of
+                                  texgs_backward_render sums each list in LDS and adds every texel to dL_dtexture once.  NULL (or no
+                                  counts, or cap 0) = fp32 atomics straight into dL_dtexture (~20 G requests/s memory-side: 0.7 ms
+                                  per C3 view).  Contents need no initialisation.                                           */
     uint32_t* tex_bin_cursor;  /* u32[texgs_tex_bin_count(R) + 2]: the fill cursors of the lists' OVERFLOW parts (scratch, set at the
                                   start of every backward: no initialisation) + two status words: [count] receives
                                   max(records a call needed) -- zero it once; never cleared by the library: the caller sizes
@@ -205,7 +229,7 @@ const char* texgs_last_error(void);
 size_t texgs_scan_temp_bytes(int32_t num_gaussians);
 size_t texgs_sort_temp_bytes(uint32_t num_rendered, uint32_t num_tiles);
 size_t texgs_tex_bin_count(int32_t tex_res);
-#define TEXGS_TEXBIN_RECORD_FLOATS 5
+#define TEXGS_TEXBIN_RECORD_FLOATS 4
 
 /* K1: frustum cull, EWA projection, radius, tile rect, SH view term, normal, UV Taylor pre-fold, depth sort key, and
  * D = sum of tiles_touched (device word).  Replaces the first half of _C.rasterize_gaussians. */

@@ -517,3 +517,109 @@ def test_wave_ops_primitives_on_hardware(lib_built):
         for name, row in zip(["lane_xor4", "lane_xor8", "sum_xor16", "sum_xor32", "wave_sum", "reduce_transposed16",
                               "reduce_transposed32", "reduce32_bankfirst", "wave_max_i"], o):
             assert float(row.abs().max()) == 0.0, (name, seed, row)
+
+
+def _stream_case():
+    scene = synth.make_scene(4000, 96, seed=31, scale_mean=0.03, random_jacobian=True)
+    cam = synth.fibonacci_cameras(6, 272, 208)[2]
+    target, nhat = synth.make_targets(208, 272, seed=6)
+    return scene, cam, target, nhat
+
+
+@pytest.mark.parametrize("surface", ["textured", "frozen_texture"])
+def test_item_stream_backward_equals_survivor_replay(lib_built, surface):
+    """The opt-in K6 -> K7 item stream (texgs.h v15: K6 leaves {T, alpha_raw, Gaussian | pixel} per contributing pair, K7 walks the
+    items instead of re-testing the survivor lists): forward images bit-identical, every gradient equal to the survivor-replay
+    backward's up to fp32 summation order and the replay's recomputed transmittance (T /= 1 - alpha vs the forward's own T); the
+    stream really ran (no overflow flag, every block's item count consistent with its pixels' contributor counts)."""
+    from texgs import rasterizer as RZ
+    scene, cam, target, nhat = _stream_case()
+    saved = (RZ.USE_ITEMS, RZ.GEOM_CACHE)
+    res, outs = {}, {}
+    try:
+        RZ.GEOM_CACHE = False      # (every call here renders the same view: a later forward must not re-use an earlier one's stream)
+        RZ.USE_ITEMS = True        # the first view of a new size sizes its page buffer by guess; the next ones from what that one needed
+        Hh.hip_run(scene, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)
+        torch.cuda.synchronize()
+        for mode in (False, True):
+            RZ.USE_ITEMS = mode
+            if surface == "textured":
+                outs[mode], res[mode] = Hh.hip_run(scene, cam, 2, torch.tensor([0.2, 0.1, 0.0]), with_grad=True, target=target, nhat=nhat,
+                                                   depth_weight=0.05)
+            else:
+                dev = torch.device("cuda:0")
+                st = Hh.settings_for(cam, 2, torch.zeros(3), device=dev, cls=RZ.GaussianRasterizationSettings)
+                lv = {n: getattr(scene, n).clone().to(dev).requires_grad_(n != "texture") for n in
+                      ("means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture")}
+                out = RZ.GaussianRasterizer(st)(means3D=lv["means3D"], means2D=None, shs=lv["shs"], opacities=lv["opacities"],
+                                                scales=lv["scales"], rotations=lv["rotations"], uvs=lv["uvs"],
+                                                gradient_uvs=scene.gradient_uvs.to(dev), texture=lv["texture"], extra_attrs=None)
+                synth.synthetic_loss(out[0], out[3], out[2], target.to(dev), nhat.to(dev)).backward()
+                outs[mode] = [o.detach() for o in out[:4]]
+                res[mode] = {n: t.grad for n, t in lv.items() if t.grad is not None}
+        # the stream's own bookkeeping, through the raw path
+        RZ.USE_ITEMS = True
+        st = Hh.settings_for(cam, 2, torch.zeros(3), device=torch.device("cuda:0"), cls=RZ.GaussianRasterizationSettings)
+        dv = {n: getattr(scene, n).to("cuda:0") for n in ("means3D", "shs", "opacities", "scales", "rotations", "uvs", "gradient_uvs", "texture")}
+        _, s = RZ.forward_raw(st, dv["means3D"], dv["shs"], dv["opacities"].reshape(-1), dv["scales"], dv["rotations"], dv["uvs"],
+                              dv["gradient_uvs"], dv["texture"])
+        torch.cuda.synchronize()
+        ctl, tail = s.tensors["item_ctl"], s.tensors["item_tail"]
+        assert ctl is not None and int(ctl[_lib_const("ITEM_CTL_FLAG")]) == 0
+        items = tail[:, 1].long()
+        nc = s.tensors["n_contrib"]
+        assert int(items.sum()) > 0
+        # a block with a contributing pixel has items, a block without has none; no block has more items than pixels x list length
+        H, W = nc.shape
+        ty, tx = (H + 15) // 16, (W + 15) // 16
+        pad = torch.zeros(ty * 16, tx * 16, dtype=torch.int64, device=nc.device)
+        pad[:H, :W] = nc.long()
+        blk = pad.reshape(ty, 2, 8, tx, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(ty * tx, 4, 64)      # [tile][block = 2 * row half + col half][pixel]
+        any_contrib = (blk > 0).any(-1).reshape(-1)
+        assert torch.equal(items > 0, any_contrib)
+        assert bool((items <= blk.sum(-1).reshape(-1)).all())
+    finally:
+        RZ.USE_ITEMS, RZ.GEOM_CACHE = saved
+        RZ.release_scratch()
+    for a, b in zip(outs[False][:4], outs[True][:4]):
+        assert torch.equal(a, b)
+    for name in res[False]:
+        r = Hh.rel_err(res[True][name], res[False][name])
+        Hh.report(f"item_stream/{surface}/stream_vs_replay/{name}", rel_l2=r)
+        assert r < 2e-5, (name, r)
+
+
+def _lib_const(name):
+    from texgs import _lib
+    return getattr(_lib, name)
+
+
+def test_item_stream_page_overflow_falls_back_to_the_replay(lib_built):
+    """A page buffer that is too small (here: two pages per sub-pool) is not an error: K6 raises the overflow flag, the stream kernel
+    does nothing and the survivor-replay kernel produces the gradients -- the same numbers as with the stream off."""
+    from texgs import rasterizer as RZ
+    scene, cam, target, nhat = _stream_case()
+    saved = (RZ.USE_ITEMS, RZ.ITEM_PAGES_FIXED, RZ.GEOM_CACHE)
+    res = {}
+    try:
+        RZ.GEOM_CACHE = False
+        for mode, (use, pages) in dict(replay=(False, 0), starved=(True, 2)).items():
+            RZ.USE_ITEMS, RZ.ITEM_PAGES_FIXED = use, pages
+            RZ.release_scratch()
+            _, res[mode] = Hh.hip_run(scene, cam, 2, torch.zeros(3), with_grad=True, target=target, nhat=nhat)
+        RZ.USE_ITEMS, RZ.ITEM_PAGES_FIXED = True, 2
+        st = Hh.settings_for(cam, 2, torch.zeros(3), device=torch.device("cuda:0"), cls=RZ.GaussianRasterizationSettings)
+        dv = {n: getattr(scene, n).to("cuda:0") for n in ("means3D", "shs", "opacities", "scales", "rotations", "uvs", "gradient_uvs", "texture")}
+        _, s = RZ.forward_raw(st, dv["means3D"], dv["shs"], dv["opacities"].reshape(-1), dv["scales"], dv["rotations"], dv["uvs"],
+                              dv["gradient_uvs"], dv["texture"])
+        torch.cuda.synchronize()
+        ctl = s.tensors["item_ctl"]
+        assert int(ctl[_lib_const("ITEM_CTL_FLAG")]) == 1
+        pools = int(s.img.item_sub_pools)
+        assert int(ctl[0:16 * pools:16].max()) * pools > int(s.img.item_page_cap)       # the cursors kept counting: what the view needs
+    finally:
+        RZ.USE_ITEMS, RZ.ITEM_PAGES_FIXED, RZ.GEOM_CACHE = saved
+        RZ.release_scratch()
+    for name in res["replay"]:
+        r = Hh.rel_err(res["starved"][name], res["replay"][name])
+        assert r < 2e-5, (name, r)        # (the same kernel twice: the run-to-run floor of its fp32 atomics)

@@ -53,7 +53,7 @@ def test_backward_flavours_equal_the_full_backward(lib_built):
     assert geo["texture"] is None
     r = Hh.rel_err(tex["texture"], full["texture"])
     Hh.report("gating/texture_only_vs_full/texture", rel_l2=r)
-    assert r < 1e-6
+    assert r < 3e-6           # (two differently shaped kernels: k7_lds vs k7_occ -- same numbers up to the order of their fp32 sums)
     for n in geo:
         if n == "texture":
             continue

@@ -185,6 +185,18 @@ static int render_forward_impl(const TexGSFrame* frame, const TexGSInputs* in, c
         hipError_t e = hipMemsetAsync(img->tex_bin_count, 0, sizeof(uint32_t) * 2 * tex_bin_count(c.R), s);
         if (e != hipSuccess) return fail("tex_bin_count memset", e);
     }
+    if (img->item_pages || img->item_link || img->item_tail || img->item_ctl) {       // the K6 -> K7 item stream: all or nothing
+        if (!img->item_pages || !img->item_link || !img->item_tail || !img->item_ctl)
+            return fail_msg("TexGSImage.item_pages / item_link / item_tail / item_ctl must be all NULL or all set");
+        if (!img->survivors) return fail_msg("the item stream needs the survivor hand-off beside it (its fallback)");
+        const uint32_t np = img->item_sub_pools;
+        if (np == 0u || np > TEXGS_ITEM_MAX_POOLS || (np & (np - 1u)) != 0u) return fail_msg("item_sub_pools must be a power of two in [1, 64]");
+        if (img->item_page_cap / np < 2u) return fail_msg("item_page_cap must hold at least two pages per sub-pool");
+        if (!counters_zeroed) {
+            hipError_t e = hipMemsetAsync(img->item_ctl, 0, sizeof(uint32_t) * TEXGS_ITEM_CTL_WORDS, s);
+            if (e != hipSuccess) return fail("item_ctl memset", e);
+        }
+    }
     { ProfScope p(TEXGS_K_RENDER_FWD, s); launch_render_fwd(c, frame, in, geom, bin, img, s); }
     return check(frame, s, "render_fwd");
 }
@@ -210,7 +222,8 @@ int texgs_bin_sort_render_forward(const TexGSFrame* frame, const TexGSInputs* in
     }
     // (the one-workgroup tile-order kernel also zero-fills the per-bin footprint counters K6 adds into)
     { ProfScope p(TEXGS_K_RANGES, s);
-      launch_ranges(c, bin, img->tex_bin_count, img->tex_bin_count ? 2 * (int)tex_bin_count(c.R) : 0, s); }
+      launch_ranges(c, bin, img->tex_bin_count, img->tex_bin_count ? 2 * (int)tex_bin_count(c.R) : 0,
+                    img->item_ctl, img->item_ctl ? TEXGS_ITEM_CTL_WORDS : 0, s); }
     if (int r = check(frame, s, "tile_ranges")) return r;
     return render_forward_impl(frame, in, geom, bin, img, stream, true);
 }

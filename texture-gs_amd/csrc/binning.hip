@@ -726,11 +726,12 @@ k_ranges(uint32_t D, const uint64_t* __restrict__ keys, uint2* __restrict__ rang
 // bucket in ONE workgroup (speed only: any order is correct; ties keep no particular order).
 __global__ void __launch_bounds__(1024)
 k_tile_order(uint32_t T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* __restrict__ zero_words,
-             int num_zero_words) {
+             int num_zero_words, uint32_t* __restrict__ zero_words2, int num_zero_words2) {
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int k = tid; k < num_zero_words; k += 1024) zero_words[k] = 0u;       // K6's per-bin footprint counters (texgs.h tex_bin_count)
+    for (int k = tid; k < num_zero_words2; k += 1024) zero_words2[k] = 0u;     // K6's item-stream page cursors + flag (texgs.h item_ctl)
     auto bucket = [](uint32_t len) -> uint32_t {            // monotone decreasing in len: 1023 = empty, 0 = longest
         if (len == 0u) return 1023u;
         const uint32_t e = 31u - (uint32_t)__clz((int)len);              // floor(log2 len), 0..31
@@ -916,7 +917,8 @@ int launch_sort(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStrea
     return (int)hipGetLastError();
 }
 
-void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int num_zero_words, hipStream_t s) {
+void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int num_zero_words, uint32_t* zero_words2,
+                   int num_zero_words2, hipStream_t s) {
     const uint32_t T = (uint32_t)(c.tiles_x * c.tiles_y);
     if (b->num_rendered == 0) (void)hipMemsetAsync(b->ranges, 0, sizeof(uint32_t) * 2 * T, s);     // no K3 ran: every tile is empty
     if (b->num_rendered > 0) {
@@ -925,5 +927,5 @@ void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int
                            reinterpret_cast<uint2*>(b->ranges));
     }
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, reinterpret_cast<const uint2*>(b->ranges), b->tile_order,
-                       zero_words, num_zero_words);
+                       zero_words, num_zero_words, zero_words2, num_zero_words2);
 }

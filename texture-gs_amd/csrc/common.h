@@ -65,7 +65,8 @@ size_t scan_temp_bytes(int N);
 size_t sort_temp_bytes(uint32_t D, uint32_t T);
 void launch_duplicate(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStream_t s);
 int  launch_sort(const CamConst& c, const TexGSGeom* g, TexGSBinning* b, hipStream_t s);
-void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int num_zero_words, hipStream_t s);
+void launch_ranges(const CamConst& c, TexGSBinning* b, uint32_t* zero_words, int num_zero_words, uint32_t* zero_words2,
+                   int num_zero_words2, hipStream_t s);
 void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, TexGSImage* img, hipStream_t s);
 size_t tex_bin_count(int R);

@@ -422,7 +422,7 @@ k_preprocess_fwd(CamConst C, const float* __restrict__ vm, const float* __restri
     float4* rs = rec_shade + (size_t)i * (TEXGS_REC_SHADE_FLOATS / 4);
     rs[0] = s0; rs[1] = s1; rs[2] = s2;
     rs[3] = make_float4(vd[1], vd[2], g.t[2], g.n[0]);
-    rs[4] = make_float4(g.n[1], g.n[2], 0.f, 0.f);
+    rs[4] = make_float4(g.n[1], g.n[2], g.xy[0], g.xy[1]);      // (xy again: K7's per-item gather of this record needs no second one)
     mix(__float_as_uint(g.t[2])); mix(rc.x); mix(rc.y);
     mix(__float_as_uint(t0.x)); mix(__float_as_uint(t0.y)); mix(__float_as_uint(t0.z)); mix(__float_as_uint(t0.w));
     mix(__float_as_uint(t1.x)); mix(__float_as_uint(t1.y)); mix(__float_as_uint(t1.z)); mix(__float_as_uint(t1.w));

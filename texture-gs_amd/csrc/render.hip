@@ -132,7 +132,20 @@ struct PixArgs {
     uint16_t* surv_qm;       // bit q: the survivor can reach quadrant q
     uint32_t* surv_cnt;      // [4 * tiles] survivors written per block
     uint32_t* resv;          // [4 * tiles][3][64] per-block reservation table {bin | offset inside the bin's list | count} (NULL: no binned texture gradient)
+    // K6 -> K7 ITEM STREAM (texgs.h v15; item_pages NULL: off): one {T, alpha_raw, Gaussian id << 6 | pixel lane} per contributing pair
+    uint32_t* item_pages;    // [cap][3][TG_PAGE]
+    uint32_t* item_link;     // [cap] previous page of the same block
+    uint32_t* item_tail;     // [4 * tiles][2] {last page, items}
+    uint32_t* item_ctl;      // sub-pool cursors (every 16th word) + overflow flag
+    uint32_t  item_sub_cap;  // pages per sub-pool
+    uint32_t  item_sub_mask; // sub-pools - 1
+    const uint32_t* run_if;  // the survivor-replay K7 only: do nothing unless this word is non-zero (NULL: always run)
 };
+#define TG_PAGE TEXGS_ITEM_PAGE
+#define TG_PAGE_SHIFT 8
+static_assert((1 << TG_PAGE_SHIFT) == TG_PAGE, "page size");
+#define TG_NOPAGE 0xFFFFFFFFu
+#define TG_PAGE_UNSET 0xFFFFFFFEu
 
 // workgroup (= one wave) -> (tile, 8x8 block).  Tiles are launched longest-list-first (tile_order).  The four blocks of a
 // tile get ids that are equal mod 8, so they run on the same XCD (workgroup b is observed on XCD b % 8: speed only) and
@@ -209,7 +222,7 @@ __device__ __forceinline__ void load_chunk(const PixArgs& a, Planes& P, int lane
     T0 = z; T1 = make_float4(0.f, 0.f, -1.f, 1.f);
     if (live) {
         const float4* __restrict__ tp = a.rec_test + 2 * (size_t)id;
-        const float4* __restrict__ sp = a.rec_shade + 5 * (size_t)id;
+        const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)id;
         T0 = tp[0]; T1 = tp[1]; S0 = sp[0]; S1 = sp[1]; S2 = sp[2]; S3 = sp[3]; S4 = sp[4];
     }
     P.A[lane] = T0;
@@ -285,6 +298,25 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     // The dense phase is software-pipelined by one batch: drain(n) first FINISHES the previous batch (its 4 taps were
     // loaded a whole batch interval ago: colour, Q32.32 accumulate), then STARTS the new one (queue pop, record fields, UV
     // Taylor step, cubemap address, tap loads issued) and returns without waiting for them.
+    // K6 -> K7 item stream (see PixArgs): pages from this block's sub-pool, one returning atomic per page, issued a page ahead
+    const bool streaming = a.item_pages != nullptr;
+    const uint32_t sub = (uint32_t)blockIdx.x & a.item_sub_mask;
+    uint32_t cur_page = TG_PAGE_UNSET, prev_page = TG_NOPAGE;      // wave-uniform
+    uint32_t pend_v = 0u;                      // lane 0: the pending allocation's result
+    int nitems = 0;
+    uint32_t cid = 0u;                         // lane = survivor of the current chunk: its Gaussian id
+    auto alloc_issue = [&]() { if (lane == 0) pend_v = atomicAdd(a.item_ctl + 16u * sub, 1u); };
+    auto alloc_take = [&](uint32_t prev) -> uint32_t {      // the pending allocation: its page (chained behind `prev`), or TG_NOPAGE
+        const uint32_t local = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_v);
+        if (local < a.item_sub_cap) {
+            const uint32_t page = sub * a.item_sub_cap + local;
+            if (lane == 0) a.item_link[page] = prev;
+            return page;
+        }
+        if (lane == 0) a.item_ctl[TEXGS_ITEM_CTL_FLAG] = 1u;     // the buffer is too small: the survivor-replay K7 runs instead
+        return TG_NOPAGE;
+    };
+    if (streaming && todo > 0) alloc_issue();
     int pn = 0;                                // lanes of the batch in flight (wave-uniform)
     int p_pl = 0;
     float p_w = 0.f, p_fx = 0.f, p_fy = 0.f, p_vd0 = 0.f, p_vd1 = 0.f, p_vd2 = 0.f;
@@ -316,10 +348,33 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         const int jj_ = KEY_J(e_.y);
         const float4 f_ = L.p.F[jj_];
         const float2 g2 = L.p.G[jj_];
+        // The queue carries T (what K7 needs), not w: alpha_raw is evaluated again here from the same planes with the same
+        // explicitly ordered operations as in the test loop -- bit-identical -- and w = min(0.99, alpha_raw) * T as there.
+        const float4 a4_ = L.p.A[jj_];
+        const float2 b2_ = *reinterpret_cast<const float2*>(&L.p.B[jj_]);
+        const float ipx_ = (float)(wave_px + KEY_OX(e_.y)), ipy_ = (float)(wave_py + KEY_OY(e_.y));
+        const float araw_ = gauss_alpha_raw(b2_.y, gauss_power(a4_.z, a4_.w, b2_.x, a4_.x - ipx_, a4_.y - ipy_));
+        const float T_ = __uint_as_float(e_.x);
+        const float w_ = fminf(TG_ALPHA_MAX, araw_) * T_;
+        if (streaming) {
+            if (cur_page == TG_PAGE_UNSET) { cur_page = alloc_take(TG_NOPAGE); alloc_issue(); }
+            const bool cross = ((nitems + n_) >> TG_PAGE_SHIFT) != (nitems >> TG_PAGE_SHIFT);
+            uint32_t nxt = TG_NOPAGE;
+            if (cross) { nxt = alloc_take(cur_page); alloc_issue(); }
+            const uint32_t v = (uint32_t)nitems + (uint32_t)lane;
+            const uint32_t page = ((v >> TG_PAGE_SHIFT) == ((uint32_t)nitems >> TG_PAGE_SHIFT)) ? cur_page : nxt;
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_ds_bpermute(jj_ << 2, (int)cid);
+            if (lane < n_ && page != TG_NOPAGE) {
+                uint32_t* __restrict__ pb = a.item_pages + (size_t)page * (3 * TG_PAGE) + (v & (TG_PAGE - 1));
+                pb[0] = e_.x; pb[TG_PAGE] = __float_as_uint(araw_); pb[2 * TG_PAGE] = (gid << 6) | (uint32_t)KEY_PL(e_.y);
+            }
+            if (cross) { prev_page = cur_page; cur_page = nxt; }
+            nitems += n_;
+        }
         if constexpr (TAPS) {
-            const float2 xy = *reinterpret_cast<const float2*>(&L.p.A[jj_]);
+            const float2 xy = make_float2(a4_.x, a4_.y);
             const float4 d_ = L.p.D[jj_], e4 = L.p.E[jj_];
-            const float dpx = (float)(wave_px + KEY_OX(e_.y)) - xy.x, dpy = (float)(wave_py + KEY_OY(e_.y)) - xy.y;
+            const float dpx = ipx_ - xy.x, dpy = ipy_ - xy.y;
             const float den = 1.0f + d_.x * dpx + d_.y * dpy;
             const float inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
             const float u0 = f_.x + (d_.z * dpx + d_.w * dpy) * inv;
@@ -358,7 +413,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
                 }
             }
         }
-        p_w = __uint_as_float(e_.x); p_pl = KEY_PL(e_.y); p_vd0 = f_.w; p_vd1 = g2.x; p_vd2 = g2.y;
+        p_w = w_; p_pl = KEY_PL(e_.y); p_vd0 = f_.w; p_vd1 = g2.x; p_vd2 = g2.y;
         pn = n_;
     };
 
@@ -403,6 +458,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         }
         qh = (qh + take) & (TG_RING - 1); nq -= take;
         float4 T0, T1;
+        cid = id;
         load_chunk(a, L.p, lane, lane < take, id, pos, T0, T1);     // (every item of the previous chunk was started by a drain: its fields are in registers)
         reinterpret_cast<uint32_t*>(&L.list[0][0])[lane] = 0x40404040u;      // pad all four lists with TG_DUMMY
         __builtin_amdgcn_wave_barrier();
@@ -446,9 +502,9 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
                     if (ok) {
                         const float w = alpha * T;
                         Dp += w * Cc.x; N0 += w * Cc.y; N1 += w * Cc.z; N2 += w * Cc.w; Al += w;
+                        L.q[(qtail + mbcnt64(bal)) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(T), keybase | (uint32_t)j);      // T BEFORE this pair
                         T = Tn;
                         last = __float_as_uint(B.z) + 1u;
-                        L.q[(qtail + mbcnt64(bal)) & (FQ_CAP - 1)] = make_uint2(__float_as_uint(w), keybase | (uint32_t)j);
                     }
                     qtail += __popcll(bal);
                     if (qtail - qhead >= 64) {
@@ -519,6 +575,11 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         rv[lane] = b; rv[TG_RESV + lane] = off; rv[2 * TG_RESV + lane] = n;
     }
     if (a.surv_cnt != nullptr && lane == 0) a.surv_cnt[4 * tile + wave] = (uint32_t)nsurv;
+    if (streaming && lane == 0) {
+        // the page that holds the block's LAST item (a stream that ends exactly on a page boundary has already moved on)
+        const uint32_t tailp = (nitems > 0 && (nitems & (TG_PAGE - 1)) == 0) ? prev_page : cur_page;
+        reinterpret_cast<uint2*>(a.item_tail)[4 * tile + wave] = make_uint2(tailp, (uint32_t)nitems);
+    }
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
         const double q = 1.0 / 4294967296.0;
@@ -549,7 +610,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
 //            (DPP only, wave_ops.h), and the 16 lanes add the Gaussian's 128-byte accumulator row as two 64-byte runs.
 #define BWD_MAX_IT 16
 struct TexBinArgs {
-    float*    rec;         // [5][cap] plane-major: fx | cell x, fy | cell y, dL/dtexel-colour r, g, b; bin b owns [base[b], base[b+1])
+    uint32_t* rec;         // [cap][4] 16-byte records (rec_pack); bin b owns [base[b], base[b+1])
     uint32_t* cursor;      // [nbins] next free record of each list's OVERFLOW part, absolute (k_bin_offsets sets it to the end of the reserved part)
     const uint32_t* base;  // [nbins + 1] exclusive scan of K6's per-bin counts
     const uint32_t* order; // [nbins] the reduce kernel's launch order: bins by falling list length (k_bin_offsets)
@@ -570,6 +631,37 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
     unsafeAtomicAdd(p01, w01 * x0); unsafeAtomicAdd(p01 + 1, w01 * x1); unsafeAtomicAdd(p01 + 2, w01 * x2);
     unsafeAtomicAdd(p10, w10 * x0); unsafeAtomicAdd(p10 + 1, w10 * x1); unsafeAtomicAdd(p10 + 2, w10 * x2);
     unsafeAtomicAdd(p11, w11 * x0); unsafeAtomicAdd(p11 + 1, w11 * x1); unsafeAtomicAdd(p11 + 2, w11 * x2);
+}
+
+// Texture-gradient RECORD, 16 bytes, one per bilinear footprint, written with ONE 16-byte store (round 6; until then 20 bytes as
+// five planes: five scattered 4-byte stores per footprint, whose partially written lines the L2 had to give up before they were
+// full -- ablation: K7 -90 us without the stores):
+//   w0 = low 16 bits of fx18 | low 16 bits of fy18 << 16          fx18 = round(fx * 2^18), 18 bits (as the 20-byte record kept)
+//   w1 = r, its 5 low mantissa bits replaced by the footprint's cell x inside its 32x32-texel bin (r rounded to 18 mantissa bits)
+//   w2 = g, likewise with cell y          w3 = b, its 4 low mantissa bits = the two high bits of fx18 and of fy18
+// inf / NaN survive the rounding (an inf / NaN upstream gradient still reaches exactly the texels it touches).
+struct __attribute__((aligned(16))) Rec4 { uint32_t a, b, c, d; };
+__device__ __forceinline__ uint32_t rec_word0(float fx, float fy, uint32_t& hi) {
+    const uint32_t qx = min((uint32_t)(fx * 262144.0f + 0.5f), 262143u), qy = min((uint32_t)(fy * 262144.0f + 0.5f), 262143u);
+    hi = (qx >> 16) | ((qy >> 16) << 2);
+    return (qx & 0xFFFFu) | (qy << 16);
+}
+__device__ __forceinline__ Rec4 rec_pack(uint32_t w0, uint32_t hi, int cx, int cy, float x0, float x1, float x2) {
+    Rec4 r;
+    r.a = w0;
+    r.b = ((__float_as_uint(x0) + 16u) & ~31u) | (uint32_t)(cx & 31);
+    r.c = ((__float_as_uint(x1) + 16u) & ~31u) | (uint32_t)(cy & 31);
+    r.d = ((__float_as_uint(x2) + 8u) & ~15u) | hi;
+    return r;
+}
+struct RecVal { int cx, cy; float fx, fy, x0, x1, x2; };
+__device__ __forceinline__ RecVal rec_unpack(const Rec4 w) {
+    RecVal r;
+    r.fx = (float)((w.a & 0xFFFFu) | ((w.d & 3u) << 16)) * (1.0f / 262144.0f);
+    r.fy = (float)((w.a >> 16) | (((w.d >> 2) & 3u) << 16)) * (1.0f / 262144.0f);
+    r.cx = (int)(w.b & 31u); r.cy = (int)(w.c & 31u);
+    r.x0 = __uint_as_float(w.b & ~31u); r.x1 = __uint_as_float(w.c & ~31u); r.x2 = __uint_as_float(w.d & ~15u);
+    return r;
 }
 
 // live accumulator-row slots (common.h M_*) of the two C2 flavours: all 28 moments / without the UV chain (M_DEN, M_DN, M_PHI)
@@ -613,6 +705,19 @@ namespace k7_lds {
 #undef K7_PREFETCH
 #undef K7_WAVES_PER_SIMD
 }  // namespace k7_lds
+// K7 over K6's item stream (texgs.h v15): the flavours with the per-Gaussian stages.  Same registers-per-wave target as k7_occ.
+#ifdef K7S_TRACE
+#ifndef K7_TRACE_BLOCKS
+#define K7_TRACE_BLOCKS 32768
+#endif
+__device__ unsigned long long k7s_trace[8 * K7_TRACE_BLOCKS];
+#endif
+#ifndef K7S_WAVES_PER_SIMD
+#define K7S_WAVES_PER_SIMD 4
+#endif
+namespace k7_stream {
+#include "render_bwd_stream.h"
+}  // namespace k7_stream
 
 // ------------------------------------------------------------------------------------------------ texture-gradient lists
 // Exclusive scan of K6's per-bin footprint counts -> list offsets (one workgroup; nbins = 6144 at R = 1024).  count[b] = the
@@ -710,17 +815,15 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     if (filled == 0u) return;                                  // uniform per workgroup
     const uint32_t room = (b0 < tb.cap) ? min(b1, tb.cap) - b0 : 0u;      // records of this list that exist (K7's own test)
     const uint32_t cnt = min(filled, room);
-    const float* __restrict__ rp = tb.rec + b0;
-    const size_t cap = tb.cap;
+    const Rec4* __restrict__ rp = reinterpret_cast<const Rec4*>(tb.rec) + b0;
     const int face = b / (tb.nb * tb.nb), by = (b / tb.nb) % tb.nb, bx = b % tb.nb;
     const uint32_t bbits = tb.stats[1];
     if (bbits >= 0x7F800000u) {                                // inf / NaN upstream gradient: float atomics, record by record
         for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)TB_THREADS) {
-            const uint32_t fxw = __float_as_uint(rp[i]), fyw = __float_as_uint(rp[cap + i]);
-            const float fx = __uint_as_float(fxw & ~31u), fy = __uint_as_float(fyw & ~31u);
-            const uint32_t y = (uint32_t)by * 32u + (fyw & 31u), x = (uint32_t)bx * 32u + (fxw & 31u);
+            const RecVal r = rec_unpack(rp[i]);
+            const uint32_t y = (uint32_t)by * 32u + (uint32_t)r.cy, x = (uint32_t)bx * 32u + (uint32_t)r.cx;
             const uint32_t o00 = ((((uint32_t)face * (uint32_t)R + y) * (uint32_t)R + x) * 3u) << 2;
-            scatter_direct(dtex, o00, 12u, 12u * (uint32_t)R, fx, fy, rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
+            scatter_direct(dtex, o00, 12u, 12u * (uint32_t)R, r.fx, r.fy, r.x0, r.x1, r.x2);
         }
         return;
     }
@@ -733,12 +836,13 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     // round(v) in its mantissa; subtracting the bias as integers leaves the two's-complement value
     const double magic = 6755399441055744.0;
     const long long magic_bits = __double_as_longlong(magic);
-    auto add_record = [&](uint32_t fxw, uint32_t fyw, float x0, float x1, float x2) {
-        const float fx = __uint_as_float(fxw & ~31u), fy = __uint_as_float(fyw & ~31u);
-        const double dx0 = (double)x0 * up, dx1 = (double)x1 * up, dx2 = (double)x2 * up;
+    auto add_record = [&](const Rec4 w) {
+        const RecVal r = rec_unpack(w);
+        const float fx = r.fx, fy = r.fy;
+        const double dx0 = (double)r.x0 * up, dx1 = (double)r.x1 * up, dx2 = (double)r.x2 * up;
         const double w00 = (double)((1.f - fx) * (1.f - fy)), w01 = (double)(fx * (1.f - fy));
         const double w10 = (double)((1.f - fx) * fy), w11 = (double)(fx * fy);
-        ull* t = reinterpret_cast<ull*>(s_tile) + ((fyw & 31u) * TB_ROW + (fxw & 31u)) * 3;
+        ull* t = reinterpret_cast<ull*>(s_tile) + (r.cy * TB_ROW + r.cx) * 3;
 #define TB_ADD(P, V) atomicAdd((P), (ull)(__double_as_longlong((V) + magic) - magic_bits))
         TB_ADD(t + 0, w00 * dx0); TB_ADD(t + 1, w00 * dx1); TB_ADD(t + 2, w00 * dx2);
         TB_ADD(t + 3, w01 * dx0); TB_ADD(t + 4, w01 * dx1); TB_ADD(t + 5, w01 * dx2);
@@ -750,19 +854,15 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         const uint32_t s1 = min(cnt, s0 + TB_SEG);
         for (int k = tid; k < TB_EDGE * TB_ROW * 3; k += TB_THREADS) s_tile[k] = 0ll;
         __syncthreads();
-        // two records per thread in flight (10 loads).  (More in flight, the next trip's loads issued ahead of the LDS atomics, lanes
-        // spread over distinct cells: no change.  Ablated: loads + arithmetic alone 75 us, + the LDS atomics 104, + the write-out 124.)
+        // two records per thread in flight.  (More in flight, the next trip's loads issued ahead of the LDS atomics, lanes spread over
+        // distinct cells: no change.)
         uint32_t i = s0 + (uint32_t)tid;
         for (; i + (uint32_t)TB_THREADS < s1; i += 2u * (uint32_t)TB_THREADS) {
-            const uint32_t i2 = i + (uint32_t)TB_THREADS;
-            const uint32_t fxa = __float_as_uint(rp[i]), fya = __float_as_uint(rp[cap + i]);
-            const float xa0 = rp[2 * cap + i], xa1 = rp[3 * cap + i], xa2 = rp[4 * cap + i];
-            const uint32_t fxb = __float_as_uint(rp[i2]), fyb = __float_as_uint(rp[cap + i2]);
-            const float xb0 = rp[2 * cap + i2], xb1 = rp[3 * cap + i2], xb2 = rp[4 * cap + i2];
-            add_record(fxa, fya, xa0, xa1, xa2);
-            add_record(fxb, fyb, xb0, xb1, xb2);
+            const Rec4 ra = rp[i], rb = rp[i + (uint32_t)TB_THREADS];
+            add_record(ra);
+            add_record(rb);
         }
-        if (i < s1) add_record(__float_as_uint(rp[i]), __float_as_uint(rp[cap + i]), rp[2 * cap + i], rp[3 * cap + i], rp[4 * cap + i]);
+        if (i < s1) add_record(rp[i]);
         __syncthreads();
         for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += TB_THREADS) {
             const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);
@@ -793,6 +893,15 @@ inline PixArgs make_pix(const CamConst& c, const TexGSFrame* f, const TexGSInput
     a.surv_qm = hand ? img->surv_qmask : nullptr;
     a.surv_cnt = hand ? img->surv_count : nullptr;
     a.resv = img->tex_bin_resv;
+    const bool items = hand && img->item_pages != nullptr && img->item_link != nullptr && img->item_tail != nullptr &&
+                       img->item_ctl != nullptr && img->item_sub_pools != 0u;
+    a.item_pages = items ? img->item_pages : nullptr;
+    a.item_link = items ? img->item_link : nullptr;
+    a.item_tail = items ? img->item_tail : nullptr;
+    a.item_ctl = items ? img->item_ctl : nullptr;
+    a.item_sub_cap = items ? img->item_page_cap / img->item_sub_pools : 0u;
+    a.item_sub_mask = items ? img->item_sub_pools - 1u : 0u;
+    a.run_if = nullptr;
     return a;
 }
 
@@ -801,7 +910,7 @@ inline TexBinArgs make_bins(const CamConst& c, const TexGSImage* img, const TexG
     tb.nb = (c.R + 31) >> 5;
     const bool on = (gr->want & TEXGS_WANT_TEXTURE) && img->tex_bin_count != nullptr && img->tex_bin_resv != nullptr && gr->tex_bins != nullptr &&
                     gr->tex_bin_cursor != nullptr && gr->tex_bin_base != nullptr && gr->tex_rec_cap > 0;
-    tb.rec = on ? gr->tex_bins : nullptr;
+    tb.rec = on ? reinterpret_cast<uint32_t*>(gr->tex_bins) : nullptr;
     tb.cursor = on ? gr->tex_bin_cursor : nullptr;
     tb.base = on ? gr->tex_bin_base : nullptr;
     tb.order = on ? gr->tex_bin_base + tex_bin_count(c.R) + 1 : nullptr;
@@ -833,7 +942,7 @@ void launch_render_fwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
 // operator.
 void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs* in, const TexGSGeom* g,
                        const TexGSBinning* b, const TexGSImage* img, TexGSGrads* gr, hipStream_t s) {
-    const PixArgs a = make_pix(c, f, in, g, b, img);
+    const PixArgs a0 = make_pix(c, f, in, g, b, img);
     const TexBinArgs tb = make_bins(c, img, gr);
     const bool taps = in->texture != nullptr;
     const bool tex = taps && (gr->want & TEXGS_WANT_TEXTURE) && gr->dL_dtexture != nullptr;
@@ -842,7 +951,19 @@ void launch_render_bwd(const CamConst& c, const TexGSFrame* f, const TexGSInputs
     if (tex && tb.rec)      // list offsets + cursors from the counts the forward left (one small workgroup)
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(1024), 0, s, (int)tex_bin_count(c.R), (const uint32_t*)img->tex_bin_count,
                            gr->tex_bin_base, gr->tex_bin_cursor, gr->tex_bin_base + tex_bin_count(c.R) + 1, tb.stats);
-    const dim3 grid(blend_grid(a.num_tiles)), blk(64);
+    const dim3 grid(blend_grid(a0.num_tiles)), blk(64);
+    PixArgs a = a0;
+    if (geo && a.item_pages != nullptr) {
+        // the forward left its item stream: the dense kernel over it; the survivor-replay kernel behind it runs only if K6 ran out of
+        // pages (one word decides for the whole view; ~10^4 empty workgroups otherwise)
+#define K7S_LAUNCH(TEX, UVG, TAPS) hipLaunchKernelGGL((k7_stream::k_render_bwd_stream<TEX, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
+        gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
+        if (!taps)      K7S_LAUNCH(false, false, false);
+        else if (tex)   K7S_LAUNCH(true, true, true);
+        else            K7S_LAUNCH(false, true, true);
+#undef K7S_LAUNCH
+        a.run_if = a.item_ctl + TEXGS_ITEM_CTL_FLAG;
+    }
 #define K7_LAUNCH(NS, TEX, GEO, UVG, TAPS) hipLaunchKernelGGL((NS::k_render_bwd<TEX, GEO, UVG, TAPS>), grid, blk, 0, s, a, tb, img->final_T, \
         img->n_contrib, gr->dL_dcolor, gr->dL_ddepth, gr->dL_dnorm, gr->dL_dalpha, gr->acc, gr->dL_dtexture)
     if (!taps)            K7_LAUNCH(k7_occ, false, true, false, false);
@@ -862,6 +983,11 @@ void launch_texgrad_reduce(const CamConst& c, const TexGSImage* img, TexGSGrads*
     hipLaunchKernelGGL(k_texgrad_reduce, dim3((unsigned)tex_bin_count(c.R)), dim3(TB_THREADS), 0, s, c.R, tb, gr->dL_dtexture);
 }
 
+#ifdef K7S_TRACE
+extern "C" __attribute__((visibility("default"))) int texgs_debug_k7s_trace(void* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k7s_trace), sizeof(unsigned long long) * 8 * K7_TRACE_BLOCKS);
+}
+#endif
 #ifdef K7_TRACE
 extern "C" __attribute__((visibility("default"))) int texgs_debug_k7_trace(void* host_dst) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k7_trace), sizeof(unsigned long long) * 4 * K7_TRACE_BLOCKS);

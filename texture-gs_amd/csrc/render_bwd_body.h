@@ -15,6 +15,9 @@ struct __attribute__((aligned(16))) BwdLds {      // bytes: configuration lds (B
     uint32_t task[64];                  //  256
     uint8_t list[4][64];                //  256
     uint32_t tpos[TG_RESV], tend[TG_RESV];   // 512: the block's reservations: next free record (absolute), end of the range (the bins: p.B[].w)
+#ifdef K7_LDS_PAD
+    char pad_[K7_LDS_PAD];                     // experiment builds: fewer waves per CU
+#endif
 };                                      // 18080 B -> 9 waves per CU / 9296 B -> 16 waves per CU (17 by LDS; the registers are held to 4 per SIMD)
 
 // What a caller wants decides what is compiled in (TexGSGrads.want, texgs.h):
@@ -35,6 +38,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     const int lane = (int)threadIdx.x;
     int tile, wave;
     if (!wave_block(a, tile, wave)) return;
+    if (a.run_if != nullptr && *a.run_if == 0u) return;      // launched as the item-stream kernel's fallback, and K6 did not run out of pages
 #ifdef K7_TRACE
     const unsigned long long trace_t0 = wall_clock64();   // experiment builds only (scripts/k7_trace.py): when each block ran, and where
 #endif
@@ -122,7 +126,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         uint32_t slot;                                    // the item's record slot (absolute); TG_SLOT_NONE: none (not binned / no room);
                                                           // TG_SLOT_OVF | leader << 8 | rank: an overflow footprint (see front_b)
         uint32_t ovf0, ovf1;                              // group leaders of overflow footprints: first slot of the group, end of the list
-        uint32_t fxw, fyw;                                // fx / fy with the cell coordinate in the 5 low mantissa bits
+        uint32_t fxw, fyw;                                // the record's first word; cell + high fraction bits (rec_word0 / rec_pack)
         uint32_t o00, dox, doy;                           // tap byte offsets: o01 = o00 + dox, o10 = o00 + doy, o11 = o00 + dox + doy
         float w, vd0, vd1, vd2, nu0, nu1, nu2, inv;
         float fx, fy, ka, kb, kc, kd;                     // d(col,row)/d(ua,ub,m) factors of the cube projection
@@ -145,7 +149,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         static_assert(BQ_CAP <= 64, "one round per segment");
         uint32_t key = 0u;
         if (lane < n_items) key = __float_as_uint(L.abuf[lane].w);
-        const float4* __restrict__ sp = a.rec_shade + 5 * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(KEY_J(key) << 2, (int)cid);
+        const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(KEY_J(key) << 2, (int)cid);
         if constexpr (TAPS) { pre.sd = sp[0]; pre.se = sp[1]; }
         pre.sf = sp[2];
         pre.s3 = sp[3];
@@ -175,7 +179,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         R.c5 = make_float4(pre.s3.z, pre.s3.w, pre.s4.x, pre.s4.y);
 #else
         // the shading record of the item's Gaussian from global memory (an L2 hit; lanes of one task read the same 80 bytes)
-        const float4* __restrict__ sp = a.rec_shade + 5 * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(R.jj << 2, (int)cid);
+        const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(R.jj << 2, (int)cid);
         if constexpr (TAPS) { R.sd = sp[0]; R.se = sp[1]; }
         R.sf = sp[2];
         const float4 s3 = sp[3];
@@ -222,8 +226,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             if constexpr (TEX) {
                 R.o00 = ct.o00; R.dox = ct.dox; R.doy = ct.doy;
                 // (rounded to 18 mantissa bits, not truncated: no bias; fx in [0, 1) may round up to exactly 1)
-                R.fxw = ((__float_as_uint(ct.fx) + 16u) & ~31u) | (uint32_t)(ct.x0 & 31);
-                R.fyw = ((__float_as_uint(ct.fy) + 16u) & ~31u) | (uint32_t)(ct.y0 & 31);
+                {   // the record's first word; fyw = cell x | cell y << 5 | the high bits of fx18 / fy18 << 10 (rec_pack)
+                    uint32_t hi;
+                    R.fxw = rec_word0(ct.fx, ct.fy, hi);
+                    R.fyw = (uint32_t)(ct.x0 & 31) | ((uint32_t)(ct.y0 & 31) << 5) | (hi << 10);
+                }
                 // slot in the texture bin's record list: from the block's reservation of that bin (K6 counted exactly these
                 // footprints), one returning LDS atomic per lane.  A footprint whose table entry belongs to another bin (2 %) goes
                 // behind the reserved part of the list: lanes grouped by bin, one returning GLOBAL atomic per group on the bin's
@@ -314,9 +321,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 if (ovf) { const uint32_t pos = p0 + (slot & 63u); slot = (pos < p1) ? pos : TG_SLOT_NONE; }
             }
             if (slot < tb.cap) {
-                float* __restrict__ rp = tb.rec + slot;
-                rp[0] = __uint_as_float(R.fxw); rp[tb.cap] = __uint_as_float(R.fyw);
-                rp[2 * (size_t)tb.cap] = x0; rp[3 * (size_t)tb.cap] = x1; rp[4 * (size_t)tb.cap] = x2;
+                reinterpret_cast<Rec4*>(tb.rec)[slot] = rec_pack(R.fxw, R.fyw >> 10, (int)(R.fyw & 31u), (int)((R.fyw >> 5) & 31u), x0, x1, x2);
             } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
                 scatter_direct(dtex, R.o00, R.dox, R.doy, R.fx, R.fy, x0, x1, x2);
             }
@@ -559,10 +564,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         // arithmetic); should they ever not, the reduce must not sum whatever an earlier call left in the unused slots.
         __builtin_amdgcn_wave_barrier();
         const uint32_t q1 = min(L.tend[lane], tb.cap);
-        for (uint32_t q = L.tpos[lane]; q < q1; ++q) {
-            float* __restrict__ rp = tb.rec + q;
-            rp[0] = 0.f; rp[tb.cap] = 0.f; rp[2 * (size_t)tb.cap] = 0.f; rp[3 * (size_t)tb.cap] = 0.f; rp[4 * (size_t)tb.cap] = 0.f;
-        }
+        for (uint32_t q = L.tpos[lane]; q < q1; ++q) { Rec4 z; z.a = 0u; z.b = 0u; z.c = 0u; z.d = 0u; reinterpret_cast<Rec4*>(tb.rec)[q] = z; }
     }
 #ifdef K7_TRACE
     if (lane == 0 && blockIdx.x < K7_TRACE_BLOCKS) {

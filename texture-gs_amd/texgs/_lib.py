@@ -6,13 +6,17 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXGS_LIB") or os.path.join(os.path.dirname(_HERE), "libtexgs.so")   # TEXGS_LIB: experiment builds only
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 ERR_CAPACITY = 1000
 TILE = 16
 REC_TEST_FLOATS = 8
 REC_SHADE_FLOATS = 20
-TEXBIN_RECORD_FLOATS = 5
+TEXBIN_RECORD_FLOATS = 4        # 16-byte texture-gradient records (TexGSGrads.tex_bins)
 RESV_WORDS = 192         # per 8x8 pixel block: 64 reservation entries x {bin, offset, count} (TexGSImage.tex_bin_resv)
+ITEM_PAGE = 256          # items per page of the K6 -> K7 item stream (TexGSImage.item_pages: three planes of ITEM_PAGE words per page)
+ITEM_MAX_POOLS = 64
+ITEM_CTL_FLAG = 16 * ITEM_MAX_POOLS
+ITEM_CTL_WORDS = 16 * ITEM_MAX_POOLS + 16
 ACC_FLOATS = 32
 WANT_TEXTURE, WANT_GAUSSIANS, WANT_ALL = 1, 2, 3
 
@@ -44,7 +48,9 @@ class Binning(C.Structure):
 class Image(C.Structure):
     _fields_ = [("out_color", _fp), ("out_depth", _fp), ("out_norm", _fp), ("out_alpha", _fp),
                 ("final_T", _fp), ("n_contrib", _fp), ("tex_bin_count", _fp),
-                ("survivors", _fp), ("surv_qmask", _fp), ("surv_count", _fp), ("tex_bin_resv", _fp)]
+                ("survivors", _fp), ("surv_qmask", _fp), ("surv_count", _fp), ("tex_bin_resv", _fp),
+                ("item_pages", _fp), ("item_link", _fp), ("item_tail", _fp), ("item_ctl", _fp),
+                ("item_page_cap", C.c_uint32), ("item_sub_pools", C.c_uint32)]
 
 
 class Grads(C.Structure):

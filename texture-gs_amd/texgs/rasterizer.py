@@ -69,6 +69,52 @@ GEOM_CACHE = _os.environ.get("TEXGS_GEOM_CACHE", "1") != "0"
 # produces the hand-off itself (one more K6) and switches the forwards back.
 LAZY_HANDOFF = _os.environ.get("TEXGS_LAZY_HANDOFF", "1") != "0"
 _CAPACITY_HINT = {}
+# K6 -> K7 item stream (texgs.h v15), OPT-IN (TEXGS_ITEMS=1): K6 leaves one 12-byte item per contributing (pixel, Gaussian) pair and
+# K7 walks those instead of re-testing the survivor lists.  Built, parity-tested and measured in round 6: K7 executes 21 % fewer
+# VALU instructions (176 M vs 222 M wave-instructions at C3) and takes the same time (the blend kernels wait on memory-side traffic,
+# not on issue), while K6 pays 45 us for writing 0.22 GB of items -- 935 vs 981 views/s, so the survivor replay stays the default
+# (DESIGN.md section 5.1.34).  The page buffer is sized from what earlier views of the same size needed (the sub-pool cursors of a
+# forward are copied to pinned memory asynchronously and looked at by a later call -- never waited for); a buffer that is too small
+# costs speed, not correctness (the survivor-replay kernel runs instead).
+USE_ITEMS = _os.environ.get("TEXGS_ITEMS", "0") != "0"
+ITEM_PAGES_FIXED = int(_os.environ.get("TEXGS_ITEM_PAGES", "0"))     # fixed page count (tests: force the fallback); 0 = adaptive
+_ITEM_HINT = {}             # (device index, N, H, W) -> pages (1.25 x the most a view needed)
+_ITEM_STAT = {}             # (device index, stream) -> _ItemStat
+
+
+class _ItemStat:
+    __slots__ = ("host", "event", "key", "pools")
+
+    def __init__(self):
+        self.host = torch.zeros(_lib.ITEM_CTL_WORDS, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.key = None
+        self.pools = 1
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            self.event = None
+            wanted = int(self.host[0:16 * self.pools:16].max()) * self.pools
+            _ITEM_HINT[self.key] = max(_ITEM_HINT.get(self.key, 0), int(wanted * 1.25) + 8 * self.pools)
+
+    def watch(self, ctl, key, pools, device):
+        if self.event is None:
+            self.host.copy_(ctl, non_blocking=True)
+            self.key, self.pools = key, pools
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(device))
+
+
+def _item_layout(hint_key, cap, tiles):
+    """(pages, sub-pools) of a forward's item buffer: >= 64 blocks per sub-pool (their demands average out), <= 64 sub-pools (one
+    hot atomic word serialises at ~13 ns per page)."""
+    blocks = 4 * tiles
+    pools = 1
+    while pools < _lib.ITEM_MAX_POOLS and pools * 2 * 64 <= blocks:
+        pools *= 2
+    pages = ITEM_PAGES_FIXED or _ITEM_HINT.get(hint_key) or (20 * cap) // _lib.ITEM_PAGE + 2 * blocks
+    pages = max(int(pages), 2 * pools)
+    return (pages + pools - 1) // pools * pools, pools
 _GEOM = {}                  # (device index, stream) -> _GeomEntry of the last forward that built lists there
 # the hand-off predictor: autograd forwards are numbered; per device, the highest number whose backward ran and the numbers of
 # those dropped without one.  (Order-independent: a state that the garbage collector frees late cannot reset the streak.)
@@ -93,7 +139,7 @@ def reset_handoff_predictor():
 
 
 class _GeomEntry:
-    __slots__ = ("ints", "cam_key", "fingerprint", "D", "bin", "arenas", "handoff", "counts", "cap")
+    __slots__ = ("ints", "cam_key", "fingerprint", "D", "bin", "arenas", "handoff", "counts", "cap", "items")
 
 
 def geometry_cache_stats():
@@ -119,7 +165,7 @@ class _StreamScratch:
 
 def release_scratch(device=None, stream=None):
     """Free the backward scratch and the shared-geometry entry cached for (device, stream); None = every device / stream."""
-    for cache in (_SCRATCH, _GEOM):
+    for cache in (_SCRATCH, _GEOM, _ITEM_STAT):
         for key in list(cache):
             if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == int(stream)):
                 del cache[key]
@@ -197,7 +243,7 @@ class _State:
     """Everything one forward leaves behind for its backward (per call: no global scratch, two forwards may
     be alive before a backward, models/texture_gaussian3d.py:318,378,410)."""
     __slots__ = ("frame", "inputs", "geom", "bin", "img", "tensors", "N", "K", "R", "H", "W", "D", "cap", "tiles",
-                 "want_counts", "lazy", "backward_ran", "shared_geometry", "serial", "__weakref__")
+                 "want_counts", "want_items", "lazy", "backward_ran", "shared_geometry", "serial", "__weakref__")
 
     def __del__(self):          # the forwards' hand-off predictor (LAZY_HANDOFF): was this autograd forward ever differentiated?
         try:
@@ -225,7 +271,7 @@ def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
 
 
 def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None,
-                for_backward=True, cov3D_precomp=None, count_bins=None, lazy=False):
+                for_backward=True, cov3D_precomp=None, count_bins=None, lazy=False, want_items=None):
     """Run K1..K6.  Returns (outputs, state).  No autograd here.
 
     `lazy` (the autograd path sets it): the hand-off may be left to the backward (see LAZY_HANDOFF).
@@ -233,6 +279,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     `for_backward`: K6 leaves the per-block survivor lists its backward replays.  `count_bins` (default: for_backward and
     there is a texture): K6 also counts the texture-gradient footprints per texture bin (the exact list sizes of
     backward_raw's binned texture gradient); a caller that will not ask for dL/dtexture saves that work.
+    `want_items` (default: for_backward): K6 also leaves its ITEM STREAM (one {T, alpha_raw, Gaussian | pixel} per contributing
+    pair) for the backward's per-Gaussian stages; a caller that will only ask for dL/dtexture saves that work.
     `texture=None`: the untextured surface (diff_gauss, render/render.py:75-84): uvs / gradient_uvs may be None too.
     `cov3D_precomp` f32[N,6] (untextured surface only): used instead of scales / rotations."""
     lib = _lib.load()
@@ -296,6 +344,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, cov3D_precomp]
     handoff = bool(for_backward) and not (lazy and LAZY_HANDOFF and unused_streak(device.index) >= 2)
     want_counts = bool(count_bins and USE_TEX_BINS)
+    want_items = bool((for_backward if want_items is None else want_items) and for_backward and USE_ITEMS)
 
     with torch.cuda.device(device):
         frame = _make_frame(st, N, K, R, device, keep)
@@ -364,6 +413,13 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             if handoff:        # K6 -> K7 hand-off of the per-block survivor lists: four blocks per tile, each at most the tile's list length
                 ar.add("survivors", (4 * c1, 2), i32)
                 ar.add("surv_qmask", (4 * c1,), torch.int16)
+            item_pages = item_pools = 0
+            if handoff and want_items:      # ... and of K6's item stream
+                item_pages, item_pools = _item_layout(hint_key, c1, tiles)
+                ar.add("item_ctl", (_lib.ITEM_CTL_WORDS,), i32)
+                ar.add("item_tail", (4 * tiles, 2), i32)
+                ar.add("item_link", (item_pages,), i32)
+                ar.add("item_pages", (item_pages, 3, _lib.ITEM_PAGE), i32)
             ar.commit()
             la = lists_ar if lists_ar is not None else ar
             b = _lib.Binning(0, ar.ptr("keys_unsorted"), ar.ptr("keys_sorted"), ar.ptr("point_list"), la.ptr("ranges"),
@@ -371,8 +427,17 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             img.tex_bin_count, img.surv_count = la.ptr("tex_bin_count"), la.ptr("surv_count")
             img.tex_bin_resv = la.ptr("tex_bin_resv")
             img.survivors, img.surv_qmask = ar.ptr("survivors"), ar.ptr("surv_qmask")
+            img.item_pages, img.item_link = ar.ptr("item_pages"), ar.ptr("item_link")
+            img.item_tail, img.item_ctl = ar.ptr("item_tail"), ar.ptr("item_ctl")
+            img.item_page_cap, img.item_sub_pools = item_pages, item_pools
             return b, ar
         hint_key = (device.index, N, H, W)
+        istat = None
+        if handoff and want_items:
+            istat = _ITEM_STAT.get(gkey)
+            if istat is None:
+                istat = _ITEM_STAT[gkey] = _ItemStat()
+            istat.poll()
         cap = _CAPACITY_HINT.get(hint_key, max(4 * N, 1024))
         binning = bin_ar = None
         if not candidate:
@@ -393,6 +458,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             if for_backward and entry.handoff and (entry.counts or not want_counts):
                 img.survivors, img.surv_qmask, img.surv_count = entry.handoff
                 img.tex_bin_count, img.tex_bin_resv = entry.counts if want_counts else (None, None)
+                if want_items and entry.items:      # T and alpha_raw of every pair are functions of the shared geometry too
+                    (img.item_pages, img.item_link, img.item_tail, img.item_ctl, img.item_page_cap, img.item_sub_pools) = entry.items
             cap = entry.cap
         else:
             _GEOM_STATS["misses"] += 1
@@ -407,6 +474,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
             _lib.check(lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
                                                          C.byref(img), stream), "texgs_bin_sort_render_forward")
             _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
+            if istat is not None and img.item_ctl and not ITEM_PAGES_FIXED:
+                istat.watch(bin_ar.view("item_ctl"), hint_key, int(img.item_sub_pools), device)
             if GEOM_CACHE:
                 e = _GeomEntry()
                 e.ints, e.cam_key, e.fingerprint, e.D, e.cap = gints, cam_key, fp, D, cap
@@ -415,11 +484,14 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
                 e.arenas = (fix, bin_ar)
                 e.handoff = (img.survivors, img.surv_qmask, img.surv_count) if handoff else None
                 e.counts = (img.tex_bin_count, img.tex_bin_resv) if (handoff and img.tex_bin_count) else None
+                e.items = (img.item_pages, img.item_link, img.item_tail, img.item_ctl, int(img.item_page_cap),
+                           int(img.item_sub_pools)) if (handoff and img.item_pages) else None
                 _GEOM[gkey] = e
     s = _State()
     s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
     s.N, s.K, s.R, s.H, s.W, s.D, s.cap, s.tiles = N, K, R, H, W, D, cap, tiles
     s.want_counts, s.lazy, s.backward_ran, s.shared_geometry = want_counts, bool(lazy and for_backward), False, shared is not None
+    s.want_items = want_items
     with _PRED_LOCK:
         _SERIAL[0] += 1
         s.serial = _SERIAL[0]
@@ -451,6 +523,13 @@ def _late_handoff(s: _State):
     if s.want_counts:
         ar.add("tex_bin_count", (2 * int(lib.texgs_tex_bin_count(s.R)),), i32)
         ar.add("tex_bin_resv", (4 * s.tiles, _lib.RESV_WORDS), i32)
+    item_pages = item_pools = 0
+    if s.want_items:
+        item_pages, item_pools = _item_layout((device.index, s.N, s.H, s.W), max(s.cap, 1), s.tiles)
+        ar.add("item_ctl", (_lib.ITEM_CTL_WORDS,), i32)
+        ar.add("item_tail", (4 * s.tiles, 2), i32)
+        ar.add("item_link", (item_pages,), i32)
+        ar.add("item_pages", (item_pages, 3, _lib.ITEM_PAGE), i32)
     ar.add("scratch_out", (8, s.H, s.W), f32)
     ar.add("final_T", (s.H, s.W), f32)
     ar.add("n_contrib", (s.H, s.W), i32)
@@ -458,13 +537,16 @@ def _late_handoff(s: _State):
     so = ar.ptr("scratch_out")
     hw = 4 * s.H * s.W
     img = _lib.Image(so, so + 3 * hw, so + 4 * hw, so + 7 * hw, ar.ptr("final_T"), ar.ptr("n_contrib"), ar.ptr("tex_bin_count"),
-                     ar.ptr("survivors"), ar.ptr("surv_qmask"), ar.ptr("surv_count"), ar.ptr("tex_bin_resv"))
+                     ar.ptr("survivors"), ar.ptr("surv_qmask"), ar.ptr("surv_count"), ar.ptr("tex_bin_resv"),
+                     ar.ptr("item_pages"), ar.ptr("item_link"), ar.ptr("item_tail"), ar.ptr("item_ctl"), item_pages, item_pools)
     _lib.check(lib.texgs_render_forward(C.byref(s.frame), C.byref(s.inputs), C.byref(s.geom), C.byref(s.bin), C.byref(img), stream),
                "texgs_render_forward (late hand-off)")
     s.img.survivors, s.img.surv_qmask, s.img.surv_count = img.survivors, img.surv_qmask, img.surv_count
     s.img.tex_bin_count, s.img.tex_bin_resv = img.tex_bin_count, img.tex_bin_resv
+    s.img.item_pages, s.img.item_link, s.img.item_tail, s.img.item_ctl = img.item_pages, img.item_link, img.item_tail, img.item_ctl
+    s.img.item_page_cap, s.img.item_sub_pools = item_pages, item_pools
     s.tensors._arenas = tuple(s.tensors._arenas) + (ar,)
-    for n in ("survivors", "surv_qmask", "surv_count", "tex_bin_count", "tex_bin_resv"):
+    for n in ("survivors", "surv_qmask", "surv_count", "tex_bin_count", "tex_bin_resv", "item_pages", "item_link", "item_tail", "item_ctl"):
         s.tensors.pop(n, None)
     if not s.want_counts:
         s.tensors["tex_bin_count"] = None
@@ -668,7 +750,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         # (autograd does not record inside Function.forward: the inputs go in as they are, no detach() copies of the tensor objects)
         outs, state = forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset,
                                   for_backward=bool(want), cov3D_precomp=cov3D_precomp,
-                                  count_bins=bool(want & _lib.WANT_TEXTURE), lazy=True)
+                                  count_bins=bool(want & _lib.WANT_TEXTURE), lazy=True,
+                                  want_items=bool(want & _lib.WANT_GAUSSIANS))
         color, depth, norm, alpha, radii = outs
         ctx.state = state
         # the backward re-reads the inputs through raw pointers (K8 recomputes geometry, K7 re-fetches texels): remember
