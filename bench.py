@@ -271,6 +271,26 @@ def main():
     t1 = time.perf_counter()
     kern_timed = _lib.profile_read()
     comm = bucket.comm_timings() if (with_bwd and dist is not None) else []
+    # the same step loop again for >= 2 s (the mandated K steps are a fraction of a second -- too short for an outside
+    # sampler to see the GPU busy); reported beside `value`, never instead of it
+    _lib.profile_enable(False)
+    long_steps, tl0 = 0, time.perf_counter()
+    while True:
+        step()
+        long_steps += 1
+        if long_steps % 8 == 0:
+            torch.cuda.synchronize(dev)
+            if time.perf_counter() - tl0 >= 2.0 or long_steps >= 4096:
+                break
+    fence()
+    long_elapsed = time.perf_counter() - tl0
+    if dist is not None:
+        tl = torch.tensor([long_elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        long_elapsed = float(tl.item())
+    value_long = long_steps * args.views_per_step * world / long_elapsed
+    if with_bwd and dist is not None:
+        bucket.comm_timings()           # (drop the long loop's entries: `comm` above is the timed region's)
     # the per-kernel table: two extra steps with every kernel group bracketed, views one after the other on one stream, so
     # that each duration is the kernel's own (in the pipelined region a kernel shares the GPU with other views' kernels)
     kern = dict(kern_timed)
@@ -507,6 +527,9 @@ def main():
                        if args.workload == "c3" else f"{mode} views/sec ({args.workload})") if not untextured
                       else f"{mode} views/sec ({args.workload}, untextured diff_gauss surface)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value_long": round(value_long, 3),
+            "value_long_note": f"the same step loop run again for {long_elapsed:.2f} s ({long_steps} steps) after the timed region",
+            "build_id": _lib.BUILD_ID,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={N} Gaussians, cubemap 6x{R}x{R}x3 f32, {W}x{H}, {mode}, sh_degree 3",

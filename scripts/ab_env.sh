@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): scripts/ab_env.sh "VAR=1 VAR2=x" "VAR=0" ...   -- C3 bench per environment setting: serial kernel table and
-# pipelined views/s (e.g. "TEXGS_ITEMS=1" "TEXGS_ITEMS=0", or "TEXGS_LIB=$PWD/texture-gs_amd/libtexgs_x.so TEXGS_ABI_ANY=1")
+# pipelined views/s (e.g. "TEXGS_ITEMS=1" "TEXGS_ITEMS=0", or "TEXGS_LIB=$PWD/texture-gs_amd/libtexgs_x.so")
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for V in "$@"; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment (GPU box): WHEN and WHERE each 8x8 block of one K7 launch ran.  Needs the trace build
-(scripts/exp_build.sh trace "-DK7_TRACE" texture-gs_amd/csrc/render.hip) selected with TEXGS_LIB + TEXGS_ABI_ANY=1.
+(scripts/exp_build.sh trace "-DK7_TRACE" texture-gs_amd/csrc/render.hip) selected with TEXGS_LIB.
 Question: K7 keeps 2.96 of its 4 wave slots per SIMD busy on average (SQ_WAVE_CYCLES / duration) -- is the idle quarter a tail
 (a few long blocks finishing alone), an imbalance between the 8 XCDs, or spread over the launch?  Prints one JSON object."""
 import ctypes as C

@@ -284,11 +284,13 @@ def grad_mass_attributed(label, got, exp, hard_flag, dev, kappa=1.5, row_rtol=1e
     widened = (kappa * dv > base) & touched
     ok_rows = ~hard
     rel = float((g[ok_rows] - e[ok_rows]).norm() / e[ok_rows].norm().clamp_min(1e-300))
+    plain_rows = ok_rows & ~widened            # rows whose tolerance is (less than twice) the plain one: their aggregate must be TIGHT
+    rel_plain = float((g[plain_rows] - e[plain_rows]).norm() / e[plain_rows].norm().clamp_min(1e-300))
     res = dict(rows=int(g.shape[0]), rows_with_gradient=int(touched.sum()), hard_flagged_rows=int((hard & touched).sum()),
                hard_flagged_frac=float((hard & touched).sum()) / max(int(touched.sum()), 1),
                rows_with_tolerance_more_than_doubled_frac=float(widened.sum()) / max(int(touched.sum()), 1),
                rows_over_plain_tolerance=int((err > base).sum()), rows_over_widened_tolerance=int(bad.sum()),
-               outlier_rows_UNEXPLAINED=int(unexplained.sum()), rel_l2_all_but_hard=rel,
+               outlier_rows_UNEXPLAINED=int(unexplained.sum()), rel_l2_all_but_hard=rel, rel_l2_plain_tolerance_rows=rel_plain,
                median_widening_over_plain=float((kappa * dv[touched] / base[touched]).median()) if bool(touched.any()) else 0.0)
     if int(unexplained.sum()):
         idx = torch.nonzero(unexplained).reshape(-1)[:8]
@@ -297,6 +299,10 @@ def grad_mass_attributed(label, got, exp, hard_flag, dev, kappa=1.5, row_rtol=1e
     report(label, **res)
     assert res["outlier_rows_UNEXPLAINED"] == 0, res
     assert res["hard_flagged_frac"] < hard_frac_max, res
+    # aggregates (the old single bound, 5 x clean_rel over every row but the hard-flagged ones, was far looser than the row
+    # checks beside it): rows at the plain tolerance must agree to clean_rel / 4 in relative L2; the figure over all rows but the hard
+    # ones includes rows whose OWN bound (cell-edge mass) is large and is held to clean_rel x 5 as a backstop
+    assert rel_plain < clean_rel / 4, res
     assert rel < clean_rel * 5, res
     return res
 

@@ -446,6 +446,56 @@ def test_block_reservations_tile_the_record_lists(lib_built):
     RZ.release_scratch()
 
 
+def test_reservation_mismatch_between_k6_and_k7_stays_exact(lib_built):
+    """the reduce sums the whole RESERVED range of every list, so the texture gradient is exact only while K7 fills exactly
+    the slots K6 reserved.  Three safety nets cover a disagreement -- the end-of-block zero-fill of reservations K7 did not use up, the
+    `pos < tend` test that sends surplus footprints to dL_dtexture directly, and the overflow path for bins the block's table does
+    not hold -- and none of them runs while K6 and K7 agree.  Force a disagreement: between forward and backward the UV anchor (phi)
+    of a third of the Gaussians is changed in K1's shading records, so K7's footprints land in other cells / bins than K6 counted;
+    the record buffer still holds the non-zero records of an earlier backward.  The binned gradient must equal the one through
+    atomics for the same (changed) records."""
+    from texgs import rasterizer as RZ
+    from texgs.rasterizer import GaussianRasterizationSettings, forward_raw, backward_raw
+    dev = torch.device("cuda:0")
+    t = lambda x: x.to(dev)
+    scene = synth.make_scene(4000, 128, seed=44, scale_mean=0.03)
+    cam = synth.fibonacci_cameras(4, 256, 192)[2]
+    st = Hh.settings_for(cam, 3, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings)
+    args = [t(scene.means3D), t(scene.shs), t(scene.opacities), t(scene.scales), t(scene.rotations), t(scene.uvs),
+            t(scene.gradient_uvs), t(scene.texture)]
+    g = torch.Generator().manual_seed(3)
+    dimg = (torch.randn(3, 192, 256, generator=g) * 1e-4).to(dev)
+    pick = (torch.rand(4000, generator=g) < 0.33).to(dev)
+    saved = RZ.GEOM_CACHE
+    try:
+        RZ.GEOM_CACHE = False
+        RZ.release_scratch()
+        _, s0 = forward_raw(st, *args)
+        backward_raw(s0, dimg * 50.0, None, None, None)            # leaves non-zero records of ANOTHER magnitude in the stream's buffer
+        res = {}
+        for mode in ("binned", "atomics"):
+            _, s = forward_raw(st, *args)
+            rs = s.tensors["rec_shade"]
+            phi = rs[:, 8:11].clone()
+            rs[:, 8:11] = torch.where(pick[:, None], phi.roll(1, dims=1) * torch.tensor([1.0, -1.0, 1.0], device=dev), phi)
+            if mode == "atomics":
+                s.tensors["tex_bin_count"] = None
+                s.img.tex_bin_count = None
+            res[mode] = backward_raw(s, dimg, None, None, None)
+            torch.cuda.synchronize()
+        r = Hh.rel_err(res["binned"][7], res["atomics"][7])
+        Hh.report("texture_bins/forced_k6_k7_mismatch", rel_l2=r, changed_gaussians=int(pick.sum()))
+        assert float(res["atomics"][7].abs().sum()) > 0
+        assert r < 1e-5, r
+        # and the unperturbed gradient differs from it (the perturbation really moved footprints)
+        _, s = forward_raw(st, *args)
+        plain = backward_raw(s, dimg, None, None, None)
+        assert Hh.rel_err(plain[7], res["atomics"][7]) > 1e-2
+    finally:
+        RZ.GEOM_CACHE = saved
+        RZ.release_scratch()
+
+
 def test_texture_gradient_scale_is_per_call(lib_built):
     """The reduce kernel's fixed-point scale is the max |dL/dpixel| of THE CALL (the backward resets a scratch word, K7 raises
     it): a backward with 1e6 x larger upstream gradients on the same stream / scratch must not coarsen the next one."""

@@ -30,7 +30,21 @@ UNITS = {
     "abi.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wave_ops.h"), os.path.join(CSRC, "render_bwd_body.h"),
-           os.path.join(ROOT, "include", "texgs.h")]
+           os.path.join(CSRC, "render_bwd_stream.h"), os.path.join(ROOT, "include", "texgs.h")]
+
+
+def build_id():
+    """Identity of what libtexgs.so is built FROM: sha256 over csrc/*, include/texgs.h and the compile flags (16 hex digits).
+    build() bakes it into the library (texgs_build_id()); texgs/_lib.py recomputes it from the tree and refuses a library that
+    was built from other sources -- the prebuilt .so is what travels to the GPU box, mtimes do not."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(ROOT, "include", "texgs.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(repr((COMMON[:4], sorted(UNITS.items()), os.environ.get("TEXGS_EXTRA_FLAGS", ""))).encode())
+    return h.hexdigest()[:16]
 
 
 def _newer(src_list, target):
@@ -43,11 +57,16 @@ def _newer(src_list, target):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     objs = []
+    bid = build_id()
+    idfile = os.path.join(OBJ, "build_id.txt")
+    stale_id = not os.path.exists(idfile) or open(idfile).read().strip() != bid
     for src, flags in UNITS.items():
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _newer([sp] + HEADERS + [os.path.abspath(__file__)], op):
+        if src == "abi.hip":        # carries the build id: rebuilt whenever any source or flag changed
+            flags = flags + ['-DTEXGS_BUILD_ID="%s"' % bid]
+        if force or _newer([sp] + HEADERS + [os.path.abspath(__file__)], op) or (src == "abi.hip" and stale_id):
             cmd = [HIPCC] + COMMON + flags + os.environ.get("TEXGS_EXTRA_FLAGS", "").split() + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -57,6 +76,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(idfile, "w") as f:
+        f.write(bid + "\n")
     return LIB
 
 

@@ -84,6 +84,11 @@ extern "C" {
 
 int texgs_abi_version(void) { return TEXGS_ABI_VERSION; }
 
+#ifndef TEXGS_BUILD_ID
+#define TEXGS_BUILD_ID "unknown"
+#endif
+const char* texgs_build_id(void) { return TEXGS_BUILD_ID; }
+
 const char* texgs_last_error(void) { return g_err; }
 
 size_t texgs_scan_temp_bytes(int32_t num_gaussians) { return scan_temp_bytes(num_gaussians); }

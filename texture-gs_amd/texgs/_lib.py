@@ -71,7 +71,7 @@ class UVNetGradStruct(C.Structure):
     _fields_ = [(n, _fp) for n in ("dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4", "dW5", "db5")]
 
 
-EXPORTS = ["texgs_abi_version", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
+EXPORTS = ["texgs_abi_version", "texgs_build_id", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
            "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_read_num_rendered2", "texgs_depth_sort_scan", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
            "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
@@ -157,10 +157,35 @@ def load():
                  "texgs_backward_preprocess", "texgs_rgb_alpha_loss", "texgs_mark_visible"):
         getattr(lib, name).restype = C.c_int
     v = lib.texgs_abi_version()
-    if v != ABI_VERSION and not (os.environ.get("TEXGS_LIB") and os.environ.get("TEXGS_ABI_ANY") == "1"):     # (A/B runs of an older experiment build)
+    if v != ABI_VERSION:
+        # (no bypass in the shipped loader -- the struct layouts differ between versions; experiment scripts that A/B an
+        #  older build must run it under that build's own host layer)
         raise RuntimeError(f"libtexgs.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    lib.texgs_build_id.restype = C.c_char_p
+    global BUILD_ID
+    BUILD_ID = lib.texgs_build_id().decode()
+    if not os.environ.get("TEXGS_LIB"):          # the product library must be built from THIS tree's sources (experiment builds: any)
+        want = tree_build_id()
+        if want is not None and BUILD_ID != want:
+            raise RuntimeError(f"libtexgs.so was built from other sources (build id {BUILD_ID}, this tree is {want}); "
+                               "rebuild it with `python texture-gs_amd/build.py`")
     _lib = lib
     return lib
+
+
+BUILD_ID = None
+
+
+def tree_build_id():
+    """The build id of the sources in this tree (texture-gs_amd/build.py build_id()); None if the build script is not there."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(_HERE), "build.py")
+    if not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location("texgs_build_script", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_id()
 
 
 def check(rc, what):

@@ -186,7 +186,7 @@ def scratch_bytes():
 
 
 class _TexBins:
-    """Scratch of the binned texture gradient for one (device, R, stream): the record buffer (TexGSGrads.tex_bins, 20 bytes per
+    """Scratch of the binned texture gradient for one (device, R, stream): the record buffer (TexGSGrads.tex_bins, 16 bytes per
     bilinear footprint of a view, exactly-sized contiguous lists), the per-bin fill cursors + two status words (all-zero
     between calls: the reduce kernel clears what it read) and the list offsets of the call in flight.  The buffer grows to
     what the views need: every call leaves the number of records its lists wanted in the word after the cursors; it is copied
@@ -219,17 +219,16 @@ class _TexBins:
         if TEX_REC_CAP:
             self._resize(TEX_REC_CAP)
             return
-        if self.rec is None and counts is not None:
-            # first backward on this (device, stream): size the buffer from K6's exact per-bin counts (one device->host read, once;
-            # afterwards the asynchronous statistic below adapts it) instead of a guess of 20 records per instance
-            self._resize(int(counts.sum().item() * 1.25) + 4096)
+        # (No device->host read here -- ADVICE r5: sizing the first buffer from K6's exact counts was a blocking sync inside backward, which
+        #  stalled a pipelined multi-stream backward and cannot run under stream capture.  The first buffer is a guess from D; the
+        #  asynchronous statistic below corrects it; a buffer that is too small only sends the excess through atomics.)
         if self.event is not None and self.event.query():
             self.event = None
             wanted = int(self.host_stat[0])
             if wanted > self.cap:
                 self._resize(int(wanted * 1.25) + 4096)
         if self.rec is None:
-            self._resize(20 * max(int(D), 1024))        # first guess: ~17 contributing pixels per (tile, Gaussian) instance at C3
+            self._resize(24 * max(int(D), 1024))        # first guess: ~17 contributing pixels per (tile, Gaussian) instance at C3
 
     def after_call(self):
         self.calls += 1

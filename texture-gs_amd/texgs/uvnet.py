@@ -154,12 +154,15 @@ class UVNet(nn.Module):
         return F.normalize(self.mlp(x), dim=-1)
 
     # ---- fused kernel ---------------------------------------------------------------------------------------------------
-    def _kernel_args(self, dev, emb):
+    def _kernel_args(self, dev, emb, params=None):
+        """`params` = [W1, b1, ..., W5, b5] to use INSTEAD of the module's current weights (the autograd node hands its saved
+        tensors: a weight rebound through `.data` between forward and backward must not change what the backward differentiates)."""
         f = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
         both = self.xyz_offset is not None and self.xyz_scale is not None
-        lins = self._linears()
-        ws = [f(lins[0].weight), f(lins[0].bias), f(lins[1].weight), f(lins[1].bias), f(emb),
-              f(lins[2].weight), f(lins[2].bias), f(lins[3].weight), f(lins[3].bias), f(lins[4].weight), f(lins[4].bias),
+        if params is None:
+            params = [t for lin in self._linears() for t in (lin.weight, lin.bias)]
+        W1, b1, W2, b2, W3, b3, W4, b4, W5, b5 = params
+        ws = [f(W1), f(b1), f(W2), f(b2), f(emb), f(W3), f(b3), f(W4), f(b4), f(W5), f(b5),
               f(self.xyz_offset) if both else None, f(self.xyz_scale) if both else None]
         if ws[0].shape != (HIDDEN, 3) or ws[2].shape != (HIDDEN, HIDDEN) or ws[9].shape != (3, HIDDEN) or ws[4].numel() != HIDDEN:
             raise ValueError("the fused kernel supports the shipped UVNet shape only (3-128-128 | 128-128-128-3, emb 128)")
@@ -198,7 +201,7 @@ class UVNet(nn.Module):
         return uvs, juv
 
     @torch.no_grad()
-    def backward_fused(self, xyz, emb, g):
+    def backward_fused(self, xyz, emb, g, params=None):
         """[dW1, db1, dW2, db2, dW3, db3, dW4, db4, dW5, db5] of sum(uvs * g) from the fused HIP backward (csrc/uvnet.hip
         k_uv_backward: one persistent kernel, activations recomputed per tile in LDS, weight gradients in registers; d emb = db2).
         What autograd does through models/modules/uv_net.py:19-36 under loss.backward() in the reference.  No CPU fallback
@@ -212,7 +215,7 @@ class UVNet(nn.Module):
         N = x.shape[0]
         if gg.shape != (N, 3):
             raise ValueError(f"g must be [N, 3], got {tuple(gg.shape)}")
-        ws = self._kernel_args(dev, emb)
+        ws = self._kernel_args(dev, emb, params)
         p = lambda t: None if t is None else t.data_ptr()
         netp = _lib.UVNetStruct(*[p(t) for t in ws], HIDDEN)
         shapes = [(HIDDEN, 3), (HIDDEN,), (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN, HIDDEN), (HIDDEN,),
@@ -297,7 +300,7 @@ class _FusedUV(torch.autograd.Function):
             d_xyz = (g[:, :, None] * juv.reshape(-1, 3, 3)).sum(dim=1)      # (elementwise: as an einsum this is 300 000 batched 1x3 . 3x3 products)
         d_emb, d_params = None, [None] * 10
         if any(need[2:]):
-            grads = net.backward_fused(xyz, emb, g)
+            grads = net.backward_fused(xyz, emb, g, params=params)        # (the forward's weights: ADVICE r5)
             for k in range(10):
                 d_params[k] = grads[k] if need[3 + k] else None
             if need[2]:
