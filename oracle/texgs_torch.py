@@ -289,12 +289,14 @@ def cubemap_fetch(uv, texture):
     return tex, margin
 
 
-def render(pre, binning, texture, st, dtype, chunk=128, tile_subset=None):
-    """K6 of SURVEY Appendix A.4, tile by tile, instance chunks processed front to back."""
+def render(pre, binning, texture, st, dtype, chunk=128, tile_subset=None, extra_attrs=None):
+    """K6 of SURVEY Appendix A.4, tile by tile, instance chunks processed front to back.  `extra_attrs` [N,C] (the lineage
+    operator's 10th kwarg, render/uv_tex_render.py:66): blended like depth / normals, extra_c = sum_i w_i e_ic -- channels 8.. of out."""
     H, W = int(st.image_height), int(st.image_width)
     gx, gy = pre['grid']
     bg = st.bg.to(dtype)
-    out = torch.zeros(8, H, W, dtype=dtype)            # r,g,b,depth,nx,ny,nz,alpha
+    CE = 0 if extra_attrs is None else int(extra_attrs.shape[1])
+    out = torch.zeros(8 + CE, H, W, dtype=dtype)       # r,g,b,depth,nx,ny,nz,alpha (, extra...)
     final_T = torch.ones(H, W, dtype=dtype)
     n_contrib = torch.zeros(H, W, dtype=torch.int64)
     ambiguity = torch.full((H, W), float('inf'), dtype=dtype)
@@ -311,7 +313,7 @@ def render(pre, binning, texture, st, dtype, chunk=128, tile_subset=None):
         npx = py.numel()
         pix = torch.stack([px, py], 1).to(dtype)
         T = torch.ones(npx, dtype=dtype)
-        acc = torch.zeros(npx, 8, dtype=dtype)
+        acc = torch.zeros(npx, 8 + CE, dtype=dtype)
         done = ~inside
         ncon = torch.zeros(npx, dtype=torch.int64)
         amb = torch.full((npx,), float('inf'), dtype=dtype)
@@ -359,6 +361,8 @@ def render(pre, binning, texture, st, dtype, chunk=128, tile_subset=None):
                               pre['depth'][ids][None, :, None].expand(npx, K, 1),
                               pre['normal'][ids][None, :, :].expand(npx, K, 3),
                               torch.ones(npx, K, 1, dtype=dtype)], dim=-1)
+            if CE:
+                feat = torch.cat([feat, extra_attrs[ids][None, :, :].expand(npx, K, CE)], dim=-1)
             acc = acc + (w[..., None] * feat).sum(1)
             # bookkeeping: last contributor position (1-based within the tile list)
             with torch.no_grad():
@@ -398,16 +402,16 @@ def _scatter_image(out, PY, PX, VAL):
 
 
 def rasterize(means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture,
-              st: Settings, dtype=torch.float64, debug=False, color_offset=None, cov3D_precomp=None):
+              st: Settings, dtype=torch.float64, debug=False, color_offset=None, cov3D_precomp=None, extra_attrs=None):
     """Whole operator (reference call: render/uv_tex_render.py:56-66).  Returns
-    (image[3,H,W], depth[1,H,W], norm[3,H,W], alpha[1,H,W], radii[N] int32, extra=None) and, with
+    (image[3,H,W], depth[1,H,W], norm[3,H,W], alpha[1,H,W], radii[N] int32, extra[C,H,W] or None) and, with
     debug=True, a dict of intermediates for the integer-stage parity tests."""
     cv = lambda t: None if t is None else t.to(dtype)
     pre = preprocess(cv(means3D), cv(means2D), cv(shs), cv(opacities), cv(scales), cv(rotations),
                      cv(uvs), cv(gradient_uvs), st, dtype, color_offset=cv(color_offset), cov3D_precomp=cv(cov3D_precomp))
     binning = bin_and_sort(pre)
-    out, final_T, n_contrib, amb = render(pre, binning, cv(texture), st, dtype)
-    res = (out[0:3], out[3:4], out[4:7], out[7:8], pre['radius'].to(torch.int32), None)
+    out, final_T, n_contrib, amb = render(pre, binning, cv(texture), st, dtype, extra_attrs=cv(extra_attrs))
+    res = (out[0:3], out[3:4], out[4:7], out[7:8], pre['radius'].to(torch.int32), None if extra_attrs is None else out[8:])
     if debug:
         return res, dict(pre=pre, binning=binning, final_T=final_T, n_contrib=n_contrib, ambiguity=amb)
     return res

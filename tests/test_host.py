@@ -63,10 +63,17 @@ def test_argument_validation():
     with pytest.raises(ValueError):
         r(means3D=torch.zeros(3, 3), means2D=None, opacities=torch.ones(3, 1), uvs=torch.ones(3, 3),
           gradient_uvs=torch.zeros(3, 9), texture=torch.zeros(6, 4, 4, 3))            # scales / rotations missing
-    with pytest.raises(NotImplementedError):
-        r(means3D=torch.zeros(3, 3), means2D=None, opacities=torch.ones(3, 1), scales=torch.ones(3, 3),
-          rotations=torch.ones(3, 4), uvs=torch.ones(3, 3), gradient_uvs=torch.zeros(3, 9),
-          texture=torch.zeros(6, 4, 4, 3), extra_attrs=torch.zeros(3, 2))
+    # extra_attrs (always None in the reference, render/uv_tex_render.py:66) is blended by extra passes of the untextured operator:
+    # its validation runs before any device work
+    from texgs.rasterizer import blend_extra_attrs, EXTRA_ATTRS_MAX
+    st = _settings(m)
+    with pytest.raises(ValueError):
+        blend_extra_attrs(st, torch.zeros(3, 3), None, torch.ones(3, 1), torch.ones(3, 3), torch.ones(3, 4), torch.zeros(4, 2))
+    with pytest.raises(ValueError):
+        blend_extra_attrs(st, torch.zeros(3, 3), None, torch.ones(3, 1), torch.ones(3, 3), torch.ones(3, 4),
+                          torch.zeros(3, EXTRA_ATTRS_MAX + 1))
+    assert blend_extra_attrs(st, torch.zeros(3, 3), None, torch.ones(3, 1), torch.ones(3, 3), torch.ones(3, 4),
+                             torch.zeros(3, 0)).shape[0] == 0
 
 
 def test_shard_views_partition():

@@ -237,6 +237,66 @@ def test_untextured_diff_gauss_surface(lib_built):
             assert ok, (mode, n, msg)
 
 
+def test_extra_attrs_blending_both_surfaces(lib_built):
+    """`extra_attrs` [N, C] -> sixth return value extra[C, H, W] = sum_i w_i e_ic (the lineage operator's 10th kwarg,
+    render/uv_tex_render.py:66,76 / render/render.py:84; the reference always passes None): forward and every gradient -- including
+    dL/dextra_attrs and the geometry gradients that flow through the blending weights -- against autograd of the fp64 oracle, on the
+    textured surface (C = 5, negative values) and on `diff_gauss` (C = 1); and the identity extra(ones) == alpha, which compares the
+    colour path (dense phase, fixed-point accumulators) with the test loop's own alpha sum."""
+    import diff_gauss as dg
+    from oracle import texgs_torch as O
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    scene, cam, deg, bg = _scene(CASES[3])
+    dev = torch.device("cuda:0")
+    N = scene.means3D.shape[0]
+    g = torch.Generator().manual_seed(28)
+    H, W = cam.image_height, cam.image_width
+    target, nhat = synth.make_targets(H, W, seed=4)
+    d = torch.float64
+    for surface, C_ in (("textured", 5), ("diff_gauss", 1)):
+        ea = (torch.randn(N, C_, generator=g) * 2.0 + 0.5)
+        gex = torch.randn(C_, H, W, generator=g) / (H * W)
+        names = ["means3D", "opacities", "scales", "rotations"] + (["shs", "uvs", "texture"] if surface == "textured" else [])
+        leaves = {n: getattr(scene, n).clone().to(dev).requires_grad_(True) for n in names}
+        eg = ea.clone().to(dev).requires_grad_(True)
+        ol = {n: getattr(scene, n).clone().to(d).requires_grad_(True) for n in names}
+        oe = ea.clone().to(d).requires_grad_(True)
+        if surface == "textured":
+            st_gpu = Hh.settings_for(cam, deg, bg, device=dev, cls=GaussianRasterizationSettings)
+            out = GaussianRasterizer(st_gpu)(means3D=leaves["means3D"], means2D=None, shs=leaves["shs"], opacities=leaves["opacities"],
+                                             scales=leaves["scales"], rotations=leaves["rotations"], uvs=leaves["uvs"],
+                                             gradient_uvs=scene.gradient_uvs.to(dev), texture=leaves["texture"], extra_attrs=eg)
+            ref = O.rasterize(ol["means3D"], None, ol["shs"], ol["opacities"], ol["scales"], ol["rotations"], ol["uvs"],
+                              scene.gradient_uvs.to(d), ol["texture"], Hh.settings_for(cam, deg, bg), extra_attrs=oe)
+        else:
+            col = torch.rand(N, 3, generator=g)
+            st_gpu = Hh.settings_for(cam, 0, bg, device=dev, cls=dg.GaussianRasterizationSettings)
+            out = dg.GaussianRasterizer(st_gpu)(means3D=leaves["means3D"], means2D=None, opacities=leaves["opacities"],
+                                                colors_precomp=col.to(dev), scales=leaves["scales"], rotations=leaves["rotations"],
+                                                extra_attrs=eg)
+            uvs = torch.zeros(N, 3, dtype=d); uvs[:, 2] = 1.0
+            ref = O.rasterize(ol["means3D"], None, None, ol["opacities"], ol["scales"], ol["rotations"], uvs, torch.zeros(N, 9, dtype=d),
+                              torch.zeros(6, 1, 1, 3, dtype=d), Hh.settings_for(cam, 0, bg), color_offset=col.to(d) - 0.5, extra_attrs=oe)
+        assert out[5].shape == (C_, H, W)
+        err = float((out[5].detach().cpu().double() - ref[5]).abs().max())
+        Hh.report(f"extra_attrs/{surface}/forward", max_abs_err=err, channels=C_)
+        assert err < 4e-4 * float(ea.abs().max()), (surface, err)
+        (synth.synthetic_loss(out[0], out[3], out[2], target.to(dev), nhat.to(dev)) + (out[5] * gex.to(dev)).sum()).backward()
+        (synth.synthetic_loss(ref[0], ref[3], ref[2], target.to(d), nhat.to(d)) + (ref[5] * gex.to(d)).sum()).backward()
+        ok, msg = Hh.grad_close(eg.grad.cpu(), oe.grad)
+        assert ok, (surface, "extra_attrs", msg)
+        for n in names:
+            ok, msg = Hh.grad_close(leaves[n].grad.cpu(), ol[n].grad)
+            assert ok, (surface, n, msg)
+    # extra(ones) == alpha
+    st_gpu = Hh.settings_for(cam, deg, bg, device=dev, cls=GaussianRasterizationSettings)
+    dv = {n: getattr(scene, n).to(dev) for n in ("means3D", "shs", "opacities", "scales", "rotations", "uvs", "gradient_uvs", "texture")}
+    out = GaussianRasterizer(st_gpu)(means3D=dv["means3D"], means2D=None, shs=dv["shs"], opacities=dv["opacities"], scales=dv["scales"],
+                                     rotations=dv["rotations"], uvs=dv["uvs"], gradient_uvs=dv["gradient_uvs"], texture=dv["texture"],
+                                     extra_attrs=torch.ones(N, 1, device=dev))
+    assert float((out[5] - out[3]).abs().max()) < 1e-5
+
+
 def test_untextured_surface_with_cov3Ds_precomp(lib_built):
     """`cov3Ds_precomp` on the diff_gauss surface (render/render.py:52-53,75-84; layout utils/general.py:73-82): K1 reads the
     6-vector instead of scales / rotations, K8 returns dL/dcov3D (off-diagonals carry both symmetric halves) -- forward and all

@@ -12,7 +12,7 @@ is the eigenvector of the smallest eigenvalue and carries no gradient (a selecti
 import torch
 from torch import nn
 
-from texgs.rasterizer import GaussianRasterizationSettings, _RasterizeGaussians  # noqa: F401
+from texgs.rasterizer import GaussianRasterizationSettings, _RasterizeGaussians, blend_extra_attrs  # noqa: F401
 
 SH_C0 = 0.28209479177387814
 
@@ -33,9 +33,6 @@ class GaussianRasterizer(nn.Module):
                 raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         elif scales is None or rotations is None:
             raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        if extra_attrs is not None:
-            raise NotImplementedError("extra_attrs is always None in the reference (render/render.py:84); blending of extra "
-                                      "per-Gaussian attributes is not built")
         if means2D is None:
             means2D = torch.zeros_like(means3D)
         rest = None
@@ -48,4 +45,7 @@ class GaussianRasterizer(nn.Module):
         color, depth, norm, alpha, radii = _RasterizeGaussians.apply(
             means3D, means2D, rest, opacities, scales, rotations, None, None, None, st, offset.contiguous(), self.grad_sink,
             cov3Ds_precomp)
-        return color, depth, norm, alpha, radii, None
+        extra = None
+        if extra_attrs is not None:         # (always None in the reference, render/render.py:84; texgs.rasterizer.blend_extra_attrs)
+            extra = blend_extra_attrs(st, means3D, means2D, opacities, scales, rotations, extra_attrs, self.grad_sink, cov3Ds_precomp)
+        return color, depth, norm, alpha, radii, extra

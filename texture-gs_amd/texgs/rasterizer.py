@@ -794,6 +794,42 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, d_uvs, None, d_tex, None, d_coff, None, d_cov)[:ctx.nargs]
 
 
+EXTRA_ATTRS_MAX = 32
+
+
+def blend_extra_attrs(st, means3D, means2D, opacities, scales, rotations, extra_attrs, grad_sink=None, cov3D_precomp=None):
+    """extra[C,H,W] = sum_i w_i * extra_attrs[i, c]: the lineage operator's `extra_attrs` kwarg / sixth return value
+    (render/uv_tex_render.py:66,76, render/render.py:84 -- the reference itself always passes None).  Blended like depth and normals:
+    no background term, no clamp.  NOT a fused path: ceil(C / 3) more passes of the UNTEXTURED operator (K1 + K6 on the lists of the
+    main pass -- same camera, same Gaussians: the shared-geometry path -- and its own backward), three channels at a time as the
+    pass's colour.  The colour path clamps at zero, so the attributes go in shifted by m = min(extra_attrs) - 1 (> 0 everywhere: the
+    clamp never acts, its gradient mask never bites) and m * alpha is added back.  Differentiable w.r.t. extra_attrs and every
+    geometry input through plain autograd."""
+    N = means3D.shape[0]
+    if not isinstance(extra_attrs, torch.Tensor) or extra_attrs.dim() != 2 or extra_attrs.shape[0] != N:
+        raise ValueError(f"extra_attrs must be a [N, C] tensor with N = {N} rows")
+    C_ = int(extra_attrs.shape[1])
+    if C_ > EXTRA_ATTRS_MAX:
+        raise ValueError(f"extra_attrs has {C_} channels; at most {EXTRA_ATTRS_MAX} are blended")
+    H, W = int(st.image_height), int(st.image_width)
+    ea = extra_attrs.to(torch.float32)
+    if C_ == 0 or N == 0:
+        return torch.zeros(C_, H, W, dtype=torch.float32, device=means3D.device) + 0.0 * ea.sum()
+    m = ea.detach().amin() - 1.0                       # (a device scalar: no sync)
+    st0 = st._replace(bg=torch.zeros_like(st.bg), sh_degree=0)
+    if means2D is None:
+        means2D = torch.zeros_like(means3D)
+    outs = []
+    for c0 in range(0, C_, 3):
+        grp = ea[:, c0:c0 + 3]
+        if grp.shape[1] < 3:
+            grp = torch.cat([grp, (m + 1.0).expand(N, 3 - grp.shape[1])], dim=1)
+        color, _, _, alpha, _ = _RasterizeGaussians.apply(means3D, means2D, None, opacities, scales, rotations, None, None, None, st0,
+                                                          ((grp - m) - 0.5).contiguous(), grad_sink, cov3D_precomp)
+        outs.append(color + m * alpha)
+    return torch.cat(outs, dim=0)[:C_]
+
+
 class GaussianRasterizer(nn.Module):
     """Same call surface as the reference's rasterizer (render/uv_tex_render.py:40,56-66)."""
 
@@ -826,11 +862,11 @@ class GaussianRasterizer(nn.Module):
             raise ValueError("scales and rotations are required (the textured operator has no cov3D_precomp path)")
         if uvs is None or gradient_uvs is None or texture is None:
             raise ValueError("uvs, gradient_uvs and texture are required")
-        if extra_attrs is not None:
-            raise NotImplementedError("extra_attrs is always None in the reference (render/uv_tex_render.py:66); "
-                                      "blending of extra per-Gaussian attributes is not built yet")
         if means2D is None:
             means2D = torch.zeros_like(means3D)
         color, depth, norm, alpha, radii = _RasterizeGaussians.apply(
             means3D, means2D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, st, None, self.grad_sink)
-        return color, depth, norm, alpha, radii, None
+        extra = None
+        if extra_attrs is not None:         # (always None in the reference, render/uv_tex_render.py:66; see blend_extra_attrs)
+            extra = blend_extra_attrs(st, means3D, means2D, opacities, scales, rotations, extra_attrs, self.grad_sink)
+        return color, depth, norm, alpha, radii, extra
