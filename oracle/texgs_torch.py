@@ -213,9 +213,14 @@ def preprocess(means3D, means2D, shs, opacities, scales, rotations, uvs, gradien
     G = G * keep[:, None, None]
     g = g * keep[:, None]
 
+    # the values the integer decisions were rounded FROM (tests flag Gaussians whose float64 value sits within fp32 rounding of a
+    # ceil / trunc boundary: there an fp32 evaluation of the same formula may legitimately land on the other side)
+    radius_f = 3.0 * torch.sqrt(lam.detach())
+    rect_f = torch.stack([(xyd[:, 0] - rf) / TILE, (xyd[:, 1] - rf) / TILE,
+                          (xyd[:, 0] + rf + (TILE - 1)) / TILE, (xyd[:, 1] + rf + (TILE - 1)) / TILE], dim=1)
     return dict(valid=valid, xy=xy, depth=tz, conic=conic, radius=radius, tiles=tiles,
                 rect=(rminx, rminy, rmaxx, rmaxy), viewdep=viewdep, normal=n,
-                G=G, g=g, phi=uvs, opacity=opacities.reshape(-1), grid=(gx, gy))
+                G=G, g=g, phi=uvs, opacity=opacities.reshape(-1), grid=(gx, gy), radius_f=radius_f, rect_f=rect_f)
 
 
 def bin_and_sort(pre, depth_f32_bits=True):

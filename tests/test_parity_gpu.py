@@ -122,6 +122,64 @@ def test_integer_stages_vs_oracle(lib_built):
     assert agree > 0.995 - 0.02 * len(mism)
 
 
+@pytest.mark.parametrize("name,N,W,H,view", [("c3", 300_000, 800, 800, 0), ("c5", 1_000_000, 1600, 1200, 7)])
+def test_index_stages_at_full_resolution_vs_float64_subset(lib_built, name, N, W, H, view):
+    """the full-size bit-exact index checks compare K1 with oracle/texgs_ref.c, whose preprocess is statement-identical
+    to K1 by design -- a mistake shared by both that only bites at scale (a tile-rect clamp on a 50x50 / 100x75 grid) would pass.
+    Here a 20 000-Gaussian random subset of the C3 / C5 scene goes through K1-K5 at the FULL resolution and through the independent
+    float64 torch oracle (oracle/texgs_torch.py preprocess + bin_and_sort, written from the spec, not from K1): radii, tile rects,
+    tiles_touched must be IDENTICAL for every Gaussian whose float64 pre-rounding values are not within fp32 rounding of a ceil /
+    trunc boundary (those are counted: < 0.1 %), every tile must hold the same Gaussians, and the per-tile order must agree up to
+    swaps of depth-neighbours (fp32 depth vs float64 depth rounded to fp32)."""
+    from oracle import texgs_torch as O
+    scene = synth.make_scene(N, 32, seed=0)                    # (the texture plays no part in the index stages)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:20_000].sort().values
+    sub = scene._replace(**{f: getattr(scene, f)[idx] for f in
+                            ("means3D", "shs", "opacities", "scales", "rotations", "uvs", "gradient_uvs")})
+    cam = synth.fibonacci_cameras(64, W, H)[view]
+    bg = torch.zeros(3)
+    d = torch.float64
+    st = Hh.settings_for(cam, 3, bg)
+    pre = O.preprocess(sub.means3D.to(d), None, sub.shs.to(d), sub.opacities.to(d), sub.scales.to(d), sub.rotations.to(d),
+                       sub.uvs.to(d), sub.gradient_uvs.to(d), st, d)
+    binning = O.bin_and_sort(pre)
+    outs, s = Hh.hip_debug_state(sub, cam, 3, bg)
+    n = sub.means3D.shape[0]
+    # Gaussians at a rounding boundary (float64 values; margins = a few fp32 roundings of the chain that produces them)
+    rfv = pre["radius_f"]
+    frag = (rfv - rfv.round()).abs() < 1e-5 * rfv + 1e-6
+    rect_f = pre["rect_f"]
+    frag |= ((rect_f - rect_f.round()).abs() < 2e-5).any(dim=1)
+    frag |= (pre["depth"] - O.NEAR_Z).abs() < 1e-6
+    frag_frac = float(frag.double().mean())
+    assert frag_frac < 1e-3, frag_frac
+    keep = ~frag
+    radii = outs[4].cpu().to(torch.int64)
+    tt = s.tensors["tiles_touched"][:n].cpu().to(torch.int64)
+    rect = s.tensors["rect"][:n].cpu().to(torch.int64) & 0xFFFFFFFF
+    got_rect = torch.stack([rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, rect[:, 1] >> 16], 1)
+    exp_rect = torch.stack(list(pre["rect"]), 1)
+    vis = pre["valid"]
+    mism = (radii != pre["radius"]) | (tt != pre["tiles"]) | (vis & (got_rect != exp_rect).any(dim=1))
+    assert not bool((mism & keep).any()), torch.nonzero(mism & keep).reshape(-1)[:8].tolist()      # every difference sits on a boundary
+    assert int(vis.sum()) > 5_000                                         # the view really sees the subset
+    assert int(exp_rect[vis][:, 2].max()) > (W // 16) // 2 and int(exp_rect[vis][:, 3].max()) > (H // 16) // 2     # rects reach the far half of the grid
+    drop = set(torch.nonzero(frag | mism).reshape(-1).tolist())
+    D = s.D
+    nonempty = lambda dct: {t: l for t, l in dct.items() if l}           # (a tile that only held boundary Gaussians on one side)
+    got = nonempty(_tile_lists(s.tensors["point_list"][:D].cpu(), s.tensors["ranges"].cpu(), drop))
+    exp = nonempty(_tile_lists(binning["point_list"], binning["ranges"], drop))
+    assert got.keys() == exp.keys()
+    same_order = 0
+    for t in exp:
+        assert sorted(got[t]) == sorted(exp[t]), t                        # the same Gaussians in every tile of the full grid
+        same_order += got[t] == exp[t]
+    assert same_order >= 0.98 * len(exp), (same_order, len(exp))
+    Hh.report(f"hip_vs_torch64/{name}_subset/index_stages", gaussians=n, visible=int(vis.sum()), boundary_frac=frag_frac,
+              mismatches_all_on_boundary=int(mism.sum()), tiles_nonempty=len(exp), tiles_with_identical_order=same_order, D=D)
+
+
 def test_empty_and_culled_inputs(lib_built):
     """Edge cases: all Gaussians behind the camera (D = 0) and N = 0."""
     scene, cam, deg, bg = _scene(CASES[3])
