@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true",
                     help="skip the extra serial steps behind the per-kernel table (profiling runs: every launch is then a pipelined one)")
+    ap.add_argument("--wire", default=os.environ.get("TEXGS_WIRE", "f32"), choices=["f32", "bf16-sh"],
+                    help="N > 1: dtype of the gradient all-reduce on the wire.  bf16-sh = the view-dependent SH gradients (54 of the 150 MB "
+                         "of a C3 bucket) are summed as bf16 -- GradBucket.all_reduce_async(wire_dtype=...) --, everything else stays f32")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the reference-call-pattern / reference-iteration / retexture legs after the timed region (A/B runs)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
@@ -147,7 +150,7 @@ def main():
         import bench_iteration
         if rank == 0:
             res = bench_iteration.run(N, R, W, H, iters=max(args.steps, 4), warm=max(args.warmup, 2), dev_index=dev_index,
-                                      precision=os.environ.get("TEXGS_UV_PRECISION", "fp32"))
+                                      precision=os.environ.get("TEXGS_UV_PRECISION", "mixed"))
             print(json.dumps({"metric": f"reference training iteration (texture stage), ms per iteration ({args.workload})",
                               "value": res["uv_once_ms_per_iteration"], "unit": "ms/iteration", "higher_is_better": False, "n_gpus": 1,
                               "dtype": "f32", "data": "synthetic", **res}), flush=True)
@@ -166,11 +169,15 @@ def main():
         leaves["shs"] = torch.cat([torch.zeros(N, 1, 3), scene.shs], 1).to(dev).requires_grad_(with_bwd)
     juv = scene.gradient_uvs.to(dev)
     means2D = torch.zeros(N, 3, device=dev, requires_grad=with_bwd)
-    # the texture last: the flat gradient bucket is then two contiguous segments, [per-Gaussian | texture]
-    params = [leaves[n] for n in names if n != "texture"] + [means2D] + ([leaves["texture"]] if "texture" in leaves else [])
+    # the texture last, the SH coefficients before it: the flat gradient bucket is then three contiguous runs,
+    # [small per-Gaussian | shs | texture] -- all-reduced as [small + shs], [texture] (f32 wire) or [small], [shs as bf16], [texture]
+    small = [leaves[n] for n in names if n not in ("texture", "shs")] + [means2D]
+    params = small + [leaves["shs"]] + ([leaves["texture"]] if "texture" in leaves else [])
     bucket = GradBucket(params) if with_bwd else None
     seg_tex = bucket.segment_of([leaves["texture"]]) if (with_bwd and "texture" in leaves) else None
     seg_gauss = bucket.segment_of([p_ for p_ in params if p_ is not leaves.get("texture")]) if with_bwd else None
+    seg_small = bucket.segment_of(small) if with_bwd else None
+    seg_shs = bucket.segment_of([leaves["shs"]]) if with_bwd else None
 
     def settings(cam):
         return GaussianRasterizationSettings(
@@ -230,7 +237,12 @@ def main():
     pipe_serial = ViewPipeline(dev, depth=1)
     cursor = [0]
 
-    def step(p=pipe):
+    step_recs = []          # N > 1: (start, render done, all-reduce waited for) events of the timed steps, this rank
+
+    def step(p=pipe, rec=None):
+        if rec is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         if with_bwd:
             bucket.zero()
         batch = [my_views[(cursor[0] + i) % len(my_views)] for i in range(args.views_per_step)]
@@ -240,12 +252,21 @@ def main():
         # issued (it overlaps that view's K8 and the host's end-of-step work); the per-Gaussian half after the last K8
         p.run(batch, view_fwd, view_bwd if with_bwd else None, sink=bucket, order=args.order,
               texture_ready=(lambda evs: bucket.all_reduce_async(dist, seg_tex, after=evs, timing=True)) if two else None)
+        if rec is not None:
+            ev[1].record()
         if with_bwd and dist is not None:
-            if two:
+            if two and args.wire == "bf16-sh":
+                bucket.all_reduce_async(dist, seg_small, timing=True)
+                bucket.all_reduce_async(dist, seg_shs, timing=True, wire_dtype=torch.bfloat16)
+                bucket.wait()
+            elif two:
                 bucket.all_reduce_async(dist, seg_gauss, timing=True)
                 bucket.wait()
             else:
                 bucket.all_reduce(dist)
+        if rec is not None:
+            ev[2].record()
+            rec.append(ev)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -265,7 +286,7 @@ def main():
     t0 = time.perf_counter()
     step_ev[0].record()
     for k in range(args.steps):
-        step()
+        step(rec=step_recs if dist is not None else None)
         step_ev[k + 1].record()
     fence()
     t1 = time.perf_counter()
@@ -274,14 +295,16 @@ def main():
     # the same step loop again for >= 2 s (the mandated K steps are a fraction of a second -- too short for an outside
     # sampler to see the GPU busy); reported beside `value`, never instead of it
     _lib.profile_enable(False)
-    long_steps, tl0 = 0, time.perf_counter()
-    while True:
+    el_max = t1 - t0
+    if dist is not None:        # (every rank must run the SAME number of steps: they contain collectives)
+        te = torch.tensor([el_max], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        el_max = float(te.item())
+    long_steps = min(4096, max(args.steps, int(math.ceil(2.2 / max(el_max / args.steps, 1e-6)))))
+    fence()
+    tl0 = time.perf_counter()
+    for _ in range(long_steps):
         step()
-        long_steps += 1
-        if long_steps % 8 == 0:
-            torch.cuda.synchronize(dev)
-            if time.perf_counter() - tl0 >= 2.0 or long_steps >= 4096:
-                break
     fence()
     long_elapsed = time.perf_counter() - tl0
     if dist is not None:
@@ -311,6 +334,21 @@ def main():
         kern = _lib.profile_read()
     _lib.profile_enable(False)
     kern[DOMINANT] = kern_timed[DOMINANT]
+    # N > 1: what every rank did in the timed region, gathered to rank 0 (the first real multi-GPU run must be
+    # diagnosable from its one JSON line): its views and their instance counts, GPU time of the rendering part of a step, the part
+    # of the all-reduce the compute stream had to wait for, the collectives' own durations on the comm stream (call order)
+    rank_table = None
+    if dist is not None:
+        ncoll = (len(comm) // max(len(step_recs), 1)) if step_recs else 0
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "views": len(my_views),
+                "D_sum": int(sum(costs[v] for v in my_views)) if world > 1 else None,
+                "render_ms_per_step": round(sum(e[0].elapsed_time(e[1]) for e in step_recs) / max(len(step_recs), 1), 4),
+                "allreduce_wait_ms_per_step": round(sum(e[1].elapsed_time(e[2]) for e in step_recs) / max(len(step_recs), 1), 4),
+                "allreduce_ms_by_collective": [round(sum(m for _, m in comm[k::ncoll]) / max(len(comm[k::ncoll]), 1), 4) for k in range(ncoll)],
+                "allreduce_wire_bytes_by_collective": [int(comm[k][0]) for k in range(ncoll)]}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        rank_table = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "wire": args.wire, "ranks": gathered}
     step_ms = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
     elapsed = t1 - t0
@@ -539,14 +577,16 @@ def main():
                        "view_sharding": "LPT by per-view instance count D" if world > 1 else "all views on the one GPU",
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal)")
                                           + " SUM of one flat f32 bucket per step, as two segments on a side stream "
-                                            "(texture after the last reduce kernel, per-Gaussian after the last K8)") if (world > 1 or force_dist) else "none (1 GPU)",
-                       "grad_allreduce_measured": ({"collectives_timed": len(comm), "steps_timed": len(comm) // 2,
-                                                    "bytes_per_step": int(sum(b for b, _ in comm) / max(len(comm) // 2, 1)),
-                                                    "ms_per_step_on_comm_stream": round(sum(m for _, m in comm) / max(len(comm) // 2, 1), 4),
+                                            "(texture after the last reduce kernel, per-Gaussian after the last K8)"
+                                          + ("; the SH-coefficient run summed as bf16 on the wire" if args.wire == "bf16-sh" else "")) if (world > 1 or force_dist) else "none (1 GPU)",
+                       "grad_allreduce_measured": ({"collectives_timed": len(comm), "steps_timed": args.steps,
+                                                    "bytes_per_step": int(sum(b for b, _ in comm) / max(args.steps, 1)),
+                                                    "ms_per_step_on_comm_stream": round(sum(m for _, m in comm) / max(args.steps, 1), 4),
                                                     "world": world} if comm else None)},
             "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
             "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4),
                                         "source": "torch.cuda.Event per step on the op's stream, this rank"},
+            "per_rank": rank_table,
             "reference_call_pattern": compat,
             "reference_iteration": ref_iter,
             "retexture_pattern": retex,

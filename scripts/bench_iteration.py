@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "texture-gs_amd")):
         sys.path.insert(0, p)
 
 
-def run(N=300_000, R=1024, W=800, H=800, iters=12, warm=4, dev_index=0, precision="fp32"):
+def run(N=300_000, R=1024, W=800, H=800, iters=12, warm=4, dev_index=0, precision="mixed"):
     from texgs import synth, _lib, losses as LS
     from texgs import rasterizer as RZ
     from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer

@@ -320,7 +320,19 @@ def _two_segment_worker(rank, world, port, q):
         bk.all_reduce_async(dist, seg_t)          # same order on every rank: texture first, then the rest
         bk.all_reduce_async(dist, seg_g)
         out = bk.wait().clone()
-        q.put((rank, bool(torch.allclose(out, vals.sum(0))), bool(torch.equal(t.grad.reshape(-1), out[32:]))))
+        ok = bool(torch.allclose(out, vals.sum(0)))
+        # the wire-size lever: one segment summed as bf16 (half the bytes); the fp32 segments beside it stay exact
+        bk.flat.copy_(vals[rank])
+        seg_b = bk.segment_of([b])
+        bk.all_reduce_async(dist, seg_t)
+        bk.all_reduce_async(dist, bk.segment_of([a]))
+        bk.all_reduce_async(dist, seg_b, wire_dtype=torch.bfloat16)
+        out2 = bk.wait().clone()
+        exact = torch.cat([out2[:21], out2[32:]])
+        ok = ok and bool(torch.allclose(exact, torch.cat([vals.sum(0)[:21], vals.sum(0)[32:]])))
+        eb = out2[21:32] - vals.sum(0)[21:32]
+        ok = ok and float(eb.norm() / vals.sum(0)[21:32].norm()) < 4e-3 * max(1.0, world ** 0.5) and float(eb.abs().max()) > 0.0
+        q.put((rank, ok, bool(torch.equal(t.grad.reshape(-1), out2[32:]))))
     finally:
         dist.destroy_process_group()
 

@@ -128,8 +128,29 @@ def test_bench_gpus2_under_driver_launcher_parses(lib_built):
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["unit"] == "views/s" and j["scaling"] == "weak"
     assert j["config"]["global_views_per_step"] == 16 and j["value"] > 0
     assert "gloo" in j["config"]["grad_allreduce"]
+    # the per-rank table of an N > 1 line: both ranks report their views, instance counts and step split
+    pr = j["per_rank"]
+    assert pr["ranks_seen"] == 2 and sorted(r["rank"] for r in pr["ranks"]) == [0, 1]
+    assert all(r["views"] == 32 and r["D_sum"] > 0 and r["render_ms_per_step"] > 0 for r in pr["ranks"])
+    assert j["value_long"] > 0
     import helpers as Hh
     Hh.report("c4/bench_gpus2_one_gpu_gloo", views_per_s=j["value"], ms_per_step=j["ms_per_step"])
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_bf16_sh_wire(lib_built):
+    """The wire-size lever (`--wire bf16-sh`: the SH-coefficient run of the bucket summed as bf16, three collectives per step instead
+    of two) through the driver's launch line, two ranks rehearsed on one device."""
+    env = dict(os.environ, TEXGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-kernel-table", "--wire", "bf16-sh"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["per_rank"]["wire"] == "bf16-sh" and "bf16" in j["config"]["grad_allreduce"]
 
 
 @pytest.mark.gpu

@@ -122,18 +122,24 @@ class GradBucket:
         off = self.slices[idx[0]][0]
         return off, self.slices[idx[-1]][0] + self.slices[idx[-1]][1] - off
 
-    def all_reduce_async(self, dist, segment=None, after=(), timing=False):
+    def all_reduce_async(self, dist, segment=None, after=(), timing=False, wire_dtype=None):
         """Issue the SUM all-reduce of `segment` = (offset, count) of the flat buffer (default: all of it) on the bucket's side
         stream, ordered after the current stream's work so far and after the events in `after`; returns immediately.  Collectives
         are issued in call order on that one stream, so every rank must call this in the same order.  wait() joins.
         Backend "nccl" (= RCCL): in place on the device buffer.  Any other backend (gloo: the CPU tests, and the single-GPU
-        rehearsal where two ranks share a device) cannot run asynchronously: the segment is reduced here and now through a host copy."""
+        rehearsal where two ranks share a device) cannot run asynchronously: the segment is reduced here and now through a host copy.
+
+        `wire_dtype=torch.bfloat16` (opt-in, the wire-size lever of DESIGN.md section 7): the segment travels -- and is SUMMED by the
+        collective -- as bf16: half the bytes over xGMI, ~2^-8 relative rounding per partial sum (a segment whose consumer tolerates
+        that: the 45 view-dependent SH coefficients per Gaussian are 54 of the 150 MB of a C3 bucket and feed Adam, which normalises
+        by the gradient's own running magnitude).  The fp32 buffer is converted into a staging tensor on the comm stream, reduced,
+        and converted back in place."""
         off, n = segment if segment is not None else (0, self.flat.numel())
         buf = self.flat[off:off + n]
         if dist.get_backend() != "nccl" or not self.flat.is_cuda:
             for ev in after:                    # (other streams' texture-gradient kernels: the host copy must see their sums)
                 ev.synchronize()
-            self._reduce_now(dist, buf)
+            self._reduce_now(dist, buf, wire_dtype)
             return self
         cur = torch.cuda.current_stream(self.flat.device)
         if getattr(self, "_comm", None) is None:
@@ -147,10 +153,17 @@ class GradBucket:
             if timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self._comm)
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if wire_dtype is None or wire_dtype == torch.float32:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                wire_bytes = n * 4
+            else:
+                stage = buf.to(wire_dtype)      # (allocated on the comm stream: the caching allocator keeps it there)
+                dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+                buf.copy_(stage)
+                wire_bytes = n * stage.element_size()
             if timing:
                 e1.record(self._comm)
-                self._comm_events.append((n * 4, e0, e1))
+                self._comm_events.append((wire_bytes, e0, e1))
         self._pending = True
         return self
 
@@ -171,13 +184,18 @@ class GradBucket:
             self._comm_events.clear()
         return out
 
-    def _reduce_now(self, dist, buf):
+    def _reduce_now(self, dist, buf, wire_dtype=None):
+        wd = torch.float32 if wire_dtype is None else wire_dtype
         if buf.is_cuda:
-            host = torch.empty(buf.shape, dtype=torch.float32).pin_memory()
+            host = torch.empty(buf.shape, dtype=wd).pin_memory()
             host.copy_(buf, non_blocking=True)
             torch.cuda.current_stream(buf.device).synchronize()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             buf.copy_(host, non_blocking=True)
+        elif wd != torch.float32:
+            stage = buf.to(wd)
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+            buf.copy_(stage)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 

@@ -91,11 +91,17 @@ def pack_tcnn_params(layers, n_in, n_out, width=HIDDEN):
 class UVNet(nn.Module):
     """pre_mlp: 3 -> 128 -> emb_dim(128); relu(. + emb); mlp: 128 -> 128 -> 128 -> 3; F.normalize  (configs/*.yaml uv_net_cfg)."""
 
-    def __init__(self, xyz_offset=None, xyz_scale=None, precision="fp32"):
+    def __init__(self, xyz_offset=None, xyz_scale=None, precision="mixed"):
         super().__init__()
-        # arithmetic of the fused kernel's three 128x128 layers: "fp32" = f32-input MFMA (exact f32 products; the checked default),
-        # "bf16x3" = every operand split into two bf16 halves, three bf16 MFMAs per product (~2.5x faster, uvs / J within ~2e-5),
-        # "mixed" = the value column as "fp32" (same uvs, same ReLU masks), the three tangent columns as "bf16x3" (J within ~1e-5)
+        # arithmetic of the fused kernel's three 128x128 layers:
+        # "mixed" (the default since round 6) = the VALUE column on the f32-input MFMA -- uvs and every ReLU mask are exactly the
+        #   "fp32" kernel's, so the rasterizer's discrete decisions (cube face, bilinear cell) do not move --, the three TANGENT
+        #   columns (3/4 of the work) split-bf16: J within ~1.4e-5 of J_max at every point, the C3 image within 1e-4 of the one
+        #   rendered with the f32 J (tests/test_uvnet.py::test_mixed_jacobian_renders_the_same_image_at_c3); ~1.6x faster;
+        # "fp32" = f32-input MFMA throughout (exact f32 products; what the float64 parity tests check);
+        # "bf16x3" = every operand split into two bf16 halves, three bf16 MFMAs per product (~2.5x faster, uvs / J within ~2e-5; the
+        #   ReLU masks then come from the split value column: near a kink the forward is that of the neighbouring linear region and
+        #   the fused backward -- which recomputes its masks in f32 -- differentiates a slightly different function: inference only)
         if precision not in ("fp32", "bf16x3", "mixed"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'mixed'")
         self.precision = precision
