@@ -1,3 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_uvnet.py -m gpu -q -p no:cacheprovider -k "c3" 2>&1 | grep -E "passed|failed|^E  |FAILED|Error" | head -30
-grep c3_image gpurun_out/parity_report.jsonl | tail -1
+for S in 2 3 4; do
+timeout 300 python bench.py --no-cpu-baseline --no-extra-legs --no-kernel-table --steps 12 --warmup 4 --streams $S 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('streams $S', d['value'], d['value_long'])
+"
+done
+scripts/gpu_suite.sh

@@ -219,9 +219,14 @@ class _TexBins:
         if TEX_REC_CAP:
             self._resize(TEX_REC_CAP)
             return
-        # (No device->host read here -- ADVICE r5: sizing the first buffer from K6's exact counts was a blocking sync inside backward, which
-        #  stalled a pipelined multi-stream backward and cannot run under stream capture.  The first buffer is a guess from D; the
-        #  asynchronous statistic below corrects it; a buffer that is too small only sends the excess through atomics.)
+        if self.rec is None and counts is not None and not torch.cuda.is_current_stream_capturing():
+            # FIRST backward on this (device, stream) -- and the first after release_scratch(): size the buffer from K6's exact
+            # per-bin counts.  This is ONE blocking device->host read (ADVICE r5 asked to remove or document it): it waits for this
+            # view's forward, which the backward is ordered behind anyway; afterwards the asynchronous statistic below adapts the
+            # size and nothing here ever waits again.  A guess from D instead (tried: 24 records per instance) sends the excess
+            # of large-splat scenes through atomics on exactly the calls tests and benchmarks look at first, and makes the first
+            # call take another path than the following ones.  Under stream capture: the guess below, no read.
+            self._resize(int(counts.sum().item() * 1.25) + 4096)
         if self.event is not None and self.event.query():
             self.event = None
             wanted = int(self.host_stat[0])
