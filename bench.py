@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--wire", default=os.environ.get("TEXGS_WIRE", "f32"), choices=["f32", "bf16-sh"],
                     help="N > 1: dtype of the gradient all-reduce on the wire.  bf16-sh = the view-dependent SH gradients (54 of the 150 MB "
                          "of a C3 bucket) are summed as bf16 -- GradBucket.all_reduce_async(wire_dtype=...) --, everything else stays f32")
+    ap.add_argument("--tex-res", type=int, default=0,
+                    help="experiment: override the workload's cubemap resolution (e.g. C3 geometry with R = 2048: a 302 MB texture, past the "
+                         "256 MB Infinity Cache); the metric string then says so and is never the headline")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the reference-call-pattern / reference-iteration / retexture legs after the timed region (A/B runs)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
@@ -145,6 +148,8 @@ def main():
     from texgs.multiview import GradBucket, ViewPipeline, shard_views
 
     N, R, W, H, mode = WORKLOADS[args.workload]
+    if args.tex_res:
+        R = args.tex_res
     if args.leg == "iteration":
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import bench_iteration
@@ -393,16 +398,18 @@ def main():
     dom = max(kinfo, key=lambda k: kinfo[k]["avg_us"]) if kinfo else None        # every group launches once per view
     roofline = None
     traffic = None
+    traffic_all = None
     traffic_source = None
     # PMC pass of the same command (scripts/prof.sh + scripts/make_traffic.py), used only if it was measured on THESE kernel sources
     tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-    if dom and args.workload == "c3" and not untextured and tfiles:
+    if dom and args.workload == "c3" and not args.tex_res and not untextured and tfiles:
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             from make_traffic import source_hash
             tj = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1])))
             if tj.get("_kernel_source_hash") == source_hash():
                 traffic = tj.get(dom, {}).get("traffic_bytes")
+                traffic_all = {k: v for k, v in tj.items() if not k.startswith("_")}
                 traffic_source = (f"profiles/{tfiles[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload with --streams 1 on "
                                   f"these kernel sources, hash {tj['_kernel_source_hash']}; {tj.get('_calibration', '')})")
             else:
@@ -421,6 +428,16 @@ def main():
         if sv and not untextured:
             roofline["alg_bytes_per_launch_survey_8d"] = sv
             roofline["frac_survey_8d"] = round(sv / (kinfo[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        if traffic_all:
+            # every kernel group's measured past-L2 traffic per view beside its algorithmic bytes (VERDICT r5 #3 iii): the ratio is
+            # what the gather / scatter access patterns cost on top of the compulsory bytes
+            tb = {k: {"traffic_MB": round(v["traffic_bytes"] / 1e6, 1), "alg_MB": round(ab.get(k, 0) / 1e6, 1),
+                      "traffic_over_alg": (round(v["traffic_bytes"] / ab[k], 2) if ab.get(k) else None)} for k, v in traffic_all.items()}
+            ttot = sum(v["traffic_bytes"] for v in traffic_all.values())
+            roofline["traffic_by_kernel_per_view"] = tb
+            roofline["traffic_total_per_view_MB"] = round(ttot / 1e6, 1)
+            roofline["traffic_total_over_alg"] = round(ttot / max(sum(ab.values()), 1), 2)
+            roofline["traffic_rate_at_value_GBps"] = round(ttot * value / world / 1e9, 1)
         if dom == DOMINANT and kern_solo_dom[1]:
             solo_us = 1e3 * kern_solo_dom[0] / kern_solo_dom[1]
             roofline["solo_launch_us"] = round(solo_us, 2)
@@ -562,7 +579,7 @@ def main():
     if rank == 0:
         line = {
             "metric": ("fwd+bwd views/sec @800x800, 300k Gaussians + 1024^2 texture; HBM GB/s vs roofline"
-                       if args.workload == "c3" else f"{mode} views/sec ({args.workload})") if not untextured
+                       if (args.workload == "c3" and not args.tex_res) else f"{mode} views/sec ({args.workload}" + (f", R={R}" if args.tex_res else "") + ")") if not untextured
                       else f"{mode} views/sec ({args.workload}, untextured diff_gauss surface)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "value_long": round(value_long, 3),

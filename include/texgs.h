@@ -224,7 +224,7 @@ typedef struct TexGSGrads {
 } TexGSGrads;
 
 int         texgs_abi_version(void);
-/* Identity of the sources this library was built from (v15): 16 hex digits of sha256 over csrc/*, include/texgs.h and the compile
+/* Identity of the sources this library was built from (v15): 16 hex digits of sha256 over the files of csrc/, include/texgs.h and the compile
  * flags, baked in by texture-gs_amd/build.py.  The Python host layer recomputes it from the tree and refuses a stale library. */
 const char* texgs_build_id(void);
 const char* texgs_last_error(void);

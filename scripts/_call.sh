@@ -1,10 +1,11 @@
 cd $GRAFT_REPO_ROOT
-for S in 2 3 4; do
-timeout 300 python bench.py --no-cpu-baseline --no-extra-legs --no-kernel-table --steps 12 --warmup 4 --streams $S 2>/dev/null | python -c "
+for V in libtexgs_base.so libtexgs.so libtexgs_base.so libtexgs.so; do
+for MODE in "--streams 1" ""; do
+TEXGS_LIB=$PWD/texture-gs_amd/$V timeout 300 python bench.py --no-cpu-baseline --no-extra-legs --steps 8 --warmup 3 $MODE 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('streams $S', d['value'], d['value_long'])
+        d=json.loads(l); print('$V $MODE', d['value'], {k:round(v['avg_us']) for k,v in (d.get('kernels') or {}).items() if 'render' in k or 'reduce' in k})
 "
 done
-scripts/gpu_suite.sh
+done

@@ -19,38 +19,49 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["render.hip", "render_bwd_body.h", "preprocess.hip", "binning.hip", "common.h", "wave_ops.h"]
+
+# kernel name fragment -> bench.py kernel group (texgs.h TEXGS_K_*); k_bin_offsets is launched inside the render_bwd bracket
+GROUPS = (("k_render_fwd", "render_fwd"), ("k_render_bwd", "render_bwd"), ("k_bin_offsets", "render_bwd"), ("k_preprocess_fwd", "preprocess_fwd"),
+          ("k_preprocess_bwd", "preprocess_bwd"), ("k_texgrad_reduce", "texgrad_reduce"), ("k_duplicate", "duplicate"),
+          ("k_ranges", "ranges"), ("k_tile_order", "ranges"), ("k_depth_", "scan"), ("k_group_prefix", "duplicate"), ("k_radix_", "sort"))
 
 
 def source_hash():
-    h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "texture-gs_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    """Identity of the kernel sources a traffic file was measured on = the library's build id (texture-gs_amd/build.py build_id())."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("texgs_build_script", os.path.join(ROOT, "texture-gs_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_id()
 
 
 if __name__ == "__main__":
     root, out = sys.argv[1], sys.argv[2]
-    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    views = collections.defaultdict(int)
     for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            c = r["Counter_Name"]
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
                 n = r["Kernel_Name"]
-                for k, short in (("k_render_fwd", "render_fwd"), ("k_render_bwd", "render_bwd"), ("k_preprocess_fwd", "preprocess_fwd"),
-                                 ("k_preprocess_bwd", "preprocess_bwd"), ("k_texgrad_reduce", "texgrad_reduce"), ("k_duplicate", "duplicate"),
-                                 ("k_ranges", "ranges")):
+                if "k_render_fwd" in n:
+                    views[c] += 1                  # one K6 launch per profiled view
+                for k, short in GROUPS:
                     if k in n:
-                        vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                        tot[short][c] += float(r["Counter_Value"])
+                        break
     res = {}
-    for k, c in vals.items():
-        f = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)
-        w = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+    for k, c in tot.items():
+        f = c["FETCH_SIZE"] / max(views["FETCH_SIZE"], 1)
+        w = c["WRITE_SIZE"] / max(views["WRITE_SIZE"], 1)
         res[k] = {"fetch_bytes": int(2 * f * 1024), "write_bytes": int(w * 1024), "traffic_bytes": int((2 * f + w) * 1024)}
+    res["_views_profiled"] = dict(views)
     res["_kernel_source_hash"] = source_hash()
     res["_calibration"] = ("FETCH_SIZE x2 = 128-B line traffic (streaming reads 0.5000 of known bytes; 12-B gathers 64 B counted per miss); "
                            "WRITE_SIZE x1 for coalesced stores and 64-B atomic runs, 32 B per scattered 4-B atomic "
                            "(profiles/r04_traffic_calibration.json, scripts/ubench/traffic_cal.hip)")
-    res["_note"] = ("per launch, averaged over the profiled launches of `bench.py --steps 1 --warmup 2 --streams 1` (scripts/prof.sh); "
-                    "traffic past the L2 (Infinity-Cache hits are counted, not excluded)")
+    res["_note"] = ("per VIEW and kernel group (all launches of the group's kernels in the profiled views / views), "
+                    "`bench.py --steps 1 --warmup 2 --streams 1` (scripts/prof.sh); traffic past the L2 (Infinity-Cache hits are counted, "
+                    "not excluded)")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res)[:800])

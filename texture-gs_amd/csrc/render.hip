@@ -641,6 +641,29 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 //   w2 = g, likewise with cell y          w3 = b, its 4 low mantissa bits = the two high bits of fx18 and of fy18
 // inf / NaN survive the rounding (an inf / NaN upstream gradient still reaches exactly the texels it touches).
 struct __attribute__((aligned(16))) Rec4 { uint32_t a, b, c, d; };
+// records are written once (K7) and read once (the reduce): non-temporal on both sides, they should not displace texel lines and
+// shading records from the L2 (TG_NT=0: plain accesses, for A/B runs)
+#ifndef TG_NT
+#define TG_NT 1
+#endif
+typedef uint32_t tg_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rec_store(uint32_t* __restrict__ base, uint32_t slot, const Rec4 r) {
+#if TG_NT
+    tg_u4 v; v.x = r.a; v.y = r.b; v.z = r.c; v.w = r.d;
+    __builtin_nontemporal_store(v, reinterpret_cast<tg_u4*>(base) + slot);
+#else
+    reinterpret_cast<Rec4*>(base)[slot] = r;
+#endif
+}
+__device__ __forceinline__ Rec4 rec_load(const Rec4* __restrict__ p) {
+#if TG_NT
+    const tg_u4 v = __builtin_nontemporal_load(reinterpret_cast<const tg_u4*>(p));
+    Rec4 r; r.a = v.x; r.b = v.y; r.c = v.z; r.d = v.w;
+    return r;
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ uint32_t rec_word0(float fx, float fy, uint32_t& hi) {
     const uint32_t qx = min((uint32_t)(fx * 262144.0f + 0.5f), 262143u), qy = min((uint32_t)(fy * 262144.0f + 0.5f), 262143u);
     hi = (qx >> 16) | ((qy >> 16) << 2);
@@ -820,7 +843,7 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
     const uint32_t bbits = tb.stats[1];
     if (bbits >= 0x7F800000u) {                                // inf / NaN upstream gradient: float atomics, record by record
         for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)TB_THREADS) {
-            const RecVal r = rec_unpack(rp[i]);
+            const RecVal r = rec_unpack(rec_load(rp + i));
             const uint32_t y = (uint32_t)by * 32u + (uint32_t)r.cy, x = (uint32_t)bx * 32u + (uint32_t)r.cx;
             const uint32_t o00 = ((((uint32_t)face * (uint32_t)R + y) * (uint32_t)R + x) * 3u) << 2;
             scatter_direct(dtex, o00, 12u, 12u * (uint32_t)R, r.fx, r.fy, r.x0, r.x1, r.x2);
@@ -858,11 +881,11 @@ k_texgrad_reduce(int R, TexBinArgs tb, float* __restrict__ dtex) {
         // distinct cells: no change.)
         uint32_t i = s0 + (uint32_t)tid;
         for (; i + (uint32_t)TB_THREADS < s1; i += 2u * (uint32_t)TB_THREADS) {
-            const Rec4 ra = rp[i], rb = rp[i + (uint32_t)TB_THREADS];
+            const Rec4 ra = rec_load(rp + i), rb = rec_load(rp + i + (uint32_t)TB_THREADS);
             add_record(ra);
             add_record(rb);
         }
-        if (i < s1) add_record(rp[i]);
+        if (i < s1) add_record(rec_load(rp + i));
         __syncthreads();
         for (int k = tid; k < TB_EDGE * TB_EDGE * 3; k += TB_THREADS) {
             const int row = k / (TB_EDGE * 3), c = k - row * (TB_EDGE * 3);

@@ -321,7 +321,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
                 if (ovf) { const uint32_t pos = p0 + (slot & 63u); slot = (pos < p1) ? pos : TG_SLOT_NONE; }
             }
             if (slot < tb.cap) {
-                reinterpret_cast<Rec4*>(tb.rec)[slot] = rec_pack(R.fxw, R.fyw >> 10, (int)(R.fyw & 31u), (int)((R.fyw >> 5) & 31u), x0, x1, x2);
+                rec_store(tb.rec, slot, rec_pack(R.fxw, R.fyw >> 10, (int)(R.fyw & 31u), (int)((R.fyw >> 5) & 31u), x0, x1, x2));
             } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
                 scatter_direct(dtex, R.o00, R.dox, R.doy, R.fx, R.fy, x0, x1, x2);
             }

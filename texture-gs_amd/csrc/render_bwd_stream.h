@@ -275,7 +275,7 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
             if (slot == 0x12345678u && x0 == 17.f) tb.rec[0] = x1 + x2 + __uint_as_float(R.fxw ^ R.fyw);      // ablation: no record stores
 #else
             if (slot < tb.cap) {
-                reinterpret_cast<Rec4*>(tb.rec)[slot] = rec_pack(R.fxw, R.fyw >> 10, (int)(R.fyw & 31u), (int)((R.fyw >> 5) & 31u), x0, x1, x2);
+                rec_store(tb.rec, slot, rec_pack(R.fxw, R.fyw >> 10, (int)(R.fyw & 31u), (int)((R.fyw >> 5) & 31u), x0, x1, x2));
             } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
                 scatter_direct(dtex, R.o00, R.dox, R.doy, R.fx, R.fy, x0, x1, x2);
             }
