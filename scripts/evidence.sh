@@ -34,6 +34,10 @@ bash scripts/prof_ref_pattern.sh > gpurun_out/ref_pattern_profile.txt 2>&1
 echo "[ref pattern $(( $(date +%s) - T0 )) s]"
 bash scripts/prof_iteration.sh > gpurun_out/iteration_profile.txt 2>&1
 echo "[iteration profile $(( $(date +%s) - T0 )) s]"
+# gpurun copies back at most 64 MiB: the raw per-launch traces and counter tables have been summarised above -- drop them
+find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete
+find gpurun_out -name "*agent_info.csv" -delete; find gpurun_out -name "*.db" -delete; find gpurun_out -name "*.rocpd" -delete
+du -sh gpurun_out | tail -1
 python - <<'PY'
 import json
 for n in ("c3", "c3_serial", "c3_s4", "c2", "c5", "c3_diff_gauss", "c3_rccl1", "c3_R2048", "c3_R2048_serial", "c3_items"):

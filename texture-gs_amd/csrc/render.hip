@@ -42,6 +42,36 @@ __device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, uint
     return *reinterpret_cast<const Texel3*>(reinterpret_cast<const char*>(tex) + boff);
 }
 
+// records are written once (K7) and read once (the reduce): non-temporal on both sides, they should not displace texel lines and
+// shading records from the L2 (TG_NT=0: plain accesses, for A/B runs)
+#ifndef TG_NT
+#define TG_NT 1
+#endif
+typedef uint32_t tg_u4 __attribute__((ext_vector_type(4)));
+// the same for the other read-once / write-once streams of the blend kernels (survivor lists, per-pixel inputs and outputs, the
+// reservation tables): whatever is touched once should not take an L2 line from a texel or a shading record
+template <class T> __device__ __forceinline__ T nt_load(const T* p) {
+#if TG_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void nt_store(T* p, T v) {
+#if TG_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ uint2 nt_load2(const uint2* p) {
+    const unsigned long long v = nt_load(reinterpret_cast<const unsigned long long*>(p));
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ void nt_store2(uint2* p, uint2 v) {
+    nt_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32));
+}
+
 // Cubemap address of direction u (not necessarily unit): face (+x,-x,+y,-y,+z,-z; NVDIFFREC/util.py:94-101
 // inverted), bilinear taps with clamp-to-edge inside the face, texel centres at (i+0.5)/R.
 struct CubeTap {
@@ -476,7 +506,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             if (rq) L.list[q][mbcnt64(m)] = (uint8_t)lane;
         }
         if (a.surv != nullptr) {                // a backward will follow: it replays exactly these survivors, back to front
-            if (lane < take) { a.surv[sbase + nsurv + lane] = make_uint2(id, pos); a.surv_qm[sbase + nsurv + lane] = (uint16_t)qbits; }
+            if (lane < take) { nt_store2(a.surv + sbase + nsurv + lane, make_uint2(id, pos)); nt_store(a.surv_qm + sbase + nsurv + lane, (uint16_t)qbits); }
             nsurv += take;
         }
         __builtin_amdgcn_wave_barrier();
@@ -572,7 +602,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
         uint32_t off = 0u;
         if (b != TG_RESV_EMPTY) off = atomicAdd(bin_count + b, n);
         uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
-        rv[lane] = b; rv[TG_RESV + lane] = off; rv[2 * TG_RESV + lane] = n;
+        nt_store(rv + lane, b); nt_store(rv + TG_RESV + lane, off); nt_store(rv + 2 * TG_RESV + lane, n);
     }
     if (a.surv_cnt != nullptr && lane == 0) a.surv_cnt[4 * tile + wave] = (uint32_t)nsurv;
     if (streaming && lane == 0) {
@@ -583,14 +613,14 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
     if (inside) {
         const int HW = a.W * a.H, pix = py * a.W + px;
         const double q = 1.0 / 4294967296.0;
-        out_color[pix] = (float)((double)L.col[lane * 3 + 0] * q) + T * a.bg[0];
-        out_color[HW + pix] = (float)((double)L.col[lane * 3 + 1] * q) + T * a.bg[1];
-        out_color[2 * HW + pix] = (float)((double)L.col[lane * 3 + 2] * q) + T * a.bg[2];
-        out_depth[pix] = Dp;
-        out_norm[pix] = N0; out_norm[HW + pix] = N1; out_norm[2 * HW + pix] = N2;
-        out_alpha[pix] = Al;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
+        nt_store(out_color + pix, (float)((double)L.col[lane * 3 + 0] * q) + T * a.bg[0]);
+        nt_store(out_color + HW + pix, (float)((double)L.col[lane * 3 + 1] * q) + T * a.bg[1]);
+        nt_store(out_color + 2 * HW + pix, (float)((double)L.col[lane * 3 + 2] * q) + T * a.bg[2]);
+        nt_store(out_depth + pix, Dp);
+        nt_store(out_norm + pix, N0); nt_store(out_norm + HW + pix, N1); nt_store(out_norm + 2 * HW + pix, N2);
+        nt_store(out_alpha + pix, Al);
+        nt_store(final_T + pix, T);
+        nt_store(n_contrib + pix, last);
     }
 }
 
@@ -641,12 +671,6 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 //   w2 = g, likewise with cell y          w3 = b, its 4 low mantissa bits = the two high bits of fx18 and of fy18
 // inf / NaN survive the rounding (an inf / NaN upstream gradient still reaches exactly the texels it touches).
 struct __attribute__((aligned(16))) Rec4 { uint32_t a, b, c, d; };
-// records are written once (K7) and read once (the reduce): non-temporal on both sides, they should not displace texel lines and
-// shading records from the L2 (TG_NT=0: plain accesses, for A/B runs)
-#ifndef TG_NT
-#define TG_NT 1
-#endif
-typedef uint32_t tg_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void rec_store(uint32_t* __restrict__ base, uint32_t slot, const Rec4 r) {
 #if TG_NT
     tg_u4 v; v.x = r.a; v.y = r.b; v.z = r.c; v.w = r.d;

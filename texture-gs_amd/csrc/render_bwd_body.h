@@ -59,11 +59,11 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     float Tfin = 1.f; int last = 0;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
     if (inside) {
-        Tfin = final_T[pix]; last = (int)n_contrib[pix];
-        if (dL_dcolor) { dpix[0] = dL_dcolor[pix]; dpix[1] = dL_dcolor[HW + pix]; dpix[2] = dL_dcolor[2 * HW + pix]; }
-        if (dL_ddepth) dpix[3] = dL_ddepth[pix];
-        if (dL_dnorm) { dpix[4] = dL_dnorm[pix]; dpix[5] = dL_dnorm[HW + pix]; dpix[6] = dL_dnorm[2 * HW + pix]; }
-        if (dL_dalpha) dpix[7] = dL_dalpha[pix];
+        Tfin = nt_load(final_T + pix); last = (int)nt_load(n_contrib + pix);
+        if (dL_dcolor) { dpix[0] = nt_load(dL_dcolor + pix); dpix[1] = nt_load(dL_dcolor + HW + pix); dpix[2] = nt_load(dL_dcolor + 2 * HW + pix); }
+        if (dL_ddepth) dpix[3] = nt_load(dL_ddepth + pix);
+        if (dL_dnorm) { dpix[4] = nt_load(dL_dnorm + pix); dpix[5] = nt_load(dL_dnorm + HW + pix); dpix[6] = nt_load(dL_dnorm + 2 * HW + pix); }
+        if (dL_dalpha) dpix[7] = nt_load(dL_dalpha + pix);
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
     if (lane < 3) L.items[BQ_CAP * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -90,8 +90,8 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         uint32_t b = TG_RESV_EMPTY, p0 = 0u, n = 0u;
         if (tb.rec != nullptr) {
             const uint32_t* __restrict__ rv = a.resv + (size_t)(4 * tile + wave) * (3 * TG_RESV);
-            b = rv[lane];
-            if (b != TG_RESV_EMPTY) { p0 = tb.base[b] + rv[TG_RESV + lane]; n = rv[2 * TG_RESV + lane]; }
+            b = nt_load(rv + lane);
+            if (b != TG_RESV_EMPTY) { p0 = tb.base[b] + nt_load(rv + TG_RESV + lane); n = nt_load(rv + 2 * TG_RESV + lane); }
         }
         resv_bin(L.p, lane) = b; L.tpos[lane] = p0; L.tend[lane] = p0 + n;
     }
@@ -114,7 +114,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     const int ns = min((int)a.surv_cnt[4 * tile + wave], todo);      // (a count beyond the block's region can only be a stale buffer)
     uint2 nsv = make_uint2(0u, 0xFFFFFFFFu);
     uint32_t nqm = 0u;
-    if (ns - 1 - lane >= 0) { nsv = a.surv[sbase + (ns - 1 - lane)]; nqm = a.surv_qm[sbase + (ns - 1 - lane)]; }
+    if (ns - 1 - lane >= 0) { nsv = nt_load2(a.surv + sbase + (ns - 1 - lane)); nqm = nt_load(a.surv_qm + sbase + (ns - 1 - lane)); }
     // ---- stage B, as two halves per round of 64 items (see the kernel header): FRONT issues everything that goes to memory,
     // BACK consumes it.  A segment has at most two rounds: both fronts first (8 tap loads + 2 returning atomics in flight), then
     // both backs.  (Starting round 0's front inside stage A, as soon as 64 items exist, was measured: K7 732 -> 771 us.)
@@ -336,7 +336,7 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         const bool live = hi - 1 - lane >= 0;
         const uint32_t id = nsv.x, pos = nsv.y, qm = nqm;
         nsv = make_uint2(0u, 0xFFFFFFFFu); nqm = 0u;
-        if (hi - 65 - lane >= 0) { nsv = a.surv[sbase + (hi - 65 - lane)]; nqm = a.surv_qm[sbase + (hi - 65 - lane)]; }
+        if (hi - 65 - lane >= 0) { nsv = nt_load2(a.surv + sbase + (hi - 65 - lane)); nqm = nt_load(a.surv_qm + sbase + (hi - 65 - lane)); }
         // survivors behind the block's last contributor (K6 tested them, nothing blended): skip whole chunks of them
         const int take = min(64, hi);
         if ((int)__builtin_amdgcn_readlane((int)pos, take - 1) >= wave_last) continue;
