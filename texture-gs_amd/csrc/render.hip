@@ -396,7 +396,7 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             const uint32_t gid = (uint32_t)__builtin_amdgcn_ds_bpermute(jj_ << 2, (int)cid);
             if (lane < n_ && page != TG_NOPAGE) {
                 uint32_t* __restrict__ pb = a.item_pages + (size_t)page * (3 * TG_PAGE) + (v & (TG_PAGE - 1));
-                pb[0] = e_.x; pb[TG_PAGE] = __float_as_uint(araw_); pb[2 * TG_PAGE] = (gid << 6) | (uint32_t)KEY_PL(e_.y);
+                nt_store(pb, e_.x); nt_store(pb + TG_PAGE, __float_as_uint(araw_)); nt_store(pb + 2 * TG_PAGE, (gid << 6) | (uint32_t)KEY_PL(e_.y));
             }
             if (cross) { prev_page = cur_page; cur_page = nxt; }
             nitems += n_;

@@ -56,11 +56,11 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
     float Tfin = 1.f;
     float dpix[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d (r,g,b,depth,nx,ny,nz,alpha)
     if (inside) {
-        Tfin = final_T[pix];
-        if (dL_dcolor) { dpix[0] = dL_dcolor[pix]; dpix[1] = dL_dcolor[HW + pix]; dpix[2] = dL_dcolor[2 * HW + pix]; }
-        if (dL_ddepth) dpix[3] = dL_ddepth[pix];
-        if (dL_dnorm) { dpix[4] = dL_dnorm[pix]; dpix[5] = dL_dnorm[HW + pix]; dpix[6] = dL_dnorm[2 * HW + pix]; }
-        if (dL_dalpha) dpix[7] = dL_dalpha[pix];
+        Tfin = nt_load(final_T + pix);
+        if (dL_dcolor) { dpix[0] = nt_load(dL_dcolor + pix); dpix[1] = nt_load(dL_dcolor + HW + pix); dpix[2] = nt_load(dL_dcolor + 2 * HW + pix); }
+        if (dL_ddepth) dpix[3] = nt_load(dL_ddepth + pix);
+        if (dL_dnorm) { dpix[4] = nt_load(dL_dnorm + pix); dpix[5] = nt_load(dL_dnorm + HW + pix); dpix[6] = nt_load(dL_dnorm + 2 * HW + pix); }
+        if (dL_dalpha) dpix[7] = nt_load(dL_dalpha + pix);
     }
     const float bgdot = a.bg[0] * dpix[0] + a.bg[1] * dpix[1] + a.bg[2] * dpix[2];
     if (lane < 3) L.items[64 * 3 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -99,7 +99,7 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
     uint32_t nT = 0u, nA = 0u, nK = 0u;                       // the NEXT segment's items, loaded one segment ahead
     {
         const uint32_t* __restrict__ sp = seg_ptr(g);
-        if (64 * g + lane < n) { nT = sp[0]; nA = sp[TG_PAGE]; nK = sp[2 * TG_PAGE]; }
+        if (64 * g + lane < n) { nT = nt_load(sp); nA = nt_load(sp + TG_PAGE); nK = nt_load(sp + 2 * TG_PAGE); }
     }
 
     struct Seg { int n_items, n_it, ntask; uint32_t it_lo, it_hi, it_first; };      // it_*: lane k = pixel ballot / first item of pseudo-iteration k
@@ -382,7 +382,7 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
         nT = 0u; nA = 0u; nK = 0u;
         if (g > 0) {
             const uint32_t* __restrict__ sp = seg_ptr(g - 1);
-            nT = sp[0]; nA = sp[TG_PAGE]; nK = sp[2 * TG_PAGE];
+            nT = nt_load(sp); nA = nt_load(sp + TG_PAGE); nK = nt_load(sp + 2 * TG_PAGE);
             if (((g - 1) >> 2) != cur_pi) {            // entered the previous page: it becomes the current one, its link is loaded a page ahead
                 cur_page = prev_page; --cur_pi;
                 prev_page = (cur_pi > 0) ? a.item_link[cur_page] : TG_NOPAGE;
