@@ -604,6 +604,19 @@ static void atomic_addd(double *p, double v) {
 void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                              const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex,
                              float tau_cell, float cell_weight, float tex_slope, double *fmass, const float *margin, float tau_fwd);
+/* CONDITIONING MASS (round 6; with fmass): the falloff exponent power = -(A dx^2 + C dy^2)/2 - B dx dy is a sum of terms that grow with
+ * the square of the distance from the splat centre; under splats hundreds of pixels wide they reach 10..100 and alpha is known only to
+ * pu = 4 roundings of the largest term, RELATIVE, in any fp32 implementation (texgs_ref_ambiguity_ex uses the same pu for its decision
+ * margins).  Everything the backward sums is a smooth function of the alphas, so to first order a pair's terms move by
+ *   its own alpha:           pu_i                                   (w_i, alpha_raw and the Gaussian factor of dL/dpower)
+ *   the transmittance:       tunc_i = sum over pairs in front of pu_j alpha_j / (1 - alpha_j)
+ *   the blend behind it:     u_all * sum_ch |dL/dout_ch| * (blend of |feature_ch| behind the pair)     (dL/dalpha is a difference
+ *                            (f - accum) that may cancel while accum's own uncertainty does not), u_all = max pu + the pixel's total tunc
+ * and the background term by the pixel's total.  cond_weight x those bounds are added to fmass, slot by slot, like the cell-edge
+ * masses; pushed through the (linear) last stage they widen a row's tolerance by what the conditioning of ITS OWN pairs allows --
+ * negligible on the benchmark scenes (pu ~ 1e-7), the whole story in the stress scene.  0 = off. */
+static float g_cond_weight = 0.0f;
+void texgs_ref_set_cond_weight(float w) { g_cond_weight = w; }
 void texgs_ref_render_bwd(const RefIn *in, const float *rec, const uint32_t *point_list, const uint32_t *ranges,
                           const float *final_T, const uint32_t *n_contrib, const float *dout, double *acc, float *dtex) {
     texgs_ref_render_bwd_ex(in, rec, point_list, ranges, final_T, n_contrib, dout, acc, dtex, 0.0f, 0.0f, 0.0f, NULL, NULL, 0.0f);
@@ -632,6 +645,22 @@ void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *
             for (int ch = 0; ch < 8; ++ch) dpix[ch] = dout[ch * HW + pix];
             const float bgdot = in->bg[0] * dpix[0] + in->bg[1] * dpix[1] + in->bg[2] * dpix[2];
             float T = Tfin, accum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_alpha = 0, last_f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            /* conditioning mass: the pixel's totals, front to back (same decisions as the loop below) */
+            const float condw = fmass ? g_cond_weight : 0.0f;
+            float tunc_total = 0.f, pu_max = 0.f, tsum_back = 0.f, accabs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (condw > 0.0f) {
+                for (int pos = 0; pos < last; ++pos) {
+                    const float *r = rec + (size_t)point_list[r0 + pos] * REC;
+                    const float dx = r[0] - pxf, dy = r[1] - pyf;
+                    const float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float alpha = fminf(ALPHA_MAX, r[5] * EXPF(power));
+                    if (alpha < ALPHA_MIN) continue;
+                    const float pu = 4.0f * 5.9604645e-8f * (0.5f * fabsf(r[2] * dx * dx) + 0.5f * fabsf(r[4] * dy * dy) + fabsf(r[3] * dx * dy));
+                    tunc_total += pu * alpha / fmaxf(1.0f - alpha, 0.01f);
+                    pu_max = fmaxf(pu_max, pu);
+                }
+            }
             for (int pos = last - 1; pos >= 0; --pos) {
                 const uint32_t id = point_list[r0 + pos];
                 const float *r = rec + (size_t)id * REC;
@@ -663,13 +692,16 @@ void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *
                     f[ch] = fmaxf(0.f, pre[ch]);
                 }
                 f[3] = r[20]; f[4] = r[21]; f[5] = r[22]; f[6] = r[23]; f[7] = 1.0f;
-                float dLda = 0.f;
+                float dLda = 0.f, behind_abs = 0.f;
                 for (int ch = 0; ch < 8; ++ch) {
+                    accabs[ch] = last_alpha * fabsf(last_f[ch]) + (1.f - last_alpha) * accabs[ch];     /* (uses last_f before it is replaced) */
                     accum[ch] = last_alpha * last_f[ch] + (1.f - last_alpha) * accum[ch];
                     last_f[ch] = f[ch];
                     dLda += (f[ch] - accum[ch]) * dpix[ch];
+                    behind_abs += accabs[ch] * fabsf(dpix[ch]);
                 }
                 last_alpha = alpha;
+                const float dLda_sum = dLda;            /* sum_ch (f - accum) dL/dout, before the factor T */
                 dLda *= T;
                 dLda += (-Tfin / (1.0f - alpha)) * bgdot;
                 const float dLdp = araw * dLda;
@@ -711,6 +743,25 @@ void texgs_ref_render_bwd_ex(const RefIn *in, const float *rec, const uint32_t *
                 }
                 double *ap = acc + (size_t)id * REC;
                 for (int k = 0; k < REC; ++k) if (part[k] != 0.f) atomic_addd(ap + k, (double)part[k]);
+                if (condw > 0.0f) {
+                    const float pu = 4.0f * 5.9604645e-8f * (0.5f * fabsf(r[2] * dx * dx) + 0.5f * fabsf(r[4] * dy * dy) + fabsf(r[3] * dx * dy));
+                    const float term = pu * alpha / fmaxf(1.0f - alpha, 0.01f);
+                    const float tunc_i = fmaxf(0.0f, tunc_total - tsum_back - term);      /* pairs strictly in front of this one */
+                    tsum_back += term;
+                    const float u_all = pu_max + tunc_total;
+                    const float rel_w = pu + tunc_i;
+                    const float dLda_unc = T * (tunc_i * fabsf(dLda_sum) + u_all * behind_abs)
+                                         + (Tfin / fmaxf(1.0f - alpha, 0.01f)) * fabsf(bgdot) * (tunc_total + term);
+                    const float cdl[6] = {araw * gdx, araw * gdy, -0.5f * dx * dx * araw, -dx * dy * araw, -0.5f * dy * dy * araw, Gs};
+                    double *fp = fmass + (size_t)id * REC;
+                    for (int k = 0; k < 6; ++k) {
+                        const float m = fabsf(cdl[k]) * (dLda_unc + fabsf(dLda) * pu);
+                        if (m != 0.f) atomic_addd(fp + k, (double)(condw * m));
+                    }
+                    if (uv0 != 0.f) atomic_addd(fp + 0, (double)(condw * fabsf(uv0) * rel_w));
+                    if (uv1 != 0.f) atomic_addd(fp + 1, (double)(condw * fabsf(uv1) * rel_w));
+                    for (int k = 6; k < REC; ++k) if (part[k] != 0.f) atomic_addd(fp + k, (double)(condw * fabsf(part[k]) * rel_w));
+                }
                 if (fmass && tex_slope > 0.0f) {
                     /* colour clamp max(0, pre) within tex_slope (= tau_relu) of switching for a channel: the pair's colour gradient of
                        that channel is all or nothing -- w dL/dcolour for the view-dependent slots, and through C0 the texture's

@@ -126,23 +126,28 @@ class RefRun:
                                  _p(self.final_T), _p(self.n_contrib))
         return self.out
 
-    def backward(self, dout, tau_cell=0.0, cell_weight=1.0, margin=None, tau_fwd=0.0, tau_relu=0.0):
+    def backward(self, dout, tau_cell=0.0, cell_weight=1.0, margin=None, tau_fwd=0.0, tau_relu=0.0, cond_weight=0.0):
         """dout: float32 [8,H,W] (r,g,b,depth,nx,ny,nz,alpha).  Returns dict of input gradients.
         tau_cell > 0: also collects self.fmass [N,24] -- per Gaussian, the absolute mass of the terms that hang on a bilinear cell
         choice within tau_cell texels of flipping (texgs_ref_render_bwd_ex) -- for cell_edge_deviation().  margin [H,W] (from
         ambiguity()) + tau_fwd: also 2/255 of every term of the pairs in forward-ambiguous pixels (a marginal contributor flipping
         moves the others' transmittance by 1/255).  tau_relu > 0: also the all-or-nothing colour gradient of pairs whose
-        max(0, .) argument is within tau_relu of zero (then ambiguity() need not flag their rows: pass it tau_relu=0)."""
+        max(0, .) argument is within tau_relu of zero (then ambiguity() need not flag their rows: pass it tau_relu=0).
+        cond_weight > 0 (with tau_cell > 0 so that fmass exists): also the CONDITIONING mass of every pair -- how far its terms move under
+        the fp32 rounding of its own falloff exponent, of the transmittance in front of it and of the blend behind it
+        (texgs_ref.c: texgs_ref_set_cond_weight) -- times cond_weight."""
         N, K, R, lib = self.N, self.K, self.R, self.lib
         dout = np.ascontiguousarray(dout.astype(np.float32))
         acc = np.zeros((max(N, 1), REC), np.float64)
         dtex = np.zeros((6, R, R, 3), np.float32) if self.textured else None
         self.fmass = np.zeros((max(N, 1), REC), np.float64) if tau_cell > 0 else None
         slope = float(tau_relu)          # (the C argument `tex_slope` carries tau_relu of the pair-level colour-clamp treatment; 0 = off)
+        lib.texgs_ref_set_cond_weight(C.c_float(float(cond_weight) if self.fmass is not None else 0.0))
         lib.texgs_ref_render_bwd_ex(C.byref(self.inp), _p(self.rec), _p(self.point_list), _p(self.ranges), _p(self.final_T),
                                     _p(self.n_contrib), _p(dout), _p(acc), _p(dtex), C.c_float(tau_cell), C.c_float(cell_weight),
                                     C.c_float(slope), _p(self.fmass),
                                     _p(None if margin is None else np.ascontiguousarray(margin, np.float32)), C.c_float(tau_fwd))
+        lib.texgs_ref_set_cond_weight(C.c_float(0.0))
         g = self._k8(acc, self._grad_arrays())
         g["texture"] = dtex
         self.acc = acc

@@ -453,3 +453,45 @@ def assert_integer_stages_bit_exact(ref, outs, s):
     # the xy / conic part of the record that the tile rect came from is bit-identical too
     rec = t["rec"][:N, :2].cpu().numpy()
     assert np.array_equal(rec[vis].view(np.uint32), ref.rec[:N, :2][vis].view(np.uint32))
+
+
+def stress_scene(N=20000, R=64, seed=3):
+    """Not the benchmark sphere: Gaussians scattered through a box that contains the camera (some behind it, some hugging
+    the near plane), scales over 3 decades (sub-pixel to screen-filling), random rotations / opacities, anisotropic."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    means = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([8.0, 6.0, 10.0])
+    scales = torch.exp(torch.rand(N, 3, generator=g) * math.log(500.0) + math.log(0.001))
+    q = torch.randn(N, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    opac = torch.rand(N, 1, generator=g)
+    opac[::7] = 0.001                                          # never reach 1/255
+    uvs = torch.randn(N, 3, generator=g)
+    uvs = uvs / uvs.norm(dim=1, keepdim=True)
+    juv = torch.randn(N, 9, generator=g) * 0.5
+    return synth.Scene(means, scales, q, opac, 0.2 * torch.randn(N, 15, 3, generator=g), uvs, juv,
+                       torch.randn(6, R, R, 3, generator=g))
+
+
+GRAD_NAMES = ["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"]
+COND_WEIGHT = 2.0
+
+
+def stress_gradient_check(label, ref, got8, dout, R, hard_frac_max=0.4):
+    """Gradients of an ill-conditioned scene WITHOUT outlier budgets: `ref` a C-oracle run after forward(), `got8` the other
+    implementation's eight gradients for upstream `dout`.  Per-Gaussian rows at pair level (grad_mass_attributed) with the cell-edge,
+    colour-clamp, marginal-contributor AND conditioning masses of the oracle's backward; texel rows by the flags of ambiguity().
+    The aggregate relative-L2 bound is the loose one: gradients of this scene span six decades, one large row inside its own
+    tolerance sets the norm."""
+    margin, hard, _ = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=0.0, tau_relu=0.0, own_only=True)
+    gref = ref.backward(dout, tau_cell=tau_cell(R), cell_weight=1.0, margin=margin, tau_fwd=TAU_FWD, tau_relu=tau_relu(R),
+                        cond_weight=COND_WEIGHT)
+    cdev = ref.cell_edge_deviation()
+    for name_, got_g in zip(GRAD_NAMES[:7], got8[:7]):
+        assert bool(torch.isfinite(got_g).all()), name_
+        grad_mass_attributed(f"{label}/bwd/{name_}", got_g.cpu(), torch.tensor(gref[name_]), hard, cdev[name_],
+                             hard_frac_max=hard_frac_max, clean_rel=2e-2)
+    _, _, tflag = ref.ambiguity(tau_fwd=TAU_FWD, tau_cell=tau_cell(R), tau_relu=tau_relu(R))
+    assert bool(torch.isfinite(got8[7]).all())
+    grad_attributed(f"{label}/bwd/texture", got8[7].cpu(), torch.tensor(gref["texture"]), tflag, flagged_frac_max=0.9, clean_rel=5e-3)
+    return gref

@@ -120,26 +120,9 @@ def test_size_independent_properties_full_size(lib_built):
     assert bool((nc <= per_px).all())
 
 
-def _stress_scene(N=20000, R=64, seed=3):
-    """Not the benchmark sphere: Gaussians scattered through a box that contains the camera (some behind it, some hugging
-    the near plane), scales over 3 decades (sub-pixel to screen-filling), random rotations / opacities, anisotropic."""
-    g = torch.Generator().manual_seed(seed)
-    means = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([8.0, 6.0, 10.0])
-    scales = torch.exp(torch.rand(N, 3, generator=g) * math.log(500.0) + math.log(0.001))
-    q = torch.randn(N, 4, generator=g)
-    q = q / q.norm(dim=1, keepdim=True)
-    opac = torch.rand(N, 1, generator=g)
-    opac[::7] = 0.001                                          # never reach 1/255
-    uvs = torch.randn(N, 3, generator=g)
-    uvs = uvs / uvs.norm(dim=1, keepdim=True)
-    juv = torch.randn(N, 9, generator=g) * 0.5
-    return synth.Scene(means, scales, q, opac, 0.2 * torch.randn(N, 15, 3, generator=g), uvs, juv,
-                       torch.randn(6, R, R, 3, generator=g))
-
-
 def test_stress_scene_vs_c_oracle(lib_built):
     from texgs.rasterizer import backward_raw
-    scene = _stress_scene()
+    scene = Hh.stress_scene()
     cam = synth.look_at_camera((0.3, -0.2, -3.0), 640, 360, fovx=1.2)
     bg = torch.tensor([0.05, 0.1, 0.15])
     ref = CR.RefRun(scene, Hh.settings_for(cam, 3, bg))
@@ -165,14 +148,11 @@ def test_stress_scene_vs_c_oracle(lib_built):
     dev = outs[0].device
     res = backward_raw(s, dout[0:3].to(dev).contiguous(), dout[3:4].to(dev).contiguous(), dout[4:7].to(dev).contiguous(),
                        dout[7:8].to(dev).contiguous())
-    gref = ref.backward(dout.numpy())
-    # gradients: this scene's screen-filling splats make the falloff exponent itself ill-conditioned (see forward_attributed's cond),
-    # and with it every gradient that passes through alpha; the row-level budgets of rounds 2-4 stay for this one scene
-    for name_, got_g in zip(["means3D", "means2D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], res[:8]):
-        assert bool(torch.isfinite(got_g).all()), name_
-        ok, msg = Hh.grad_close(got_g.cpu(), torch.tensor(gref[name_]), max_outlier_frac=0.005, global_rel=1e-2,
-                                label=f"hip_vs_c32/stress/bwd/{name_}")
-        assert ok, (name_, msg)
+    # gradients: this scene's screen-filling splats make the falloff exponent itself ill-conditioned, and with it every gradient that
+    # passes through alpha.  Until round 5: row budgets (0.5 % outlier rows, 1e-2 global L2).  Now the oracle's backward books what that
+    # conditioning can move, pair by pair, and EVERY row is checked against plain tolerance + its own bound: zero unexplained rows
+    # (helpers.stress_gradient_check; validated on the CPU against a differently-rounded build, tests/test_c_oracle.py)
+    Hh.stress_gradient_check("hip_vs_c32/stress", ref, list(res[:8]), dout.numpy(), R)
 
 
 def test_more_than_65536_tiles_three_digit_tile_sort(lib_built):
