@@ -1,3 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_parity_c_oracle_gpu.py -m gpu -q -p no:cacheprovider -k "stress" 2>&1 | grep -E "passed|failed|^E  |FAILED|Error" | cut -c1-600 | head -20
-grep "hip_vs_c32/stress/bwd" gpurun_out/parity_report.jsonl | cut -c1-700
+for V in libtexgs.so libtexgs_fulllds.so; do
+for MODE in "--streams 1" ""; do
+TEXGS_LIB=$PWD/texture-gs_amd/$V timeout 300 python bench.py --no-cpu-baseline --no-extra-legs --steps 12 --warmup 4 $MODE 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$V $MODE', d['value'], d['value_long'], {k:round(v['avg_us']) for k,v in (d.get('kernels') or {}).items() if 'render' in k or 'reduce' in k})
+"
+done
+done

@@ -18,15 +18,17 @@
 //                  texture work (UV Taylor step, cubemap address, 4 taps, colour / gradients) runs 64 pairs at a time.
 //
 // Texture gradient (K7): every fp32 global atomic on this part executes memory-side at ~20 G requests/s and the ~19 M
-// bilinear footprints of a C3 view cost 0.69 ms that way (profiles/r02_ablation.md).  Instead K7 APPENDS a 20-byte
-// record {fx | cell x, fy | cell y, dL/dtexel-colour (3)} per footprint with plain stores to the list of the 32x32-texel
+// bilinear footprints of a C3 view cost 0.69 ms that way (profiles/r02_ablation.md).  Instead K7 WRITES one 16-byte
+// record {fx, fy, cell, dL/dtexel-colour (3)} per footprint with ONE non-temporal store into the list of the 32x32-texel
 // texture block ("bin") the footprint is anchored in, and k_texgrad_reduce then sums each bin's list in LDS and adds every
 // texel of the block to dL_dtexture once.  The lists are EXACTLY sized and every slot has an owner before K7 starts: K6
 // counts the footprints per (8x8 pixel block, bin) in a 16-entry LDS table while it renders and, at block end, RESERVES the
 // block's range of each list with one returning atomic per entry on the bin's total; a one-workgroup scan turns the totals
 // into list offsets; K7 reads its block's table back and hands out slots with an LDS atomic (round 5; until then: a grouping
 // loop and one returning GLOBAL atomic per (wave round, distinct bin) on a cursor -- 100 of K7's 700 us).  The records of a
-// view are one contiguous array (~0.37 GB at C3) -- no per-bin capacity, no chunk tables, nothing to wait for.
+// view are one contiguous array (~0.30 GB at C3) -- no per-bin capacity, no chunk tables, nothing to wait for.
+// What bounds these kernels (round 6): the path behind the L2 -- gather / scatter requests into the Infinity
+// Cache -- not instruction issue; write-once / read-once streams are therefore non-temporal (nt_load / nt_store).
 // No MFMA: there is no dense contraction on this path.
 #include "common.h"
 #include "wave_ops.h"
@@ -43,26 +45,15 @@ __device__ __forceinline__ Texel3 load_texel(const float* __restrict__ tex, uint
 }
 
 // records are written once (K7) and read once (the reduce): non-temporal on both sides, they should not displace texel lines and
-// shading records from the L2 (TG_NT=0: plain accesses, for A/B runs)
-#ifndef TG_NT
-#define TG_NT 1
-#endif
+// shading records from the L2 (A/B against plain accesses: K7 FETCH_SIZE 1.42 -> 1.03 GB, 589 -> 578 us; profiles/r06_ablation.md)
 typedef uint32_t tg_u4 __attribute__((ext_vector_type(4)));
 // the same for the other read-once / write-once streams of the blend kernels (survivor lists, per-pixel inputs and outputs, the
 // reservation tables): whatever is touched once should not take an L2 line from a texel or a shading record
 template <class T> __device__ __forceinline__ T nt_load(const T* p) {
-#if TG_NT
     return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
 }
 template <class T> __device__ __forceinline__ void nt_store(T* p, T v) {
-#if TG_NT
     __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ uint2 nt_load2(const uint2* p) {
     const unsigned long long v = nt_load(reinterpret_cast<const unsigned long long*>(p));
@@ -274,9 +265,6 @@ __device__ __forceinline__ void init_dummy(Planes& P, int lane) {
 // of every contributing (pixel, Gaussian) pair is added by the dense phase into the pixel's LDS accumulator as Q32.32
 // fixed point with integer atomics -- the sum is order-independent, so it equals the in-order blend and is bit-reproducible.
 #define FQ_CAP 128
-#ifndef K6_UNROLL2
-#define K6_UNROLL2 1
-#endif
 struct __attribute__((aligned(16))) FwdLds {
     Planes p;                           // 6768 B
     uint2 q[FQ_CAP];                    // 1024: dense-phase queue {w, key}
@@ -553,7 +541,6 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
                 }
             return false;
         };
-#if K6_UNROLL2
         // Two register sets, used and refilled alternately: set X holds the even entries, set Y the odd ones; while one is evaluated
         // the other is loaded (one iteration ahead), the list index two ahead.  (One set rotated through a "next" copy cost eight
         // 64-bit register moves per iteration: a fifth of the loop's VALU instructions.)
@@ -571,20 +558,6 @@ k_render_fwd(PixArgs a, float* __restrict__ out_color, float* __restrict__ out_d
             jy = mylist[min(t + 3, 63)];
             if (test_one(yA, yB, yC, j1)) break;
         }
-#else
-        int cj = mylist[0], nj = mylist[1], nnj = mylist[2];
-        float4 cA = L.p.A[cj], cB = L.p.B[cj], cC = L.p.C[cj];
-        float4 nA = L.p.A[nj], nB = L.p.B[nj], nC = L.p.C[nj];
-        for (int t = 0; t < tmax; ++t) {
-            const float4 A = cA, B = cB, Cc = cC;
-            const int j = cj;
-            cj = nj; cA = nA; cB = nB; cC = nC;
-            nj = nnj;
-            nA = L.p.A[nj]; nB = L.p.B[nj]; nC = L.p.C[nj];
-            nnj = mylist[min(t + 3, 63)];
-            if (test_one(A, B, Cc, j)) break;
-        }
-#endif
         // items reference this chunk's LDS planes: start them before the next chunk is loaded
         if (qtail - qhead > 0) {
             __builtin_amdgcn_wave_barrier();
@@ -672,21 +645,13 @@ __device__ __forceinline__ void scatter_direct(float* __restrict__ dtex, uint32_
 // inf / NaN survive the rounding (an inf / NaN upstream gradient still reaches exactly the texels it touches).
 struct __attribute__((aligned(16))) Rec4 { uint32_t a, b, c, d; };
 __device__ __forceinline__ void rec_store(uint32_t* __restrict__ base, uint32_t slot, const Rec4 r) {
-#if TG_NT
     tg_u4 v; v.x = r.a; v.y = r.b; v.z = r.c; v.w = r.d;
     __builtin_nontemporal_store(v, reinterpret_cast<tg_u4*>(base) + slot);
-#else
-    reinterpret_cast<Rec4*>(base)[slot] = r;
-#endif
 }
 __device__ __forceinline__ Rec4 rec_load(const Rec4* __restrict__ p) {
-#if TG_NT
     const tg_u4 v = __builtin_nontemporal_load(reinterpret_cast<const tg_u4*>(p));
     Rec4 r; r.a = v.x; r.b = v.y; r.c = v.z; r.d = v.w;
     return r;
-#else
-    return *p;
-#endif
 }
 __device__ __forceinline__ uint32_t rec_word0(float fx, float fy, uint32_t& hi) {
     const uint32_t qx = min((uint32_t)(fx * 262144.0f + 0.5f), 262143u), qy = min((uint32_t)(fy * 262144.0f + 0.5f), 262143u);
@@ -727,29 +692,22 @@ __device__ __forceinline__ RecVal rec_unpack(const Rec4 w) {
 #define K7_TRACE_BLOCKS 32768
 __device__ unsigned long long k7_trace[4 * K7_TRACE_BLOCKS];
 #endif
-#ifndef K7_OCC_PREFETCH
-#define K7_OCC_PREFETCH 0
-#endif
 namespace k7_occ {
 #define BQ_CAP 64
 #define K7_GATHER 1
 #define K7_WAVES_PER_SIMD 4
-#define K7_PREFETCH K7_OCC_PREFETCH
 #include "render_bwd_body.h"
 #undef BQ_CAP
 #undef K7_GATHER
 #undef K7_WAVES_PER_SIMD
-#undef K7_PREFETCH
 }  // namespace k7_occ
 namespace k7_lds {
 #define BQ_CAP 128
 #define K7_GATHER 0
-#define K7_PREFETCH 0
 #define K7_WAVES_PER_SIMD 2
 #include "render_bwd_body.h"
 #undef BQ_CAP
 #undef K7_GATHER
-#undef K7_PREFETCH
 #undef K7_WAVES_PER_SIMD
 }  // namespace k7_lds
 // K7 over K6's item stream (texgs.h v15): the flavours with the per-Gaussian stages.  Same registers-per-wave target as k7_occ.

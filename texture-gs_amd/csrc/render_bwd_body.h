@@ -15,9 +15,6 @@ struct __attribute__((aligned(16))) BwdLds {      // bytes: configuration lds (B
     uint32_t task[64];                  //  256
     uint8_t list[4][64];                //  256
     uint32_t tpos[TG_RESV], tend[TG_RESV];   // 512: the block's reservations: next free record (absolute), end of the range (the bins: p.B[].w)
-#ifdef K7_LDS_PAD
-    char pad_[K7_LDS_PAD];                     // experiment builds: fewer waves per CU
-#endif
 };                                      // 18080 B -> 9 waves per CU / 9296 B -> 16 waves per CU (17 by LDS; the registers are held to 4 per SIMD)
 
 // What a caller wants decides what is compiled in (TexGSGrads.want, texgs.h):
@@ -138,24 +135,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
     };
     uint32_t cid = 0u;                                    // lane = survivor of the current chunk: its Gaussian id
     (void)cid;
-#if K7_GATHER && K7_PREFETCH
-    // The shading records of the NEXT segment's items, gathered one segment ahead: issued right after stage A has produced the
-    // segment's items, they travel while the current segment's back half and stage C run (the gathers miss the L2 more often than
-    // not -- 0.5 GB of K7's fetch traffic -- and front_b cannot start the taps before they are here).  18 registers per lane.
-    struct Pre { float4 sd, se, sf, s3; float2 s4; };
-    Pre pre;
-    pre.sd = pre.se = pre.sf = pre.s3 = make_float4(0.f, 0.f, 0.f, 0.f); pre.s4 = make_float2(0.f, 0.f);
-    auto prefetch = [&](int n_items) {
-        static_assert(BQ_CAP <= 64, "one round per segment");
-        uint32_t key = 0u;
-        if (lane < n_items) key = __float_as_uint(L.abuf[lane].w);
-        const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(KEY_J(key) << 2, (int)cid);
-        if constexpr (TAPS) { pre.sd = sp[0]; pre.se = sp[1]; }
-        pre.sf = sp[2];
-        pre.s3 = sp[3];
-        pre.s4 = *reinterpret_cast<const float2*>(sp + 4);
-    };
-#endif
     // front half, part A: the item, and (K7_GATHER) the loads of its Gaussian's shading record.  Part A of EVERY round of the segment
     // runs before any part B: vmcnt retires in order, a record load issued behind another round's taps would wait for those taps.
     auto front_a = [&](int rbase, Round& R, int n_items) {
@@ -171,13 +150,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         R.jj = KEY_J(R.key);
         R.w = fminf(TG_ALPHA_MAX, it.z) * it.x;
 #if K7_GATHER
-#if K7_PREFETCH
-        // (the record was gathered while the previous segment's back half and stage C ran: `pre`)
-        if constexpr (TAPS) { R.sd = pre.sd; R.se = pre.se; }
-        R.sf = pre.sf;
-        R.vd1 = pre.s3.x; R.vd2 = pre.s3.y;
-        R.c5 = make_float4(pre.s3.z, pre.s3.w, pre.s4.x, pre.s4.y);
-#else
         // the shading record of the item's Gaussian from global memory (an L2 hit; lanes of one task read the same 80 bytes)
         const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)(uint32_t)__builtin_amdgcn_ds_bpermute(R.jj << 2, (int)cid);
         if constexpr (TAPS) { R.sd = sp[0]; R.se = sp[1]; }
@@ -186,7 +158,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         const float2 s4 = *reinterpret_cast<const float2*>(sp + 4);
         R.vd1 = s3.x; R.vd2 = s3.y;
         R.c5 = make_float4(s3.z, s3.w, s4.x, s4.y);
-#endif
 #endif
     };
     auto front_b = [&](Round& R) {
@@ -517,10 +488,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
         static_assert(BQ_CAP <= 192, "item indices travel in 8 bits (task words), and index BQ_CAP is the all-zero item");
         Seg nxt;
         stage_a(nxt);
-#if K7_GATHER && K7_PREFETCH
-        __builtin_amdgcn_wave_barrier();
-        prefetch(nxt.n_items);
-#endif
         while (nxt.n_items > 0) {
             const Seg cur = nxt;
             __builtin_amdgcn_wave_barrier();
@@ -543,10 +510,6 @@ k_render_bwd(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T, const 
             nxt.n_items = 0; nxt.n_it = 0;
             if (t < tmax) {
                 stage_a(nxt);
-#if K7_GATHER && K7_PREFETCH
-                __builtin_amdgcn_wave_barrier();
-                prefetch(nxt.n_items);
-#endif
             }
             // ================================================================ stage B, back halves
 #pragma unroll

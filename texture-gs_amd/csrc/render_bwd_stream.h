@@ -24,9 +24,6 @@ struct __attribute__((aligned(16))) StreamLds {
     uint32_t task[64];                 //  256: first item | items << 8
     uint32_t rbin[TG_RESV], tpos[TG_RESV], tend[TG_RESV];   // 768: the block's record-list reservations {bin, next free, end}
     uint8_t itf[64];                   //   64: first item of each pseudo-iteration
-#ifdef K7S_LDS_PAD
-    char pad_[K7S_LDS_PAD];                     // experiment builds: fewer waves per CU
-#endif
 };                                     // 7288 B
 
 template <bool TEX, bool UVG, bool TAPS>
@@ -125,11 +122,7 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
         R.pl = (int)(R.key & 63u);
         R.w = fminf(TG_ALPHA_MAX, R.araw) * R.T;
         // the shading record of the item's Gaussian (lanes of one task read the same 80 bytes; a lane without an item reads Gaussian 0)
-#ifdef K7S_ABL_GATHER0
-        const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)((R.key >> 6) & 255u);      // ablation: every record an L1 / L2 hit
-#else
         const float4* __restrict__ sp = a.rec_shade + (TEXGS_REC_SHADE_FLOATS / 4) * (size_t)(R.key >> 6);
-#endif
         float4 sd = make_float4(0.f, 0.f, 0.f, 0.f), se = sd;
         if constexpr (TAPS) { sd = sp[0]; se = sp[1]; }
         const float4 sf = sp[2];
@@ -146,16 +139,8 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
             R.inv = (den >= TG_DEN_MIN) ? __builtin_amdgcn_rcpf(den) : 0.0f;
             R.nu0 = sd.z * dpx + sd.w * dpy; R.nu1 = se.x * dpx + se.y * dpy; R.nu2 = se.z * dpx + se.w * dpy;
             const CubeTap ct = cube_address(sf.x + R.nu0 * R.inv, sf.y + R.nu1 * R.inv, sf.z + R.nu2 * R.inv, a.R);
-#ifdef K7S_ABL_TAP0
-            {   // ablation: every tap an L1 / L2 hit (same instruction count)
-                const uint32_t o_ = ct.o00 & 0xFFFu;
-                R.t00 = load_texel(tex, o_); R.t01 = load_texel(tex, o_ + ct.dox);
-                R.t10 = load_texel(tex, o_ + (ct.doy ? 4096u : 0u)); R.t11 = load_texel(tex, o_ + (ct.doy ? 4096u : 0u) + ct.dox);
-            }
-#else
             R.t00 = load_texel(tex, ct.o00); R.t01 = load_texel(tex, ct.o00 + ct.dox);
             R.t10 = load_texel(tex, ct.o00 + ct.doy); R.t11 = load_texel(tex, ct.o00 + ct.doy + ct.dox);
-#endif
             R.fx = ct.fx; R.fy = ct.fy;
             if constexpr (UVG) {
                 R.axis = ct.axis;
@@ -271,15 +256,11 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
                 const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ldr, (int)R.ovf1);
                 if (ovf) { const uint32_t pos = p0 + (slot & 63u); slot = (pos < p1) ? pos : TG_SLOT_NONE; }
             }
-#ifdef K7S_ABL_NOREC
-            if (slot == 0x12345678u && x0 == 17.f) tb.rec[0] = x1 + x2 + __uint_as_float(R.fxw ^ R.fyw);      // ablation: no record stores
-#else
             if (slot < tb.cap) {
                 rec_store(tb.rec, slot, rec_pack(R.fxw, R.fyw >> 10, (int)(R.fyw & 31u), (int)((R.fyw >> 5) & 31u), x0, x1, x2));
             } else if (R.have && (x0 != 0.f || x1 != 0.f || x2 != 0.f)) {
                 scatter_direct(dtex, R.o00, R.dox, R.doy, R.fx, R.fy, x0, x1, x2);
             }
-#endif
         }
     };
 
@@ -344,11 +325,7 @@ k_render_bwd_stream(PixArgs a, TexBinArgs tb, const float* __restrict__ final_T,
                 float lo, hi;
                 static_assert(M_N + 3 == 28, "the live-slot masks cover slots 0..27");
                 reduce32_rows16_masked<UVG ? TG_MOMENTS_ALL : TG_MOMENTS_NOUV>(part, lane, lo, hi);
-#ifdef K7S_ABL_NOACC
-                if (live && lo == 12345.f && hi == 54321.f) {           // ablation: no accumulator atomics
-#else
                 if (live) {
-#endif
                     float* row = acc + (size_t)gid * TEXGS_ACC_FLOATS + transposed_index(sub);
                     if (lo != 0.f) unsafeAtomicAdd(row, lo);
                     if (hi != 0.f) unsafeAtomicAdd(row + 16, hi);
