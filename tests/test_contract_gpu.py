@@ -241,6 +241,20 @@ def test_c4_one_rank_rccl_group_allreduce(lib_built):
         torch.cuda.synchronize()
         assert torch.allclose(b.flat, before / 4.0)
         assert p[0].grad.data_ptr() == b.flat.data_ptr()
+        # the asynchronous segments on the side stream under RCCL itself (one rank: a sum over one term): f32 segments come back bit for
+        # bit, a segment sent as bf16 (the wire-size lever, texgs.multiview) comes back as its bf16 rounding; the timed collectives report
+        # their WIRE bytes
+        ref = torch.randn_like(b.flat)
+        b.flat.copy_(ref)
+        seg0, seg1 = b.segment_of([p[0]]), b.segment_of([p[1]])
+        b.all_reduce_async(dist, seg1, timing=True)
+        b.all_reduce_async(dist, seg0, timing=True, wire_dtype=torch.bfloat16)
+        out = b.wait().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out[seg1[0]:seg1[0] + seg1[1]], ref[seg1[0]:seg1[0] + seg1[1]])
+        assert torch.equal(out[seg0[0]:seg0[0] + seg0[1]], ref[seg0[0]:seg0[0] + seg0[1]].to(torch.bfloat16).float())
+        tm = b.comm_timings()
+        assert [t[0] for t in tm] == [seg1[1] * 4, seg0[1] * 2] and all(t[1] >= 0.0 for t in tm)
     finally:
         dist.destroy_process_group()
 
