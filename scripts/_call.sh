@@ -1,2 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_contract_gpu.py -m gpu -q -p no:cacheprovider -k "rccl" 2>&1 | grep -E "passed|failed|^E  |FAILED|Error" | head
+mkdir -p gpurun_out
+timeout 300 python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err
+python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/bench_c3.json").read().splitlines() if l.startswith("{")][-1])
+print("final", j["value"], j["value_long"], j["ms_per_step_percentiles"], j["build_id"], (j["reference_call_pattern"] or {}).get("views_per_s"), (j.get("roofline") or {}).get("traffic"))
+PY

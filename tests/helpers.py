@@ -222,7 +222,7 @@ def forward_attributed(label, got8, ref, margin, tol=1e-4, depth_tol=4e-4, n_con
     return res
 
 
-def grad_attributed(label, got, exp, flagged, row_rtol=1e-3, row_atol_frac=1e-4, flagged_frac_max=0.7, clean_rel=1e-3,
+def grad_attributed(label, got, exp, flagged, row_rtol=1e-3, row_atol_frac=1e-4, flagged_frac_max=0.5, clean_rel=1e-3,
                     flagged_outlier_frac_max=5e-3, flagged_err_max=0.5):
     """Every gradient row (Gaussian / texel) the C oracle did NOT flag must be within 1e-3 relative + 1e-4 of the largest entry:
     zero unexplained outliers, no budget.  Flagged rows (a bilinear cell / colour clamp / 1-in-255 decision within rounding of
