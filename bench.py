@@ -57,6 +57,9 @@ def parse():
                     help="skip the reference-call-pattern / reference-iteration / retexture legs after the timed region (A/B runs)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TEXGS_BENCH_STREAMS", "3")),
                     help="HIP streams the views of a step are pipelined over (texgs.multiview.ViewPipeline); 1 = serial")
+    ap.add_argument("--prefetch", type=int, default=int(os.environ.get("TEXGS_BENCH_PREFETCH", "1")), choices=[0, 1],
+                    help="1 = ViewPipeline.run begins every view's forward (K1 + the instance-count readback) one view per stream ahead "
+                         "(GaussianRasterizer.prefetch); 0 = every forward begins when it is called")
     ap.add_argument("--order", default=os.environ.get("TEXGS_BENCH_ORDER", "accumulate"), choices=["backward", "accumulate", "none"])
     ap.add_argument("--leg", default="operator", choices=["operator", "iteration"],
                     help="iteration = one training iteration of the reference's texture stage on this stack (UV map, two renders, the "
@@ -213,6 +216,11 @@ def main():
                           opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
                           uvs=leaves["uvs"], gradient_uvs=juv, texture=leaves["texture"], extra_attrs=None)
 
+    def view_prefetch(v):        # K1 + the instance-count readback of view v, begun ahead of the stream's pending backward
+        return rasters[v].prefetch(means3D=leaves["means3D"], means2D=means2D, shs=leaves["shs"],
+                                   opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                                   uvs=leaves["uvs"], gradient_uvs=juv, texture=leaves["texture"], extra_attrs=None)
+
     def view_bwd(out):
         torch.autograd.backward([out[0], out[3], out[2]], [g_img, g_alpha, g_norm])
 
@@ -256,7 +264,9 @@ def main():
         # the texture half of the bucket is all-reduced on a side stream as soon as the last view's texture-gradient reduce has been
         # issued (it overlaps that view's K8 and the host's end-of-step work); the per-Gaussian half after the last K8
         p.run(batch, view_fwd, view_bwd if with_bwd else None, sink=bucket, order=args.order,
-              texture_ready=(lambda evs: bucket.all_reduce_async(dist, seg_tex, after=evs, timing=True)) if two else None)
+              texture_ready=(lambda evs: bucket.all_reduce_async(dist, seg_tex, after=evs, timing=True)) if two else None,
+              prefetch_fn=view_prefetch if (args.prefetch and p.streams and not untextured) else None,
+              prefetch_ahead=int(os.environ.get("TEXGS_BENCH_PREFETCH_AHEAD", "1")))
         if rec is not None:
             ev[1].record()
         if with_bwd and dist is not None:
@@ -590,7 +600,9 @@ def main():
             "config": {"workload": f"{args.workload}: N={N} Gaussians, cubemap 6x{R}x{R}x3 f32, {W}x{H}, {mode}, sh_degree 3",
                        "views_per_step_per_gpu": args.views_per_step, "global_views_per_step": args.views_per_step * world,
                        "num_rendered_D": s.D, "D_eff": D_eff, "parallelism": f"views sharded dp{world}",
-                       "view_pipeline": f"{args.streams} HIP streams, order={args.order}" if args.streams > 1 else "serial",
+                       "view_pipeline": (f"{args.streams} HIP streams, order={args.order}"
+                                         + (", forwards begun one view per stream ahead" if (args.prefetch and not untextured) else ""))
+                       if args.streams > 1 else "serial",
                        "view_sharding": "LPT by per-view instance count D" if world > 1 else "all views on the one GPU",
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal)")
                                           + " SUM of one flat f32 bucket per step, as two segments on a side stream "

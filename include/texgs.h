@@ -253,6 +253,14 @@ int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32
  * existing lists and calls texgs_depth_sort_scan itself if the fingerprint turns out different. */
 int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, uint64_t* fingerprint_out,
                              int32_t sort_first, void* stream);
+/* The same readback in two steps (v15), for a caller that issues K1 of a later view early so that no forward ever waits for its own
+ * K1: texgs_num_rendered_begin copies K1's partial sums into the caller's PINNED host buffer (>= texgs_num_rendered_words(N) words)
+ * asynchronously on `stream` and, with sort_first, launches K2; the caller records an event behind it.  texgs_num_rendered_reduce --
+ * host only, after that event completed -- returns D and the geometry fingerprint. */
+size_t texgs_num_rendered_words(int32_t num_gaussians);
+int texgs_num_rendered_begin(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_pinned, size_t host_words, int32_t sort_first,
+                             void* stream);
+int texgs_num_rendered_reduce(const uint32_t* host_pinned, int32_t num_gaussians, uint32_t* host_out, uint64_t* fingerprint_out);
 /* K2 alone: depth sort of the Gaussians + exclusive scan of tiles_touched in depth-rank order (writes geom->offsets, scan_temp). */
 int texgs_depth_sort_scan(TexGSGeom* geom, int32_t num_gaussians, void* stream);
 

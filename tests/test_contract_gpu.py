@@ -176,8 +176,9 @@ def test_c4_semantics_two_virtual_ranks_equal_single_bucket(lib_built):
     assert rel < 1e-5, rel
 
 
-@pytest.mark.parametrize("depth,order", [(2, "backward"), (2, "accumulate"), (2, "none"), (3, "none"), (3, "accumulate")])
-def test_view_pipeline_streams_equal_serial(lib_built, depth, order):
+@pytest.mark.parametrize("depth,order,prefetch", [(2, "backward", False), (2, "accumulate", False), (2, "none", False), (3, "none", False),
+                                                  (3, "accumulate", False), (3, "accumulate", True), (2, "backward", True)])
+def test_view_pipeline_streams_equal_serial(lib_built, depth, order, prefetch):
     """texgs.multiview.ViewPipeline: the views of a step pipelined over HIP streams accumulate the same bucket as the
     serial loop (per-Gaussian sums: same K8 order in "backward"/"accumulate", a different association in "none"; the
     texture gradient and K7's moment sums go through atomics either way)."""
@@ -191,7 +192,9 @@ def test_view_pipeline_streams_equal_serial(lib_built, depth, order):
     target, nhat = target.to(dev), nhat.to(dev)
     sts = [Hh.settings_for(c, 3, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings) for c in cams]
 
-    def accumulate(pipe_depth, pipe_order, steps=2):
+    from texgs import rasterizer as RZ
+
+    def accumulate(pipe_depth, pipe_order, steps=2, pre=False):
         names, leaves = _leaves(scene, dev)
         m2 = torch.zeros(20000, 3, device=dev, requires_grad=True)
         bucket = GradBucket(leaves + [m2])
@@ -204,21 +207,83 @@ def test_view_pipeline_streams_equal_serial(lib_built, depth, order):
 
         def bwd(obj):
             obj[1].backward()
+
+        def pre_fn(v):          # (the forwards of a step begun one view per stream ahead: GaussianRasterizer.prefetch)
+            m3, shs, op, sc, rot, uv, tex = leaves
+            GaussianRasterizer(sts[v], grad_sink=bucket).prefetch(means3D=m3, means2D=m2, shs=shs, opacities=op, scales=sc, rotations=rot,
+                                                                  uvs=uv, gradient_uvs=juv, texture=tex)
         for _ in range(steps):                        # two steps: the replicas / scratch must come back clean
             bucket.zero()
-            res = pipe.run(range(7), fwd, bwd, sink=bucket, order=pipe_order)
+            res = pipe.run(range(7), fwd, bwd, sink=bucket, order=pipe_order, prefetch_fn=pre_fn if pre else None)
             torch.cuda.synchronize()
             images = [r[0][0].detach().clone() for r in res]
+            assert not any(RZ._PREFETCH.values()), "a begun forward was not picked up by its view"
         assert bucket.before_accumulate is None and bucket.active == 0
         return bucket.flat.double().clone(), images
     whole, img_s = accumulate(1, "backward")
-    got, img_p = accumulate(depth, order)
+    got, img_p = accumulate(depth, order, pre=prefetch)
     for a, b in zip(img_s, img_p):
         assert torch.equal(a, b), "forward images differ between the serial and the pipelined run"
     rel = float((whole - got).norm() / whole.norm())
-    Hh.report(f"view_pipeline/depth{depth}_{order}_vs_serial", rel_l2=rel, max_abs=float((whole - got).abs().max()),
+    Hh.report(f"view_pipeline/depth{depth}_{order}{'_prefetch' if prefetch else ''}_vs_serial", rel_l2=rel, max_abs=float((whole - got).abs().max()),
               grad_max=float(whole.abs().max()))
     assert rel < 1e-5, rel
+
+
+def test_forward_prefetch_is_the_same_forward(lib_built):
+    """GaussianRasterizer.prefetch begins a forward (K1 + the instance-count readback + K2); the same call through forward() finishes
+    it: bit-identical outputs and the same gradients as a forward that was never begun early, with other work (another view's forward
+    and backward) queued on the stream in between.  A begun forward whose inputs changed in between is not picked up."""
+    from texgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from texgs import rasterizer as RZ
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene(20000, 256, seed=7, scale_mean=0.012)
+    cams = synth.fibonacci_cameras(3, 400, 304)
+    juv = scene.gradient_uvs.to(dev)
+    sts = [Hh.settings_for(c, 3, torch.zeros(3), device=dev, cls=GaussianRasterizationSettings) for c in cams]
+    target, nhat = synth.make_targets(304, 400, seed=3)
+    target, nhat = target.to(dev), nhat.to(dev)
+
+    def run(pre):
+        names, leaves = _leaves(scene, dev)
+        m2 = torch.zeros(20000, 3, device=dev, requires_grad=True)
+        m3, shs, op, sc, rot, uv, tex = leaves
+        kw = dict(means3D=m3, means2D=m2, shs=shs, opacities=op, scales=sc, rotations=rot, uvs=uv, gradient_uvs=juv, texture=tex)
+        if pre:
+            GaussianRasterizer(sts[1]).prefetch(**kw)
+            assert sum(len(v) for v in RZ._PREFETCH.values()) == 1
+        out0 = _view(GaussianRasterizer, sts[0], leaves, m2, juv)               # another view in between, forward and backward
+        synth.synthetic_loss(out0[0], out0[3], out0[2], target, nhat).backward()
+        g0 = [l.grad.clone() for l in leaves]
+        for l in leaves:
+            l.grad = None
+        out1 = _view(GaussianRasterizer, sts[1], leaves, m2, juv)
+        assert not any(RZ._PREFETCH.values())
+        synth.synthetic_loss(out1[0], out1[3], out1[2], target, nhat).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out1[:5]], [l.grad.clone() for l in leaves], g0
+    outs_a, grads_a, g0_a = run(False)
+    outs_b, grads_b, g0_b = run(True)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    for n, a, b in zip(["means3D", "shs", "opacities", "scales", "rotations", "uvs", "texture"], grads_a, grads_b):
+        rel = float((a.double() - b.double()).norm() / a.double().norm())
+        assert rel < 1e-6, (n, rel)                      # (atomics order in K7's moment sums / the overflow path)
+    # inputs modified after the begin: the pending forward must not be used
+    names, leaves = _leaves(scene, dev)
+    m2 = torch.zeros(20000, 3, device=dev, requires_grad=True)
+    m3, shs, op, sc, rot, uv, tex = leaves
+    kw = dict(means3D=m3, means2D=m2, shs=shs, opacities=op, scales=sc, rotations=rot, uvs=uv, gradient_uvs=juv, texture=tex)
+    GaussianRasterizer(sts[2]).prefetch(**kw)
+    with torch.no_grad():
+        m3.mul_(1.01)
+    out = _view(GaussianRasterizer, sts[2], leaves, m2, juv)
+    assert sum(len(v) for v in RZ._PREFETCH.values()) == 1, "a stale begun forward was consumed"
+    with torch.no_grad():
+        ref = _view(GaussianRasterizer, sts[2], [l.detach() for l in leaves], m2.detach(), juv)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[4], ref[4])
+    RZ.release_scratch()
+    assert not RZ._PREFETCH
 
 
 def test_c4_one_rank_rccl_group_allreduce(lib_built):

@@ -170,6 +170,42 @@ int texgs_read_num_rendered2(const TexGSGeom* geom, int32_t num_gaussians, uint3
     return 0;
 }
 
+// The same readback in two steps, for a caller that issues K1 of a LATER view early (texgs.rasterizer forward prefetch): `begin` copies
+// K1's per-workgroup partial sums into the caller's PINNED host buffer asynchronously (and launches K2 with sort_first), the caller
+// records an event of its own behind it and goes on; `reduce` -- host only, after that event has completed -- adds them up.
+size_t texgs_num_rendered_words(int32_t num_gaussians) {
+    return num_gaussians <= 0 ? 0 : 3 * (((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK);
+}
+int texgs_num_rendered_begin(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_pinned, size_t host_words, int32_t sort_first,
+                             void* stream) {
+    if (!geom || !host_pinned) return fail_msg("NULL argument");
+    if (num_gaussians <= 0) return 0;
+    const size_t nw = texgs_num_rendered_words(num_gaussians);
+    if (host_words < nw) return fail_msg("host buffer too small (texgs_num_rendered_words)");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(host_pinned, bin_block_sums_ptr(geom, num_gaussians), nw * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return fail("num_rendered readback", e);
+    if (sort_first) {
+        TexGSFrame f0; memset(&f0, 0, sizeof(f0)); f0.num_gaussians = num_gaussians;
+        if (int r = depth_sort_scan(&f0, const_cast<TexGSGeom*>(geom), s)) return r;
+    }
+    return 0;
+}
+int texgs_num_rendered_reduce(const uint32_t* host_pinned, int32_t num_gaussians, uint32_t* host_out, uint64_t* fingerprint_out) {
+    if (!host_pinned || !host_out) return fail_msg("NULL argument");
+    *host_out = 0;
+    if (fingerprint_out) *fingerprint_out = 0;
+    if (num_gaussians <= 0) return 0;
+    const size_t nblk = ((size_t)num_gaussians + TG_BLOCK - 1) / TG_BLOCK;
+    unsigned long long total = 0ull;
+    uint32_t fa = 0u, fb = 0u;
+    for (size_t k = 0; k < nblk; ++k) { total += host_pinned[k]; fa += host_pinned[nblk + k]; fb += host_pinned[2 * nblk + k]; }
+    if (total > 0xFFFFFFFFull) return fail_msg("num_rendered exceeds 2^32 - 1 instances");
+    *host_out = (uint32_t)total;
+    if (fingerprint_out) *fingerprint_out = ((uint64_t)fb << 32) | (uint64_t)fa;
+    return 0;
+}
+
 int texgs_read_num_rendered(const TexGSGeom* geom, int32_t num_gaussians, uint32_t* host_out, void* stream) {
     return texgs_read_num_rendered2(geom, num_gaussians, host_out, nullptr, 1, stream);
 }

@@ -72,7 +72,7 @@ class UVNetGradStruct(C.Structure):
 
 
 EXPORTS = ["texgs_abi_version", "texgs_build_id", "texgs_last_error", "texgs_scan_temp_bytes", "texgs_sort_temp_bytes",
-           "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_read_num_rendered2", "texgs_depth_sort_scan", "texgs_bin_sort_render_forward",
+           "texgs_preprocess_forward", "texgs_read_num_rendered", "texgs_read_num_rendered2", "texgs_num_rendered_words", "texgs_num_rendered_begin", "texgs_num_rendered_reduce", "texgs_depth_sort_scan", "texgs_bin_sort_render_forward",
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
            "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
            "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_norm_from_depth", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes", "texgs_uv_pack", "texgs_uv_taylor_packed",
@@ -106,6 +106,12 @@ def load():
     lib.texgs_read_num_rendered.argtypes = [P(Geom), C.c_int32, P(C.c_uint32), C.c_void_p]
     lib.texgs_read_num_rendered2.argtypes = [P(Geom), C.c_int32, P(C.c_uint32), P(C.c_uint64), C.c_int32, C.c_void_p]
     lib.texgs_read_num_rendered2.restype = C.c_int
+    lib.texgs_num_rendered_words.argtypes = [C.c_int32]
+    lib.texgs_num_rendered_words.restype = C.c_size_t
+    lib.texgs_num_rendered_begin.argtypes = [P(Geom), C.c_int32, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
+    lib.texgs_num_rendered_begin.restype = C.c_int
+    lib.texgs_num_rendered_reduce.argtypes = [C.c_void_p, C.c_int32, P(C.c_uint32), P(C.c_uint64)]
+    lib.texgs_num_rendered_reduce.restype = C.c_int
     lib.texgs_depth_sort_scan.argtypes = [P(Geom), C.c_int32, C.c_void_p]
     lib.texgs_depth_sort_scan.restype = C.c_int
     lib.texgs_bin_sort_render_forward.argtypes = [P(Frame), P(Inputs), P(Geom), P(Binning), P(Image), C.c_void_p]

@@ -262,8 +262,15 @@ class ViewPipeline:
         except Exception:
             pass
 
-    def run(self, views, forward_fn, backward_fn=None, sink=None, order="accumulate", texture_ready=None):
-        """`texture_ready(events)` (optional, needs a GradBucket sink and order="accumulate"): called ONCE, from inside the last
+    def run(self, views, forward_fn, backward_fn=None, sink=None, order="accumulate", texture_ready=None, prefetch_fn=None,
+            prefetch_ahead=1):
+        """`prefetch_fn(view)` (optional; e.g. GaussianRasterizer.prefetch with the arguments forward_fn will use): begins the forward
+        of the view this stream renders NEXT -- K1 and the instance-count readback -- right after the current view's forward and
+        BEFORE its backward is queued, so that the next forward on this stream does not wait for that backward (the first view of every
+        stream is begun before the loop).  The host then runs up to one view per stream ahead of the device instead of none, which is
+        what keeps the queues full when a host thread is descheduled for a few milliseconds.
+
+        `texture_ready(events)` (optional, needs a GradBucket sink and order="accumulate"): called ONCE, from inside the last
         view's backward, between its K7 + texture-gradient reduce and its K8 -- the point where every view's contribution to
         dL/dtexture has been issued; `events` = one event per stream, recorded after that stream's latest K7 + reduce.  The caller
         starts the texture segment's all-reduce there (GradBucket.all_reduce_async(..., after=events)).
@@ -277,6 +284,8 @@ class ViewPipeline:
         if not self.streams:                       # depth 1: the caller's stream, nothing to order
             for i, v in enumerate(views):
                 obj = forward_fn(v)
+                if prefetch_fn is not None and i + 1 < len(views):
+                    prefetch_fn(views[i + 1])
                 if backward_fn is not None:
                     if texture_ready is not None and sink is not None and i == len(views) - 1:
                         sink.before_accumulate = lambda: texture_ready([])
@@ -296,14 +305,22 @@ class ViewPipeline:
             s.wait_stream(cur)
         prev_bwd = None
         render_done = {}                            # stream index -> event after that stream's latest K7 + texture-gradient reduce
+        depth = len(self.streams)
         try:
+            ahead = depth * max(1, int(prefetch_ahead))     # (views; prefetch_ahead = forwards begun ahead PER STREAM)
+            if prefetch_fn is not None:
+                for i, v in enumerate(views[:ahead]):
+                    with torch.cuda.stream(self.streams[i % depth]):
+                        prefetch_fn(v)
             for i, v in enumerate(views):
-                k = i % len(self.streams)
+                k = i % depth
                 s = self.streams[k]
                 with torch.cuda.stream(s):
                     if order == "none":
                         sink.select(k)
                     obj = forward_fn(v)
+                    if prefetch_fn is not None and i + ahead < len(views):
+                        prefetch_fn(views[i + ahead])
                     if backward_fn is not None:
                         if order == "backward" and prev_bwd is not None:
                             s.wait_event(prev_bwd)

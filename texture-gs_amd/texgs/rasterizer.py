@@ -165,7 +165,7 @@ class _StreamScratch:
 
 def release_scratch(device=None, stream=None):
     """Free the backward scratch and the shared-geometry entry cached for (device, stream); None = every device / stream."""
-    for cache in (_SCRATCH, _GEOM, _ITEM_STAT):
+    for cache in (_SCRATCH, _GEOM, _ITEM_STAT, _PREFETCH):
         for key in list(cache):
             if (device is None or key[0] == torch.device(device).index) and (stream is None or key[1] == int(stream)):
                 del cache[key]
@@ -274,8 +274,63 @@ def _make_frame(st: GaussianRasterizationSettings, N, K, R, device, keep):
     return f
 
 
+# ---- forward prefetch: K1 (+ the D readback, + K2) of a LATER view issued early ---------------------------------------------------
+# A forward waits once for the device: D, the instance count that sizes K3..K6's launches.  On a stream that runs its views in order,
+# that wait is for everything the stream still has queued -- the previous view's whole backward.  With a few views pipelined over a
+# few streams the GPU stays busy meanwhile, but the host is then never more than a view or two ahead of the device: any host thread
+# stall of a few milliseconds (a neighbour process on the box's cores) drains the queue.  prefetch_forward issues K1 and the readback
+# of a view AHEAD of the backward that is about to be queued on the same stream; when that view's forward is called, with the same
+# tensors (same storage, same version counters) and settings, its D arrived long ago and nothing waits.  One pending forward per key;
+# a forward that does not match anything pending runs as usual.
+_PREFETCH = {}             # (device index, stream) -> [(key, finish closure)]
+_PIN_POOL = {}             # words -> [pinned int32 tensors]
+
+
+def _pin_take(words):
+    pool = _PIN_POOL.setdefault(words, [])
+    return pool.pop() if pool else torch.empty(max(words, 1), dtype=torch.int32).pin_memory()
+
+
+def _pin_give(t):
+    pool = _PIN_POOL.setdefault(t.numel(), [])
+    if len(pool) < 16:
+        pool.append(t)
+
+
+def _prefetch_key(st, tensors, flags):
+    t = lambda x: None if x is None else (x.data_ptr(), x._version, tuple(x.shape), x.requires_grad)
+    return (int(st.image_height), int(st.image_width), float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier), int(st.sh_degree),
+            bool(st.debug), t(st.bg), t(st.viewmatrix), t(st.projmatrix), t(st.campos)) + tuple(t(x) for x in tensors) + tuple(flags)
+
+
+def _prefetch_take(device, key):
+    lst = _PREFETCH.get((device.index, int(torch.cuda.current_stream(device).cuda_stream)))
+    if not lst:
+        return None
+    for k, (key_k, fin) in enumerate(lst):
+        if key_k == key:
+            del lst[k]
+            return fin
+    return None
+
+
+def prefetch_forward(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None,
+                     for_backward=True, cov3D_precomp=None, count_bins=None, lazy=False, want_items=None):
+    """Begin a forward now -- K1, the asynchronous D readback, K2 -- on the current stream; a later forward_raw / GaussianRasterizer
+    call on this stream with the same arguments (same tensor storages and versions, same settings, same flags) finishes it without
+    waiting for the device.  At most four forwards are kept pending per stream (older ones are dropped: their K1 was wasted, nothing
+    else).  Returns nothing."""
+    fin = forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, for_backward,
+                      cov3D_precomp, count_bins, lazy, want_items, _begin_only=True)
+    key = _prefetch_key(st, (means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, cov3D_precomp),
+                        (for_backward, count_bins, lazy, want_items))
+    lst = _PREFETCH.setdefault((means3D.device.index, int(torch.cuda.current_stream(means3D.device).cuda_stream)), [])
+    lst.append((key, fin))
+    del lst[:-4]
+
+
 def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset=None,
-                for_backward=True, cov3D_precomp=None, count_bins=None, lazy=False, want_items=None):
+                for_backward=True, cov3D_precomp=None, count_bins=None, lazy=False, want_items=None, _begin_only=False):
     """Run K1..K6.  Returns (outputs, state).  No autograd here.
 
     `lazy` (the autograd path sets it): the hand-off may be left to the backward (see LAZY_HANDOFF).
@@ -292,6 +347,11 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
     if device.type != "cuda":
         raise RuntimeError("the textured rasterizer runs on an AMD GPU (torch device 'cuda' = HIP); "
                            f"got tensors on {device}. There is no CPU fallback.")
+    if _PREFETCH and not _begin_only:        # was this very forward begun earlier (prefetch_forward)?  Then K1 ran long ago: finish it
+        pend = _prefetch_take(device, _prefetch_key(st, (means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture,
+                                                         color_offset, cov3D_precomp), (for_backward, count_bins, lazy, want_items)))
+        if pend is not None:
+            return pend()
     N = means3D.shape[0]
     means3D = _f32c(means3D, "means3D", device)
     if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -446,71 +506,90 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         binning = bin_ar = None
         if not candidate:
             binning, bin_ar = alloc_bin(cap, fix)
-        d_host, fp_host = C.c_uint32(0), C.c_uint64(0)
         _lib.check(lib.texgs_preprocess_forward(C.byref(frame), C.byref(inputs), C.byref(geom), stream), "texgs_preprocess_forward")
-        _lib.check(lib.texgs_read_num_rendered2(C.byref(geom), N, C.byref(d_host), C.byref(fp_host), 0 if candidate else 1, stream),
-                   "texgs_read_num_rendered")
-        D, fp = int(d_host.value), int(fp_host.value)
-        shared = None
-        if candidate and fp == entry.fingerprint and D == entry.D:
-            # same geometry as the forward that built `entry`: its lists are this forward's lists; K6 alone, no hand-off work
-            _GEOM_STATS["hits"] += 1
-            shared = entry
-            binning = _lib.Binning(D, *entry.bin)
-            _lib.check(lib.texgs_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning), C.byref(img),
-                                                stream), "texgs_render_forward")
-            if for_backward and entry.handoff and (entry.counts or not want_counts):
-                img.survivors, img.surv_qmask, img.surv_count = entry.handoff
-                img.tex_bin_count, img.tex_bin_resv = entry.counts if want_counts else (None, None)
-                if want_items and entry.items:      # T and alpha_raw of every pair are functions of the shared geometry too
-                    (img.item_pages, img.item_link, img.item_tail, img.item_ctl, img.item_page_cap, img.item_sub_pools) = entry.items
-            cap = entry.cap
-        else:
-            _GEOM_STATS["misses"] += 1
-            if candidate:           # expected to share, cannot: build the lists after all (K2 was not started before the sync)
-                binning, bin_ar = alloc_bin(max(cap, int(D * 1.25) + 1024), None)
-                cap = max(cap, int(D * 1.25) + 1024)
-                _lib.check(lib.texgs_depth_sort_scan(C.byref(geom), N, stream), "texgs_depth_sort_scan")
-            elif D > cap:           # rare: grow
-                cap = int(D * 1.25) + 1024
-                binning, bin_ar = alloc_bin(cap, fix)
-            binning.num_rendered = D
-            _lib.check(lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
-                                                         C.byref(img), stream), "texgs_bin_sort_render_forward")
-            _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
-            if istat is not None and img.item_ctl and not ITEM_PAGES_FIXED:
-                istat.watch(bin_ar.view("item_ctl"), hint_key, int(img.item_sub_pools), device)
-            if GEOM_CACHE:
-                e = _GeomEntry()
-                e.ints, e.cam_key, e.fingerprint, e.D, e.cap = gints, cam_key, fp, D, cap
-                e.bin = (binning.keys_unsorted, binning.keys_sorted, binning.point_list, binning.ranges, binning.tile_order,
-                         binning.sort_temp, binning.sort_temp_bytes)
-                e.arenas = (fix, bin_ar)
-                e.handoff = (img.survivors, img.surv_qmask, img.surv_count) if handoff else None
-                e.counts = (img.tex_bin_count, img.tex_bin_resv) if (handoff and img.tex_bin_count) else None
-                e.items = (img.item_pages, img.item_link, img.item_tail, img.item_ctl, int(img.item_page_cap),
-                           int(img.item_sub_pools)) if (handoff and img.item_pages) else None
-                _GEOM[gkey] = e
-    s = _State()
-    s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
-    s.N, s.K, s.R, s.H, s.W, s.D, s.cap, s.tiles = N, K, R, H, W, D, cap, tiles
-    s.want_counts, s.lazy, s.backward_ran, s.shared_geometry = want_counts, bool(lazy and for_backward), False, shared is not None
-    s.want_items = want_items
-    with _PRED_LOCK:
-        _SERIAL[0] += 1
-        s.serial = _SERIAL[0]
-    arenas = (fix,) + ((bin_ar,) if bin_ar is not None else ()) + (tuple(shared.arenas) if shared is not None else ())
-    # (NOT the output tensors: autograd hangs its node on them, the node holds this state -- a cycle that kept every dropped
-    #  graph's buffers alive until the garbage collector ran)
-    s.tensors = _Tensors(arenas, keep=keep, radii=radii)
-    if img.survivors is None:           # no hand-off in this state (forward-only call, lazy mode, or a shared entry without one)
-        s.tensors["survivors"] = None
-        s.tensors["surv_qmask"] = None
-        s.tensors["surv_count"] = None
-    if img.tex_bin_count is None:
-        s.tensors["tex_bin_count"] = None
-    s.tensors["for_backward"] = bool(for_backward)
-    return (out_color, out_depth, out_norm, out_alpha, radii), s
+        # the one device->host read of a forward (D and K1's geometry fingerprint), in two steps: the copy into pinned memory is issued
+        # here (with K2 behind it unless earlier lists are expected to be shared), the host waits for it in finish() -- immediately when
+        # this is an ordinary forward, or several views later when it was PREFETCHED (prefetch_forward: K1 of a later view issued ahead
+        # of this stream's pending backward, so that its forward never waits for the stream to drain)
+        pin = _pin_take(int(lib.texgs_num_rendered_words(N)))
+        _lib.check(lib.texgs_num_rendered_begin(C.byref(geom), N, pin.data_ptr(), pin.numel(), 0, stream), "texgs_num_rendered_begin")
+        d_ev = torch.cuda.Event()
+        d_ev.record(torch.cuda.current_stream(device))
+        if not candidate:           # K2 behind the event: the host waits for K1 + the copy only, the device goes on sorting
+            _lib.check(lib.texgs_depth_sort_scan(C.byref(geom), N, stream), "texgs_depth_sort_scan")
+
+    def finish():
+        nonlocal binning, bin_ar, cap
+        with torch.cuda.device(device):
+            d_ev.synchronize()
+            d_host, fp_host = C.c_uint32(0), C.c_uint64(0)
+            _lib.check(lib.texgs_num_rendered_reduce(pin.data_ptr(), N, C.byref(d_host), C.byref(fp_host)), "texgs_num_rendered_reduce")
+            _pin_give(pin)
+            D, fp = int(d_host.value), int(fp_host.value)
+            shared = None
+            if candidate and fp == entry.fingerprint and D == entry.D:
+                # same geometry as the forward that built `entry`: its lists are this forward's lists; K6 alone, no hand-off work
+                _GEOM_STATS["hits"] += 1
+                shared = entry
+                binning = _lib.Binning(D, *entry.bin)
+                _lib.check(lib.texgs_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning), C.byref(img),
+                                                    stream), "texgs_render_forward")
+                if for_backward and entry.handoff and (entry.counts or not want_counts):
+                    img.survivors, img.surv_qmask, img.surv_count = entry.handoff
+                    img.tex_bin_count, img.tex_bin_resv = entry.counts if want_counts else (None, None)
+                    if want_items and entry.items:      # T and alpha_raw of every pair are functions of the shared geometry too
+                        (img.item_pages, img.item_link, img.item_tail, img.item_ctl, img.item_page_cap, img.item_sub_pools) = entry.items
+                cap = entry.cap
+            else:
+                _GEOM_STATS["misses"] += 1
+                if candidate:           # expected to share, cannot: build the lists after all (K2 was not started before the sync)
+                    binning, bin_ar = alloc_bin(max(cap, int(D * 1.25) + 1024), None)
+                    cap = max(cap, int(D * 1.25) + 1024)
+                    _lib.check(lib.texgs_depth_sort_scan(C.byref(geom), N, stream), "texgs_depth_sort_scan")
+                elif D > cap:           # rare: grow
+                    cap = int(D * 1.25) + 1024
+                    binning, bin_ar = alloc_bin(cap, fix)
+                binning.num_rendered = D
+                _lib.check(lib.texgs_bin_sort_render_forward(C.byref(frame), C.byref(inputs), C.byref(geom), C.byref(binning),
+                                                             C.byref(img), stream), "texgs_bin_sort_render_forward")
+                _CAPACITY_HINT[hint_key] = max(_CAPACITY_HINT.get(hint_key, 0), int(D * 1.25) + 1024)
+                if istat is not None and img.item_ctl and not ITEM_PAGES_FIXED:
+                    istat.watch(bin_ar.view("item_ctl"), hint_key, int(img.item_sub_pools), device)
+                if GEOM_CACHE:
+                    e = _GeomEntry()
+                    e.ints, e.cam_key, e.fingerprint, e.D, e.cap = gints, cam_key, fp, D, cap
+                    e.bin = (binning.keys_unsorted, binning.keys_sorted, binning.point_list, binning.ranges, binning.tile_order,
+                             binning.sort_temp, binning.sort_temp_bytes)
+                    e.arenas = (fix, bin_ar)
+                    e.handoff = (img.survivors, img.surv_qmask, img.surv_count) if handoff else None
+                    e.counts = (img.tex_bin_count, img.tex_bin_resv) if (handoff and img.tex_bin_count) else None
+                    e.items = (img.item_pages, img.item_link, img.item_tail, img.item_ctl, int(img.item_page_cap),
+                               int(img.item_sub_pools)) if (handoff and img.item_pages) else None
+                    _GEOM[gkey] = e
+        s = _State()
+        s.frame, s.inputs, s.geom, s.bin, s.img = frame, inputs, geom, binning, img
+        s.N, s.K, s.R, s.H, s.W, s.D, s.cap, s.tiles = N, K, R, H, W, D, cap, tiles
+        s.want_counts, s.lazy, s.backward_ran, s.shared_geometry = want_counts, bool(lazy and for_backward), False, shared is not None
+        s.want_items = want_items
+        with _PRED_LOCK:
+            _SERIAL[0] += 1
+            s.serial = _SERIAL[0]
+        arenas = (fix,) + ((bin_ar,) if bin_ar is not None else ()) + (tuple(shared.arenas) if shared is not None else ())
+        # (NOT the output tensors: autograd hangs its node on them, the node holds this state -- a cycle that kept every dropped
+        #  graph's buffers alive until the garbage collector ran)
+        s.tensors = _Tensors(arenas, keep=keep, radii=radii)
+        if img.survivors is None:           # no hand-off in this state (forward-only call, lazy mode, or a shared entry without one)
+            s.tensors["survivors"] = None
+            s.tensors["surv_qmask"] = None
+            s.tensors["surv_count"] = None
+        if img.tex_bin_count is None:
+            s.tensors["tex_bin_count"] = None
+        s.tensors["for_backward"] = bool(for_backward)
+        return (out_color, out_depth, out_norm, out_alpha, radii), s
+
+    if _begin_only:
+        return finish
+    return finish()
 
 
 def _late_handoff(s: _State):
@@ -859,6 +938,18 @@ class GaussianRasterizer(nn.Module):
             _lib.check(lib.texgs_mark_visible(C.byref(frame), positions.data_ptr(), vis.data_ptr(), stream),
                        "texgs_mark_visible")
         return vis.bool()
+
+    def prefetch(self, means3D, means2D, opacities, shs=None, scales=None, rotations=None, uvs=None,
+                 gradient_uvs=None, texture=None, extra_attrs=None):
+        """Begin this forward now (K1 + the asynchronous instance-count readback + K2, on the current stream); the same call through
+        forward() later -- same tensors, unchanged in between, same settings tensors, same stream -- finishes it without waiting for
+        whatever the stream was given in the meantime (prefetch_forward).  Not part of the reference API; a no-op for its results."""
+        grad = torch.is_grad_enabled()
+        rg = lambda t: bool(grad and t is not None and t.requires_grad)
+        want_tex = rg(texture)
+        want_g = any(rg(t) for t in (means3D, means2D, shs, opacities, scales, rotations, uvs))
+        prefetch_forward(self.raster_settings, means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, None,
+                         for_backward=want_tex or want_g, cov3D_precomp=None, count_bins=want_tex, lazy=True, want_items=want_g)
 
     def forward(self, means3D, means2D, opacities, shs=None, scales=None, rotations=None, uvs=None,
                 gradient_uvs=None, texture=None, extra_attrs=None):
