@@ -394,6 +394,11 @@ typedef struct TexGSUVNetGrad {
 size_t texgs_uv_backward_temp_bytes(int32_t N);
 int texgs_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
                       void* stream);
+/* The same gradients with the six GEMMs of the backward chain (W^T d, d h^T) as split-bf16 products (three bf16 MFMAs per f32
+ * product, f32 accumulation: ~1e-5 relative); the forward recomputation stays on the f32-input MFMA, so the ReLU masks are those
+ * of the forward launch bit for bit (v15; same arguments and temp size). */
+int texgs_uv_backward_mixed(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
+                            void* stream);
 
 /* Hardware self-test of the wave64 cross-lane primitives the backward's reductions use (csrc/wave_ops.h: DPP lane^4 /
  * lane^8 exchanges, permlane16/32 swaps, both transposing butterflies).  seed: f32[128] device; out: f32[576] device,

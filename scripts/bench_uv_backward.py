@@ -21,14 +21,22 @@ for prec in ("fp32", "bf16x3", "mixed"):
     net = UVNet(precision=prec).to(dev)
     for _ in range(reps):
         net.uv_and_jacobian(xyz, emb)
-net = UVNet().to(dev)
 ev = lambda: torch.cuda.Event(enable_timing=True)
-net.backward_fused(xyz, emb, g)
-torch.cuda.synchronize()
-e0, e1 = ev(), ev()
-e0.record()
-for _ in range(reps):
-    net.backward_fused(xyz, emb, g)
-e1.record()
-torch.cuda.synchronize()
-print({"uv_backward_fused_us": round(1e3 * e0.elapsed_time(e1) / reps, 1), "N": N})
+out = {"N": N}
+grads = {}
+for prec in ("fp32", "mixed"):          # (the backward of "bf16x3" is the mixed one)
+    net = UVNet(precision=prec).to(dev)
+    torch.manual_seed(1)
+    for lin in net._linears():
+        torch.nn.init.normal_(lin.weight, std=0.1)
+    grads[prec] = net.backward_fused(xyz, emb, g)
+    torch.cuda.synchronize()
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(reps):
+        net.backward_fused(xyz, emb, g)
+    e1.record()
+    torch.cuda.synchronize()
+    out[f"uv_backward_{prec}_us"] = round(1e3 * e0.elapsed_time(e1) / reps, 1)
+out["mixed_vs_fp32_rel_l2"] = [round(float((a - b).double().norm() / b.double().norm()), 8) for a, b in zip(grads["mixed"], grads["fp32"])]
+print(out)

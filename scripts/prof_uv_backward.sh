@@ -20,7 +20,7 @@ for d in ("pmc1", "pmc2"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            for k in ("k_uv_taylor_bf16x3", "k_uv_taylor_mixed", "k_uv_taylor", "k_uv_backward_reduce", "k_uv_backward"):
+            for k in ("k_uv_taylor_bf16x3", "k_uv_taylor_mixed", "k_uv_taylor", "k_uv_backward_reduce", "k_uv_backward<true>", "k_uv_backward<false>", "k_uv_backward"):
                 if k in n:
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"])); break
         for k, cs in agg.items():

@@ -370,7 +370,8 @@ def test_fused_autograd_node_routes_gradients(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,bias,norm", [(1, True, False), (63, True, True), (64, False, False), (200, True, True), (16_385, False, True),
                                          (40_000, True, False)])
-def test_fused_backward_kernel_vs_float64(lib_built, n, bias, norm):
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+def test_fused_backward_kernel_vs_float64(lib_built, n, bias, norm, precision):
     """csrc/uvnet.hip k_uv_backward (+ its reduction) through UVNet.backward_fused against the plain-torch chain `uvnet_backward`
     in float64: every weight / bias gradient within 1e-4 relative L2 (fp32 MFMA, sums over up to 40 000 points in f32).  Sizes: a
     single point, one short of a tile, exactly one tile, a ragged tail, one point past 256 tiles (the persistent grid wraps: a
@@ -380,7 +381,7 @@ def test_fused_backward_kernel_vs_float64(lib_built, n, bias, norm):
     dev = torch.device("cuda:0")
     torch.manual_seed(11 + n)
     kw = dict(xyz_offset=[0.1, -0.2, 0.05], xyz_scale=[1.5, 0.8, 1.2]) if norm else {}
-    net = UVNet(precision="fp32", **kw)
+    net = UVNet(precision=precision, **kw)       # "mixed": the backward chain's six GEMMs as split-bf16 products (texgs_uv_backward_mixed)
     if not bias:
         with torch.no_grad():
             for lin in net._linears():
@@ -411,7 +412,7 @@ def test_fused_backward_kernel_vs_float64(lib_built, n, bias, norm):
         errs[f"W{k + 1}"] = Hh.rel_err(got[2 * k].cpu(), dW[k])
         errs[f"b{k + 1}"] = Hh.rel_err(got[2 * k + 1].cpu(), db[k])
     errs["emb"] = Hh.rel_err(got[3].cpu(), demb)
-    Hh.report(f"uv_backward/n{n}/bias{int(bias)}/norm{int(norm)}", **errs)
+    Hh.report(f"uv_backward/{precision}/n{n}/bias{int(bias)}/norm{int(norm)}", **errs)
     assert max(errs.values()) < 1e-4, errs
     # deterministic: partial sums are added in workgroup order, no atomics
     again = net.backward_fused(xyz.to(dev), emb.to(dev), g.to(dev))

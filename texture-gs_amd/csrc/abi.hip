@@ -466,14 +466,22 @@ int texgs_uv_taylor_packed_mixed(const TexGSUVNet* net, const void* packed, cons
 
 size_t texgs_uv_backward_temp_bytes(int32_t N) { return uv_backward_temp_bytes(N < 0 ? 0 : N); }
 
-int texgs_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
-                      void* stream) {
+static int uv_backward_impl(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
+                            int mixed, void* stream) {
     if (!net || !out || !temp) return fail_msg("NULL argument");
     if (int r = check_uvnet(net)) return r;
     if (N < 0) return fail_msg("N < 0");
     if (N > 0 && (!xyz || !g_uvs)) return fail_msg("NULL argument");
-    if (int r = launch_uv_backward(net, xyz, g_uvs, N, out, temp, (hipStream_t)stream)) return fail("uv_backward", (hipError_t)r);
+    if (int r = launch_uv_backward(net, xyz, g_uvs, N, out, temp, mixed, (hipStream_t)stream)) return fail("uv_backward", (hipError_t)r);
     return 0;
+}
+int texgs_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
+                      void* stream) {
+    return uv_backward_impl(net, xyz, g_uvs, N, out, temp, 0, stream);
+}
+int texgs_uv_backward_mixed(const TexGSUVNet* net, const float* xyz, const float* g_uvs, int32_t N, const TexGSUVNetGrad* out, void* temp,
+                            void* stream) {
+    return uv_backward_impl(net, xyz, g_uvs, N, out, temp, 1, stream);
 }
 
 int texgs_selftest_waveops(const float* seed128, float* out576, void* stream) {

@@ -89,5 +89,6 @@ int launch_uv_taylor_packed(const TexGSUVNet* net, const void* packed, const flo
 int launch_uv_taylor(const TexGSUVNet* net, const float* xyz, int N, float* uvs, float* grad_uvs, void* temp, hipStream_t s);
 int launch_uv_pack_bf16x3(const TexGSUVNet* net, void* packed, hipStream_t s);
 size_t uv_backward_temp_bytes(int N);
-int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, int N, const TexGSUVNetGrad* out, void* temp, hipStream_t s);
+int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, int N, const TexGSUVNetGrad* out, void* temp, int mixed,
+                       hipStream_t s);
 int launch_uv_taylor_packed_bf16x3(const TexGSUVNet* net, const void* packed, const float* xyz, int N, float* uvs, float* grad_uvs, hipStream_t s);

@@ -443,14 +443,31 @@ struct UVBwdArgs {
 // W2, W3, W4, W2^T, W3^T, W4^T in A-operand order, four k-steps per 16-byte load:
 //   pk4[m][band][g][lane] = (M_m[32 band + (lane & 31)][2 (4 g + j) + (lane >> 5)], j = 0..3),  M = W for m < 3, W^T for m >= 3
 __global__ void __launch_bounds__(256)
-k_uv_pack_bwd(const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ W4, float* __restrict__ pk) {
+k_uv_pack_bwd(const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ W4, float* __restrict__ pk, int n_mat) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 6 * 4 * 64 * 64) return;
+    if (idx >= n_mat * 4 * 64 * 64) return;
     const int j = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 15, band = (idx >> 12) & 3, m = idx >> 14;
     const int layer = m % 3;
     const float* W = layer == 0 ? W2 : (layer == 1 ? W3 : W4);
     const int r = band * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
     pk[idx] = m < 3 ? W[r * UV_H + k] : W[k * UV_H + r];
+}
+
+// The mixed backward's W2^T, W3^T, W4^T: the same 64 KB per matrix and 16 KB per wave slice, as split bf16 in the A-operand order of
+// mfma_f32_32x32x16_bf16 -- chunk (2 s + {0: hi, 1: lo}) of a slice holds lane l's M^T[32 band + (l & 31)][16 s + 8 (l >> 5) + j], j = 0..7
+__global__ void __launch_bounds__(256)
+k_uv_pack_bwd_b16(const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ W4, uint4* __restrict__ pkT) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * 4 * 8 * 64) return;
+    const int lane = idx & 63, s = (idx >> 6) & 7, band = (idx >> 9) & 3, layer = idx >> 11;
+    const float* W = layer == 0 ? W2 : (layer == 1 ? W3 : W4);
+    const int r = band * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 x, y; split_bf16(W[(k0 + j) * UV_H + r], x, y); h[j] = x; l[j] = y; }
+    uint4* o = pkT + ((size_t)((layer * 4 + band) * 16 + 2 * s)) * 64 + lane;
+    o[0] = __builtin_bit_cast(uint4, h);
+    o[64] = __builtin_bit_cast(uint4, l);
 }
 
 typedef float BwPlane[BW_PITCH];
@@ -489,6 +506,155 @@ __device__ __forceinline__ void bw_outer(const BwPlane* sD, const BwPlane* sH, i
     }
 }
 
+// ---- the mixed backward's forms of the two (round 6): the operands split into two bf16 each on the fly, three
+// v_mfma_f32_32x32x16_bf16 per f32 product (Ah Bh + Ah Bl + Al Bh, f32 accumulation: ~2^-17 relative, as in k_uv_taylor_bf16x3).  The
+// activation planes stay f32 and neuron-major in LDS (the forward recomputation needs them exact: its ReLU masks are the forward
+// launch's); a B operand -- eight consecutive k of one column -- is eight 4-byte reads, conflict-free at the 65-float pitch either way.
+// One wave per SIMD: nothing else hides an LDS round trip or fills the matrix pipe's shadow, and per MFMA (32 cycles of the pipe)
+// there are ~8 VALU instructions of conversion to place.  Left to the compiler, instruction selection sinks every read next to its
+// conversion (one exposed LDS round trip per pair of elements; scheduling fences only bind the machine scheduler that runs later):
+// so the reads are inline asm with hand-counted s_waitcnt, and both loops are software-pipelined three deep by hand -- a stage issues
+// the reads of step s + 2, the MFMAs of step s and, between them, the conversions of step s + 1 (read one stage ago).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bw_lds_addr(const void* p) { return (unsigned)(unsigned long long)p; }      // generic -> LDS byte offset
+template <int O0, int O1> __device__ __forceinline__ f32x2v bw_lds_rd2(unsigned addr) {                          // offsets in dwords, < 256
+    f32x2v v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+    return v;
+}
+// base + a compile-time constant, formed where it is used (left to the compiler, the 40 stage addresses of a tile are hoisted out of the
+// tile loop as invariants, spilled, and re-read from scratch in front of every group of reads)
+template <int OFF> __device__ __forceinline__ unsigned bw_addr_plus(unsigned base) {
+    unsigned a;
+    asm volatile("v_add_u32_e32 %0, %2, %1" : "=v"(a) : "v"(base), "n"(OFF));
+    return a;
+}
+#define BW_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ bf16x8 bw_a_frag(const float (&A)[64], int q) {
+    const f32x4v v = {A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// two consecutive k of one operand -> elements 2 i, 2 i + 1 of its high and low halves (round-to-nearest both: |x - hi - lo| <= 2^-16 |x|).
+// One wave per SIMD issues a VALU instruction every 8 clocks (v_cvt_pk_bf16_f32: 16; measured), so these five instructions per pair,
+// not the MFMAs, bound the loops below.  (A truncated high half -- v_perm instead of the first convert -- measured no faster and
+// doubles the error.)
+__device__ __forceinline__ void bw_split_pair(const f32x2v x, int i, bf16x8& h, bf16x8& l) {
+    __bf16 h0, l0, h1, l1;
+    split_bf16(x[0], h0, l0); split_bf16(x[1], h1, l1);
+    h[2 * i] = h0; h[2 * i + 1] = h1; l[2 * i] = l0; l[2 * i + 1] = l1;
+}
+#define BW_MF16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+// c[wave's 32 rows x 64 points] = M^T slice (split bf16, k_uv_pack_bwd_b16 order, in registers) x sIn[128][64]
+// reads of step S: x[tile][i] = {sIn[16 S + 8 bk + 2 i][bn + 32 tile], the row below}: one ds_read2 per pair of k
+template <int S> __device__ __forceinline__ void bw_gemm_ld(unsigned base, f32x2v (&u)[2][4]) {
+    const unsigned b0 = bw_addr_plus<16 * S * BW_PITCH * 4>(base), b1 = bw_addr_plus<(16 * S + 4) * BW_PITCH * 4>(base);
+    u[0][0] = bw_lds_rd2<0, BW_PITCH>(b0); u[0][1] = bw_lds_rd2<2 * BW_PITCH, 3 * BW_PITCH>(b0);
+    u[1][0] = bw_lds_rd2<32, BW_PITCH + 32>(b0); u[1][1] = bw_lds_rd2<2 * BW_PITCH + 32, 3 * BW_PITCH + 32>(b0);
+    u[0][2] = bw_lds_rd2<0, BW_PITCH>(b1); u[0][3] = bw_lds_rd2<2 * BW_PITCH, 3 * BW_PITCH>(b1);
+    u[1][2] = bw_lds_rd2<32, BW_PITCH + 32>(b1); u[1][3] = bw_lds_rd2<2 * BW_PITCH + 32, 3 * BW_PITCH + 32>(b1);
+}
+#define BW_WAIT8(N_, U_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(U_[0][0]), "+v"(U_[0][1]), "+v"(U_[0][2]), "+v"(U_[0][3]), \
+                                      "+v"(U_[1][0]), "+v"(U_[1][1]), "+v"(U_[1][2]), "+v"(U_[1][3]))
+template <int S> __device__ __forceinline__ void bw_gemm_stage(const float (&A)[64], unsigned base, f32x2v (&x)[3][2][4], bf16x8 (&hb)[2][2],
+                                                               bf16x8 (&lb)[2][2], f32x16& c0, f32x16& c1) {
+    constexpr int c = S & 1, n = (S + 1) % 3;
+    constexpr bool more = S + 1 < 8, load = S + 2 < 8;
+    const bf16x8 ah = bw_a_frag(A, 2 * S), al = bw_a_frag(A, 2 * S + 1);
+    auto cvt = [&](int i) { bw_split_pair(x[n][0][i], i, hb[c ^ 1][0], lb[c ^ 1][0]); bw_split_pair(x[n][1][i], i, hb[c ^ 1][1], lb[c ^ 1][1]); };
+    BW_FENCE();
+    if constexpr (load) bw_gemm_ld<S + 2 < 8 ? S + 2 : 0>(base, x[(S + 2) % 3]);
+    BW_FENCE();
+    BW_MF16(ah, hb[c][0], c0);
+    BW_FENCE();
+    if constexpr (more) {                   // the reads of step S + 1 have had a whole stage; only this stage's eight may be outstanding
+        if constexpr (load) BW_WAIT8(8, x[n]); else BW_WAIT8(0, x[n]);
+    }
+    BW_FENCE();
+    BW_MF16(ah, hb[c][1], c1);
+    BW_FENCE();
+    if constexpr (more) cvt(0);
+    BW_FENCE();
+    BW_MF16(ah, lb[c][0], c0);
+    BW_FENCE();
+    if constexpr (more) cvt(1);
+    BW_FENCE();
+    BW_MF16(ah, lb[c][1], c1);
+    BW_FENCE();
+    if constexpr (more) cvt(2);
+    BW_FENCE();
+    BW_MF16(al, hb[c][0], c0);
+    BW_FENCE();
+    if constexpr (more) cvt(3);
+    BW_FENCE();
+    BW_MF16(al, hb[c][1], c1);
+    if constexpr (more) bw_gemm_stage<more ? S + 1 : 0>(A, base, x, hb, lb, c0, c1);
+}
+__device__ __forceinline__ void bw_gemm_b16(const float (&A)[64], const BwPlane* sIn, int bn, int bk, f32x16& c0, f32x16& c1) {
+    static_assert(3 * BW_PITCH + 32 < 256, "ds_read2_b32 offsets are 8 bits");
+    f32x2v x[3][2][4];                      // [step % 3][tile][pair of k]
+    bf16x8 hb[2][2], lb[2][2];              // [step & 1][tile]
+    const unsigned base = bw_lds_addr(&sIn[8 * bk][bn]);
+    bw_gemm_ld<0>(base, x[0]); bw_gemm_ld<1>(base, x[1]);
+    BW_WAIT8(8, x[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bw_split_pair(x[0][0][i], i, hb[0][0], lb[0][0]); bw_split_pair(x[0][1][i], i, hb[0][1], lb[0][1]); }
+    bw_gemm_stage<0>(A, base, x, hb, lb, c0, c1);
+    BW_FENCE();
+}
+// dW[32 rows of this wave x 128] += sD[rows][64 points] x sH[128][64 points]^T, k = the point; a stage = (k-step sk, column block t)
+template <int OFF> __device__ __forceinline__ void bw_outer_ld(unsigned base, f32x2v (&u)[4]) {       // eight consecutive points as four pairs
+    const unsigned a = bw_addr_plus<OFF>(base);
+    u[0] = bw_lds_rd2<0, 1>(a); u[1] = bw_lds_rd2<2, 3>(a); u[2] = bw_lds_rd2<4, 5>(a); u[3] = bw_lds_rd2<6, 7>(a);
+}
+constexpr int BW_NS = (BW_P / 16) * 4;      // 16 stages, q = 4 sk + t
+constexpr int bw_b_off(int q) { return ((q & 3) * 32 * BW_PITCH + 16 * (q >> 2)) * 4; }
+template <int Q> __device__ __forceinline__ void bw_outer_stage(unsigned base_a, unsigned base_b, f32x2v (&xb)[3][4], f32x2v (&xa)[2][4],
+                                                                bf16x8 (&bh)[2], bf16x8 (&bl)[2], bf16x8 (&ah)[2], bf16x8 (&al)[2], f32x16 (&dW)[4]) {
+    constexpr int sk = Q >> 2, t = Q & 3, c = Q & 1, n = (Q + 1) % 3, an = (sk + 1) & 1;
+    constexpr bool more_a = sk + 1 < BW_P / 16, more = Q + 1 < BW_NS, load = Q + 2 < BW_NS;
+    BW_FENCE();
+    if constexpr (load) bw_outer_ld<bw_b_off(load ? Q + 2 : 0)>(base_b, xb[(Q + 2) % 3]);
+    if constexpr (t == 0 && more_a) bw_outer_ld<16 * (sk + 1) * 4>(base_a, xa[an]);       // the next k-step's rows of d: converted at t = 1, 2
+    BW_FENCE();
+    BW_MF16(ah[sk & 1], bh[c], dW[t]);
+    BW_FENCE();
+    if constexpr (more) {                   // the reads of the previous stage are done; this stage's four (+ four of d at t = 0) may be outstanding
+        if constexpr (!load) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[n][0]), "+v"(xb[n][1]), "+v"(xb[n][2]), "+v"(xb[n][3]));
+        else if constexpr (t == 0 && more_a) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xb[n][0]), "+v"(xb[n][1]), "+v"(xb[n][2]), "+v"(xb[n][3]));
+        else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xb[n][0]), "+v"(xb[n][1]), "+v"(xb[n][2]), "+v"(xb[n][3]),
+                          "+v"(xa[an][0]), "+v"(xa[an][1]), "+v"(xa[an][2]), "+v"(xa[an][3]));
+        bw_split_pair(xb[n][0], 0, bh[c ^ 1], bl[c ^ 1]); bw_split_pair(xb[n][1], 1, bh[c ^ 1], bl[c ^ 1]);
+    }
+    BW_FENCE();
+    BW_MF16(ah[sk & 1], bl[c], dW[t]);
+    BW_FENCE();
+    if constexpr (more) { bw_split_pair(xb[n][2], 2, bh[c ^ 1], bl[c ^ 1]); bw_split_pair(xb[n][3], 3, bh[c ^ 1], bl[c ^ 1]); }
+    BW_FENCE();
+    BW_MF16(al[sk & 1], bh[c], dW[t]);
+    BW_FENCE();
+    if constexpr (more_a && (t == 1 || t == 2)) {          // (read at t = 0, waited for at t = 1)
+        bw_split_pair(xa[an][2 * (t - 1)], 2 * (t - 1), ah[an], al[an]); bw_split_pair(xa[an][2 * (t - 1) + 1], 2 * (t - 1) + 1, ah[an], al[an]);
+    }
+    if constexpr (more) bw_outer_stage<more ? Q + 1 : 0>(base_a, base_b, xb, xa, bh, bl, ah, al, dW);
+}
+__device__ __forceinline__ void bw_outer_b16(const BwPlane* sD, const BwPlane* sH, int wave, int bn, int bk, f32x16 (&dW)[4]) {
+    f32x2v xb[3][4], xa[2][4];
+    bf16x8 bh[2], bl[2], ah[2], al[2];
+    const unsigned base_b = bw_lds_addr(&sH[bn][8 * bk]), base_a = bw_lds_addr(&sD[32 * wave + bn][8 * bk]);
+    bw_outer_ld<bw_b_off(0)>(base_b, xb[0]); bw_outer_ld<0>(base_a, xa[0]); bw_outer_ld<bw_b_off(1)>(base_b, xb[1]);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[0][2]), "+v"(xb[0][3]), "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bw_split_pair(xb[0][i], i, bh[0], bl[0]); bw_split_pair(xa[0][i], i, ah[0], al[0]); }
+    bw_outer_stage<0>(base_a, base_b, xb, xa, bh, bl, ah, al, dW);
+    BW_FENCE();
+}
+#undef BW_WAIT8
+#undef BW_MF16
+#undef BW_FENCE
+
+// B16 = the mixed form: forward recomputation on the f32-input MFMA (bit-identical masks), the six backward GEMMs on split bf16
+template <bool B16>
 __global__ void __launch_bounds__(256, 1)
 k_uv_backward(UVBwdArgs a) {
     __shared__ float sH1[UV_H][BW_PITCH], sA[UV_H][BW_PITCH], sH2[UV_H][BW_PITCH], sH3[UV_H][BW_PITCH];
@@ -635,7 +801,17 @@ k_uv_backward(UVBwdArgs a) {
         }
         __syncthreads();
         // ---- layer 4: d3 = W4^T d4 . [h2 > 0], dW4 += d4 h2^T
-        {
+        if constexpr (B16) {
+            // ONE A buffer through the backward chain: the outer product needs no A operand, so the next layer's slice is loaded into
+            // the registers the GEMM has just finished with and lands while the outer product runs (RA is dead until the last load:
+            // 64 registers for the hand-pipelined operand conversions)
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm_b16(RB, sH3, bn, bk, c0, c1);
+            bw_load_a(RB, pk, pT + LSTR, lane);                     // W3^T
+            bw_outer_b16(sH3, sH2, wave, bn, bk, dW4);
+            __syncthreads();
+            mask_into(sH2, c0, c1);
+        } else {
             bw_load_a(RA, pk, pT + LSTR, lane);                     // W3^T
             f32x16 c0 = {0.f}, c1 = {0.f};
             bw_gemm(RB, sH3, bn, bk, c0, c1);
@@ -645,7 +821,15 @@ k_uv_backward(UVBwdArgs a) {
         }
         __syncthreads();
         // ---- layer 3
-        {
+        if constexpr (B16) {
+            f32x16 c0 = {0.f}, c1 = {0.f};
+            bw_gemm_b16(RB, sH2, bn, bk, c0, c1);
+            bw_load_a(RB, pk, pT, lane);                            // W2^T
+            bw_outer_b16(sH2, sA, wave, bn, bk, dW3);
+            acc_s[5] += row_sum(sH2);
+            __syncthreads();
+            mask_into(sA, c0, c1);
+        } else {
             bw_load_a(RB, pk, pT, lane);                            // W2^T
             f32x16 c0 = {0.f}, c1 = {0.f};
             bw_gemm(RA, sH2, bn, bk, c0, c1);
@@ -657,10 +841,16 @@ k_uv_backward(UVBwdArgs a) {
         __syncthreads();
         // ---- layer 2
         {
-            bw_load_a(RA, pk, pF, lane);                            // W2, for the next tile
             f32x16 c0 = {0.f}, c1 = {0.f};
-            bw_gemm(RB, sA, bn, bk, c0, c1);
-            bw_outer(sA, sH1, wave, bn, bk, dW2);
+            if constexpr (B16) {
+                bw_gemm_b16(RB, sA, bn, bk, c0, c1);
+                bw_load_a(RA, pk, pF, lane);                        // W2, for the next tile
+                bw_outer_b16(sA, sH1, wave, bn, bk, dW2);
+            } else {
+                bw_load_a(RA, pk, pF, lane);                        // W2, for the next tile
+                bw_gemm(RB, sA, bn, bk, c0, c1);
+                bw_outer(sA, sH1, wave, bn, bk, dW2);
+            }
             acc_s[4] += row_sum(sA);
             __syncthreads();
             mask_into(sH1, c0, c1);
@@ -795,7 +985,8 @@ size_t uv_backward_temp_bytes(int N) {
     return 2 * uv_taylor_temp_bytes() + (size_t)uv_backward_blocks(N) * uv_backward_part_floats() * sizeof(float);
 }
 
-int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, int N, const TexGSUVNetGrad* out, void* temp, hipStream_t s) {
+int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, int N, const TexGSUVNetGrad* out, void* temp, int mixed,
+                       hipStream_t s) {
     const int G = uv_backward_blocks(N);
     float* packed = reinterpret_cast<float*>(temp);
     float* partW = packed + 6 * UV_H * UV_H;
@@ -805,12 +996,19 @@ int launch_uv_backward(const TexGSUVNet* net, const float* xyz, const float* g, 
     if (N <= 0) {                                          // no points: every gradient is zero
         (void)hipMemsetAsync(partW, 0, (size_t)G * uv_backward_part_floats() * sizeof(float), s);
     } else {
-        hipLaunchKernelGGL(k_uv_pack_bwd, dim3(6 * 4 * 64 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4, packed);
+        if (mixed) {        // W2..W4 in f32 A-operand order (forward recomputation), W2^T..W4^T as split bf16
+            hipLaunchKernelGGL(k_uv_pack_bwd, dim3(3 * 4 * 64 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4, packed, 3);
+            hipLaunchKernelGGL(k_uv_pack_bwd_b16, dim3(3 * 4 * 8 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4,
+                               reinterpret_cast<uint4*>(packed + 3 * UV_H * UV_H));
+        } else {
+            hipLaunchKernelGGL(k_uv_pack_bwd, dim3(6 * 4 * 64 * 64 / 256), dim3(256), 0, s, net->W2, net->W3, net->W4, packed, 6);
+        }
         UVBwdArgs a;
         a.W1 = net->W1; a.b1 = net->b1; a.b2 = net->b2; a.emb = net->emb; a.b3 = net->b3; a.b4 = net->b4; a.W5 = net->W5; a.b5 = net->b5;
         a.off = net->xyz_offset; a.scale = net->xyz_scale; a.pk4 = reinterpret_cast<const float4*>(packed); a.xyz = xyz; a.g = g;
         a.N = N; a.n_tiles = (N + BW_P - 1) / BW_P; a.partW = partW; a.partS = partS; a.partB5 = partB5;
-        hipLaunchKernelGGL(k_uv_backward, dim3(G), dim3(256), 0, s, a);
+        if (mixed) hipLaunchKernelGGL(k_uv_backward<true>, dim3(G), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_uv_backward<false>, dim3(G), dim3(256), 0, s, a);
     }
     const int n_out = 3 * UV_H * UV_H + BW_SMALL * UV_H + 3;
     hipLaunchKernelGGL(k_uv_backward_reduce, dim3((n_out + 255) / 256), dim3(256), 0, s, partW, partS, partB5, G, o);

@@ -76,7 +76,7 @@ EXPORTS = ["texgs_abi_version", "texgs_build_id", "texgs_last_error", "texgs_sca
            "texgs_render_forward", "texgs_forward", "texgs_backward", "texgs_backward_render", "texgs_backward_preprocess",
            "texgs_rgb_alpha_loss", "texgs_mark_visible", "texgs_profile_enable", "texgs_tex_bin_count",
            "texgs_profile_read", "texgs_profile_select", "texgs_selftest_waveops", "texgs_geom_losses", "texgs_norm_from_depth", "texgs_uv_taylor", "texgs_uv_taylor_temp_bytes", "texgs_uv_pack", "texgs_uv_taylor_packed",
-           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3", "texgs_uv_backward", "texgs_uv_backward_temp_bytes", "texgs_uv_pack_mixed", "texgs_uv_taylor_packed_mixed"]
+           "texgs_uv_pack_bf16x3", "texgs_uv_taylor_packed_bf16x3", "texgs_uv_backward", "texgs_uv_backward_mixed", "texgs_uv_backward_temp_bytes", "texgs_uv_pack_mixed", "texgs_uv_taylor_packed_mixed"]
 KERNEL_NAMES = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd",
                 "texgrad_reduce"]
 
@@ -150,6 +150,8 @@ def load():
     lib.texgs_uv_backward_temp_bytes.restype = C.c_size_t
     lib.texgs_uv_backward.argtypes = [P(UVNetStruct), C.c_void_p, C.c_void_p, C.c_int32, P(UVNetGradStruct), C.c_void_p, C.c_void_p]
     lib.texgs_uv_backward.restype = C.c_int
+    lib.texgs_uv_backward_mixed.argtypes = lib.texgs_uv_backward.argtypes
+    lib.texgs_uv_backward_mixed.restype = C.c_int
     lib.texgs_selftest_waveops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.texgs_selftest_waveops.restype = C.c_int
     lib.texgs_profile_enable.argtypes = [C.c_int]

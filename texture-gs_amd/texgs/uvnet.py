@@ -231,7 +231,10 @@ class UVNet(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             temp = torch.empty(lib.texgs_uv_backward_temp_bytes(N), dtype=torch.uint8, device=dev)
             gr = _lib.UVNetGradStruct(*[p(t) for t in outs])
-            _lib.check(lib.texgs_uv_backward(C.byref(netp), p(x), p(gg), N, C.byref(gr), p(temp), stream), "texgs_uv_backward")
+            # precision "fp32": all nine GEMMs on the f32-input MFMA; "mixed" / "bf16x3": the forward recomputation in f32 (the
+            # forward launch's ReLU masks bit for bit), the six GEMMs of the backward chain as split-bf16 products (~1e-5 relative)
+            fn = lib.texgs_uv_backward if self.precision == "fp32" else lib.texgs_uv_backward_mixed
+            _lib.check(fn(C.byref(netp), p(x), p(gg), N, C.byref(gr), p(temp), stream), "texgs_uv_backward")
         return outs
 
     def uvs_and_jacobian_with_grad(self, xyz, emb):
