@@ -289,6 +289,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if os.environ.get("TEXGS_BENCH_GC_FREEZE", "1") == "1":
+        # everything allocated so far (torch, the scene, the modules) is long-lived: keep the cyclic collector from walking it when its
+        # oldest generation comes due in the middle of the step loop (measured: ONE 40-60 ms stall, 10-40 ms after the loop starts --
+        # 25 % of a C2 timed region, and able to land in C3's)
+        import gc
+        gc.collect()
+        gc.freeze()
     for _ in range(args.warmup):
         step()
     fence()
@@ -364,7 +371,10 @@ def main():
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, mine)
         rank_table = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "wire": args.wire, "ranks": gathered}
-    step_ms = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
+    step_raw = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
+    step_ms = sorted(step_raw)
+    if os.environ.get("TEXGS_BENCH_STEP_TRACE") and rank == 0:
+        print("step_ms", [round(x, 2) for x in step_raw], file=sys.stderr)
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
     elapsed = t1 - t0
     if dist is not None:
@@ -613,7 +623,7 @@ def main():
                                                     "ms_per_step_on_comm_stream": round(sum(m for _, m in comm) / max(args.steps, 1), 4),
                                                     "world": world} if comm else None)},
             "ms_per_view": round(1e3 * elapsed / (args.steps * args.views_per_step), 4),
-            "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4),
+            "ms_per_step_percentiles": {"p10": round(pct(0.1), 4), "median": round(pct(0.5), 4), "p90": round(pct(0.9), 4), "max": round(pct(1.0), 4), "slowest_step": int(np.argmax(step_raw)),
                                         "source": "torch.cuda.Event per step on the op's stream, this rank"},
             "per_rank": rank_table,
             "reference_call_pattern": compat,

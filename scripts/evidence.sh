@@ -18,6 +18,8 @@ echo "[prof $(( $(date +%s) - T0 )) s]"
 timeout 600 python bench.py > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > gpurun_out/bench_c3_serial.json 2> gpurun_out/bench_c3_serial.err
 timeout 300 python bench.py --streams 4 --no-cpu-baseline --no-kernel-table > gpurun_out/bench_c3_s4.json 2> gpurun_out/bench_c3_s4.err
+timeout 300 python bench.py --prefetch 0 --no-cpu-baseline --no-kernel-table --no-extra-legs > gpurun_out/bench_c3_noprefetch.json 2> gpurun_out/bench_c3_noprefetch.err
+timeout 300 python bench.py --no-cpu-baseline --no-kernel-table --no-extra-legs > gpurun_out/bench_c3_again.json 2> gpurun_out/bench_c3_again.err
 timeout 300 python bench.py --workload c2 --no-cpu-baseline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err
 timeout 300 python bench.py --workload c5 --no-cpu-baseline --steps 8 --warmup 3 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
 timeout 300 python bench.py --surface diff_gauss --no-cpu-baseline > gpurun_out/bench_c3_diff_gauss.json 2> gpurun_out/bench_c3_diff_gauss.err
@@ -34,13 +36,15 @@ bash scripts/prof_ref_pattern.sh > gpurun_out/ref_pattern_profile.txt 2>&1
 echo "[ref pattern $(( $(date +%s) - T0 )) s]"
 bash scripts/prof_iteration.sh > gpurun_out/iteration_profile.txt 2>&1
 echo "[iteration profile $(( $(date +%s) - T0 )) s]"
+bash scripts/prof_uv_backward.sh > gpurun_out/uv_kernels_profile.txt 2>&1
+echo "[uv kernels profile $(( $(date +%s) - T0 )) s]"
 # gpurun copies back at most 64 MiB: the raw per-launch traces and counter tables have been summarised above -- drop them
 find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete
 find gpurun_out -name "*agent_info.csv" -delete; find gpurun_out -name "*.db" -delete; find gpurun_out -name "*.rocpd" -delete
 du -sh gpurun_out | tail -1
 python - <<'PY'
 import json
-for n in ("c3", "c3_serial", "c3_s4", "c2", "c5", "c3_diff_gauss", "c3_rccl1", "c3_R2048", "c3_R2048_serial", "c3_items"):
+for n in ("c3", "c3_again", "c3_noprefetch", "c3_serial", "c3_s4", "c2", "c5", "c3_diff_gauss", "c3_rccl1", "c3_R2048", "c3_R2048_serial", "c3_items"):
     try:
         j = json.loads([l for l in open(f"gpurun_out/bench_{n}.json").read().splitlines() if l.startswith("{")][-1])
         print(n, j["value"], j.get("value_long"), j["ms_per_step_percentiles"]["median"], {k: round(v["avg_us"]) for k, v in j["kernels"].items()},
@@ -61,5 +65,6 @@ PY
 cat gpurun_out/variants.jsonl | cut -c1-400
 cat gpurun_out/ref_pattern_profile.txt | head -50
 cat gpurun_out/iteration_profile.txt | head -34
+grep -E "k_uv_backward|uv_backward_" gpurun_out/uv_kernels_profile.txt | cut -c1-420
 grep -E "k_render|k_texgrad|k_preprocess|k_bin_off|k_radix|k_depth|k_dup|k_ranges|k_tile" gpurun_out/prof_summary.txt | grep calls | head -40
 cat gpurun_out/traffic.json | head -40
