@@ -459,3 +459,66 @@ def test_depth_bin_and_group_arithmetic_of_k2():
         last_bin = cnt[np.concatenate([np.nonzero(opens)[0][1:] - 1, [nb - 1]])]
         assert np.all(sizes < DS_GROUP + np.maximum(last_bin, 1)) and sizes.sum() == n
         assert opens.sum() <= min(n // DS_GROUP + 2, nb)
+
+
+def test_view_pipeline_prefetch_order_with_recorded_streams(monkeypatch):
+    """ViewPipeline.run(prefetch_fn=...): the first view of every stream is begun before the loop, and after each view's forward --
+    BEFORE its backward is queued -- the view that stream renders next, on that stream; every view is begun exactly once; the serial
+    (depth 1) path begins the next view between a view's forward and backward too."""
+    import contextlib
+    import texgs.multiview as MV
+    log = []
+
+    class FakeEvent:
+        def record(self, stream):
+            pass
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_stream(self, other):
+            pass
+
+        def wait_event(self, ev):
+            pass
+    current = [FakeStream("main")]
+
+    @contextlib.contextmanager
+    def fake_stream_ctx(s):
+        current.append(s)
+        try:
+            yield
+        finally:
+            current.pop()
+    monkeypatch.setattr(MV.torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(MV.torch.cuda, "stream", fake_stream_ctx)
+    monkeypatch.setattr(MV.torch.cuda, "current_stream", lambda dev=None: current[-1])
+
+    def run(depth, nviews, ahead=1):
+        log.clear()
+        p = MV.ViewPipeline.__new__(MV.ViewPipeline)
+        p.device = torch.device("cpu")
+        p.streams = [FakeStream(f"s{k}") for k in range(depth)] if depth > 1 else []
+        p.run(list(range(nviews)), lambda v: log.append(("fwd", current[-1].name, v)) or v, lambda v: log.append(("bwd", current[-1].name, v)),
+              sink=None, order="backward", prefetch_fn=lambda v: log.append(("begin", current[-1].name, v)), prefetch_ahead=ahead)
+        return list(log)
+
+    lg = run(3, 7)
+    assert lg[:3] == [("begin", "s0", 0), ("begin", "s1", 1), ("begin", "s2", 2)]
+    for v in range(7):
+        s = f"s{v % 3}"
+        i = lg.index(("fwd", s, v))
+        assert lg.index(("begin", s, v)) < i                                    # begun earlier, on its own stream
+        if v + 3 < 7:
+            assert lg[i + 1] == ("begin", s, v + 3) and lg[i + 2] == ("bwd", s, v)   # the stream's next view, before this view's backward
+        else:
+            assert lg[i + 1] == ("bwd", s, v)
+    assert sorted(e[2] for e in lg if e[0] == "begin") == list(range(7))
+    lg = run(2, 5, ahead=2)                                                       # two views per stream ahead
+    assert lg[:4] == [("begin", "s0", 0), ("begin", "s1", 1), ("begin", "s0", 2), ("begin", "s1", 3)]
+    assert lg[lg.index(("fwd", "s0", 0)) + 1] == ("begin", "s0", 4)
+    assert sorted(e[2] for e in lg if e[0] == "begin") == list(range(5))
+    lg = run(1, 3)                                                                # serial path, the caller's stream
+    assert lg == [("fwd", "main", 0), ("begin", "main", 1), ("bwd", "main", 0), ("fwd", "main", 1), ("begin", "main", 2), ("bwd", "main", 1),
+                  ("fwd", "main", 2), ("bwd", "main", 2)]
