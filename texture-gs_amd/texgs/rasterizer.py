@@ -404,7 +404,8 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         raise ValueError("sh_degree must be in [0,3]")
     H, W = int(st.image_height), int(st.image_width)
     tiles = ((W + _lib.TILE - 1) // _lib.TILE) * ((H + _lib.TILE - 1) // _lib.TILE)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    cur_stream = torch.cuda.current_stream(device)
+    stream = cur_stream.cuda_stream
     keep = [means3D, shs, opacities, scales, rotations, uvs, gradient_uvs, texture, color_offset, cov3D_precomp]
     handoff = bool(for_backward) and not (lazy and LAZY_HANDOFF and unused_streak(device.index) >= 2)
     want_counts = bool(count_bins and USE_TEX_BINS)
@@ -514,7 +515,7 @@ def forward_raw(st, means3D, shs, opacities, scales, rotations, uvs, gradient_uv
         pin = _pin_take(int(lib.texgs_num_rendered_words(N)))
         _lib.check(lib.texgs_num_rendered_begin(C.byref(geom), N, pin.data_ptr(), pin.numel(), 0, stream), "texgs_num_rendered_begin")
         d_ev = torch.cuda.Event()
-        d_ev.record(torch.cuda.current_stream(device))
+        d_ev.record(cur_stream)
         if not candidate:           # K2 behind the event: the host waits for K1 + the copy only, the device goes on sorting
             _lib.check(lib.texgs_depth_sort_scan(C.byref(geom), N, stream), "texgs_depth_sort_scan")
 
@@ -636,6 +637,9 @@ def _late_handoff(s: _State):
     _GEOM_STATS["late_handoffs"] += 1
 
 
+_ITEMSIZE = {torch.float32: 4, torch.int32: 4, torch.int64: 8, torch.int16: 2, torch.uint8: 1, torch.float64: 8}
+
+
 class _Arena:
     """One device allocation carved into named, 256-byte-aligned pieces."""
 
@@ -645,7 +649,7 @@ class _Arena:
     def add(self, name, shape, dtype):
         off = (self.size + 255) & ~255
         self.specs[name] = (off, tuple(shape), dtype)
-        self.size = off + math.prod(shape) * torch.empty(0, dtype=dtype).element_size()
+        self.size = off + math.prod(shape) * _ITEMSIZE[dtype]
 
     def commit(self):
         self.buf = torch.empty(max(self.size, 1), dtype=torch.uint8, device=self.device)
@@ -655,7 +659,7 @@ class _Arena:
 
     def view(self, name):
         off, shape, dtype = self.specs[name]
-        n = math.prod(shape) * torch.empty(0, dtype=dtype).element_size()
+        n = math.prod(shape) * _ITEMSIZE[dtype]
         return self.buf[off:off + n].view(dtype).view(shape)
 
 
