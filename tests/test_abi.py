@@ -66,3 +66,34 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "texgs.h"\nint main(void){return 0;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "c.o")])
+
+
+def test_num_rendered_reduce_is_host_only_arithmetic(lib_built):
+    """texgs_num_rendered_words / texgs_num_rendered_reduce (the second half of the two-step instance-count readback, texgs.h) run on
+    the host: D = sum of K1's per-workgroup partial sums, the fingerprint = the two wrapped 32-bit sums, an instance count past
+    2^32 - 1 is an error, NULL arguments are errors.  (The first half needs a GPU: tests/test_contract_gpu.py.)"""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "texture-gs_amd"))
+    from texgs import _lib
+    lib = _lib.load()
+    for N in (1, 255, 256, 257, 300_000):
+        nblk = (N + 255) // 256
+        assert lib.texgs_num_rendered_words(N) == 3 * nblk
+        rng = np.random.RandomState(N)
+        buf = np.concatenate([rng.randint(0, 5000, nblk), rng.randint(0, 2**32, nblk, dtype=np.int64),
+                              rng.randint(0, 2**32, nblk, dtype=np.int64)]).astype(np.uint32)
+        d, fp = C.c_uint32(0), C.c_uint64(0)
+        rc = lib.texgs_num_rendered_reduce(buf.ctypes.data, N, C.byref(d), C.byref(fp))
+        assert rc == 0
+        assert d.value == int(buf[:nblk].astype(np.uint64).sum())
+        fa = int(buf[nblk:2 * nblk].astype(np.uint64).sum()) & 0xFFFFFFFF
+        fb = int(buf[2 * nblk:].astype(np.uint64).sum()) & 0xFFFFFFFF
+        assert fp.value == (fb << 32) | fa
+    assert lib.texgs_num_rendered_words(0) == 0 and lib.texgs_num_rendered_words(-3) == 0
+    d = C.c_uint32(7)
+    assert lib.texgs_num_rendered_reduce(buf.ctypes.data, 0, C.byref(d), None) == 0 and d.value == 0       # no Gaussians: D = 0
+    big = np.full(3 * 2, 0xFFFFFFFF, dtype=np.uint32)                                                        # two workgroups of 2^32 - 1 each
+    assert lib.texgs_num_rendered_reduce(big.ctypes.data, 512, C.byref(d), None) != 0
+    assert b"2^32" in lib.texgs_last_error()
+    assert lib.texgs_num_rendered_reduce(None, 4, C.byref(d), None) != 0
