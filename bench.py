@@ -265,7 +265,7 @@ def main():
         # issued (it overlaps that view's K8 and the host's end-of-step work); the per-Gaussian half after the last K8
         p.run(batch, view_fwd, view_bwd if with_bwd else None, sink=bucket, order=args.order,
               texture_ready=(lambda evs: bucket.all_reduce_async(dist, seg_tex, after=evs, timing=True)) if two else None,
-              prefetch_fn=view_prefetch if (args.prefetch and p.streams and not untextured) else None,
+              prefetch_fn=view_prefetch if (args.prefetch and p.streams and not untextured and with_bwd) else None,   # (forward-only: nothing to get ahead of)
               prefetch_ahead=int(os.environ.get("TEXGS_BENCH_PREFETCH_AHEAD", "1")))
         if rec is not None:
             ev[1].record()
@@ -611,7 +611,7 @@ def main():
                        "views_per_step_per_gpu": args.views_per_step, "global_views_per_step": args.views_per_step * world,
                        "num_rendered_D": s.D, "D_eff": D_eff, "parallelism": f"views sharded dp{world}",
                        "view_pipeline": (f"{args.streams} HIP streams, order={args.order}"
-                                         + (", forwards begun one view per stream ahead" if (args.prefetch and not untextured) else ""))
+                                         + (", forwards begun one view per stream ahead" if (args.prefetch and not untextured and with_bwd) else ""))
                        if args.streams > 1 else "serial",
                        "view_sharding": "LPT by per-view instance count D" if world > 1 else "all views on the one GPU",
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (host-staged rehearsal)")
